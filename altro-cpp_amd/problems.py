@@ -1,0 +1,194 @@
+"""Problem factories: host-side counterparts of the reference's examples/problems/*.
+
+Each factory configures an already-created ``BatchSolver`` (any implementation of the C-ABI) the way
+the reference's ``UnicycleProblem::MakeProblem`` / ``TripleIntegratorProblem::MakeProblem`` build an
+``altro::problem::Problem`` (examples/problems/unicycle.cpp:11-89, unicycle.hpp:84-92,
+examples/problems/triple_integrator.hpp:22-105), and the ``batch_*`` helpers generate the seeded
+synthetic batches of SURVEY.md section 8(d) (instance 0 is always the exact reference problem).
+
+Quirk Q1 (float time step) is reproduced: ``h = float32(tf) / N`` and the cost weights inherit it.
+"""
+import numpy as np
+
+from . import (CON_CIRCLE, CON_CONTROL_BOUND, CON_GOAL, F32, F64, MODEL_QUADROTOR12,
+               MODEL_TRIPLE_INTEGRATOR, MODEL_UNICYCLE, BatchSolver)
+
+SEED_BASE = 20260927
+
+
+def _f32step(tf, N):
+    return np.float32(np.float32(tf) / np.float32(N))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Unicycle (examples/problems/unicycle.cpp)
+# ---------------------------------------------------------------------------------------------------
+def unicycle_turn90(make, batch=1, N=100, dtype=F64, constraints=True, xf=None, u0=None, **kw):
+    """kTurn90 scenario (unicycle.cpp:17-25, unicycle.hpp:41-55): goal + control bounds +-1.5.
+
+    ``make(n, m, N, batch, dtype)`` returns a BatchSolver-like object.  ``xf`` may be [3] or [B][3].
+    """
+    s = make(3, 2, N, batch, dtype)
+    h = _f32step(3.0, N)
+    hd = float(h)
+    Q = np.eye(3) * (1e-2 * hd)
+    R = np.eye(2) * (1e-2 * hd)
+    Qf = np.eye(3) * 100.0
+    xf = np.array([1.5, 1.5, np.pi / 2]) if xf is None else np.asarray(xf, dtype=np.float64)
+    u0 = np.array([0.1, 0.1]) if u0 is None else np.asarray(u0, dtype=np.float64)
+    uref = np.zeros(2)
+    s.set_model(MODEL_UNICYCLE)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, Q, R, xf, uref)
+    s.set_lqr_cost(N, N + 1, Qf, R * 0, xf, uref)
+    if constraints:
+        s.add_control_bound(0, N, [-1.5, -1.5], [1.5, 1.5])
+        s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(3))
+    U = np.tile(u0, (N, 1)) if u0.ndim == 1 else np.repeat(u0[:, None, :], N, axis=1)
+    s.set_trajectory(None, U)
+    return s
+
+
+THREE_OBSTACLE_CIRCLES = np.array([[0.25 * 3.0, 0.25 * 3.0, 0.425],
+                                   [0.5 * 3.0, 0.5 * 3.0, 0.425],
+                                   [0.75 * 3.0, 0.75 * 3.0, 0.425]])
+
+
+def unicycle_three_obstacles(make, batch=1, N=100, dtype=F64, constraints=True, circles=None, **kw):
+    """kThreeObstacles scenario (unicycle.cpp:27-60): the perf/benchmark_unicycle.cpp problem.
+
+    The circle constraint is added BEFORE the bounds (first in the inequality list), on knots
+    1..N-1; bounds v in [0,3], w in [-3,3] on 0..N-1; goal at N."""
+    s = make(3, 2, N, batch, dtype)
+    h = _f32step(5.0, N)
+    hd = float(h)
+    Q = np.eye(3) * (1.0 * hd)
+    R = np.eye(2) * (0.5 * hd)
+    Qf = np.eye(3) * 10.0
+    xf = np.array([3.0, 3.0, 0.0])
+    uref = np.zeros(2)
+    circles = THREE_OBSTACLE_CIRCLES if circles is None else np.asarray(circles, dtype=np.float64)
+    s.set_model(MODEL_UNICYCLE)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, Q, R, xf, uref)
+    s.set_lqr_cost(N, N + 1, Qf, R * 0, xf, uref)
+    # The reference registers the obstacles even with add_constraints=false (unicycle.cpp:55-59),
+    # but a plain iLQR ignores every constraint (ilqr.hpp:117-119; quirk Q10).  On this ABI "plain
+    # iLQR" means "no constraint registered", so constraints=False registers none.
+    if constraints:
+        s.add_circle_constraint(1, N, circles)
+        s.add_control_bound(0, N, [0.0, -3.0], [3.0, 3.0])
+        s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(3))
+    s.set_trajectory(None, np.full((N, 2), 0.01))
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# Triple integrator (examples/problems/triple_integrator.hpp, test/ilqr/ilqr_test.cpp:29-122)
+# ---------------------------------------------------------------------------------------------------
+def triple_integrator(make, batch=1, N=10, dtype=F64, constraints=False, goal_only=False,
+                      xf=None, h=0.1, **kw):
+    """dof=2 triple integrator.  uref = 0 (quirk Q9: the reference factory leaves it uninitialised;
+    its unit-test fixture uses zeros).  ``goal_only`` reproduces the ilqr_test.cpp fixture (goal
+    constraint at N, no bounds); ``constraints`` reproduces MakeProblem(add_constraints=true)."""
+    dof, n, m = 2, 6, 2
+    s = make(n, m, N, batch, dtype)
+    hf = np.float32(h)
+    Q = np.eye(n)
+    R = np.eye(m) * 1e-3
+    Qf = np.eye(n) * 1e5
+    if xf is None:
+        xf = np.zeros(n)
+        xf[0], xf[1] = 1.0, 2.0
+    xf = np.asarray(xf, dtype=np.float64)
+    x0 = -xf
+    uref = np.zeros(m)
+    s.set_model(MODEL_TRIPLE_INTEGRATOR, [dof])
+    s.set_uniform_step(hf)
+    s.set_lqr_cost(0, N, Q, R, xf, uref)
+    s.set_lqr_cost(N, N + 1, Qf, R * 0, xf, uref)
+    if constraints:
+        ub = np.array([100.0 * (i + 1) for i in range(dof)])
+        s.add_control_bound(0, N, -ub, ub)
+        s.add_constraint(CON_GOAL, N, N + 1, xf)
+    elif goal_only:
+        s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(x0)
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# Quadrotor-like 12-state model (BASELINE config 5; build-defined, no reference counterpart)
+# ---------------------------------------------------------------------------------------------------
+def quadrotor12(make, batch=1, N=200, dtype=F32, xf_pos=None, **kw):
+    n, m = 12, 4
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.02)
+    hd = float(h)
+    Q = np.eye(n) * (1e-2 * hd)
+    R = np.eye(m) * (1e-2 * hd)
+    Qf = np.eye(n) * 100.0
+    if xf_pos is None:
+        xf_pos = np.array([1.0, -1.0, 0.5])
+    xf_pos = np.asarray(xf_pos, dtype=np.float64)
+    xf = np.zeros(xf_pos.shape[:-1] + (n,))
+    xf[..., :3] = xf_pos
+    uref = np.zeros(m)
+    s.set_model(MODEL_QUADROTOR12)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, Q, R, xf, uref)
+    s.set_lqr_cost(N, N + 1, Qf, R * 0, xf, uref)
+    s.add_control_bound(0, N, [-5.0, -3.0, -3.0, -3.0], [5.0, 3.0, 3.0, 3.0])
+    s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# Seeded synthetic batches; instance 0 = the exact reference problem
+# ---------------------------------------------------------------------------------------------------
+def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3):
+    """BASELINE config 3: kTurn90 with per-instance goal xf = (1.5+dx, 1.5+dy, pi/2+dth)."""
+    rng = np.random.default_rng(seed)
+    xf = np.tile(np.array([1.5, 1.5, np.pi / 2]), (batch, 1))
+    if batch > 1:
+        xf[1:, 0] += rng.uniform(-0.5, 0.5, batch - 1)
+        xf[1:, 1] += rng.uniform(-0.5, 0.5, batch - 1)
+        xf[1:, 2] += rng.uniform(-0.3, 0.3, batch - 1)
+    return unicycle_turn90(make, batch=batch, N=N, dtype=dtype, xf=xf)
+
+
+def batch_three_obstacles(make, batch, N=100, dtype=F32, seed=SEED_BASE + 4):
+    """BASELINE config 4: kThreeObstacles with per-instance obstacle centres jittered +-0.1."""
+    rng = np.random.default_rng(seed)
+    circles = np.tile(THREE_OBSTACLE_CIRCLES, (batch, 1, 1))
+    if batch > 1:
+        circles[1:, :, :2] += rng.uniform(-0.1, 0.1, (batch - 1, 3, 2))
+    return unicycle_three_obstacles(make, batch=batch, N=N, dtype=dtype, circles=circles)
+
+
+def batch_triple_integrator(make, batch, N=50, dtype=F64, seed=SEED_BASE + 2):
+    """BASELINE config 2: unconstrained triple integrator, 51 knots, xf[0:2] ~ U([0.5,2]^2)."""
+    rng = np.random.default_rng(seed)
+    xf = np.zeros((batch, 6))
+    xf[:, 0], xf[:, 1] = 1.0, 2.0
+    if batch > 1:
+        xf[1:, :2] = rng.uniform(0.5, 2.0, (batch - 1, 2))
+    return triple_integrator(make, batch=batch, N=N, dtype=dtype, xf=xf)
+
+
+def batch_quadrotor12(make, batch, N=200, dtype=F32, seed=SEED_BASE + 5):
+    """BASELINE config 5: hover-to-hover, xf_p ~ U([-2,2]^3)."""
+    rng = np.random.default_rng(seed)
+    pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
+    if batch > 1:
+        pos[1:] = rng.uniform(-2.0, 2.0, (batch - 1, 3))
+    return quadrotor12(make, batch=batch, N=N, dtype=dtype, xf_pos=pos)
+
+
+def make_hip(n, m, N, batch, dtype, device_id=0):
+    return BatchSolver(n, m, N, batch, dtype, device_id)

@@ -1,0 +1,278 @@
+/*
+ * altro_hip.h — C-ABI of the MI355X-native batched AL-iLQR solver (libaltro_hip.so).
+ *
+ * This header is the drop-in boundary for the hot path of optimusride/altro-cpp
+ * (AltroCpp v0.3.4).  The reference has no FFI layer of its own: its public surface is the C++
+ * classes altro::problem::Problem, altro::ilqr::iLQR<n,m> and
+ * altro::augmented_lagrangian::AugmentedLagrangianiLQR<n,m>, whose extension points are host
+ * virtual functions over Eigen::Ref arguments that a GPU kernel cannot call.  Each entry point
+ * below therefore replaces one method (or group of methods) of those classes; the reference
+ * file:line it replaces is cited next to it.  The header-only C++ facade in include/altro/ keeps
+ * the reference's class and method names on top of this ABI.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an
+ *    altro_status; no exception crosses the boundary.  altro_last_error() gives the text.
+ *  - All host arrays exchanged over the ABI are IEEE fp64, caller-owned, and are copied during
+ *    the call.  The device computes in the dtype chosen at altro_create (fp64 or fp32).
+ *  - NEW relative to the reference: a batch of B independent problem instances per handle.
+ *    Host layout is instance-major, then knot point, then Eigen column-major matrix:
+ *    X[b][k][i] (k = 0..N), U[b][k][j] (k = 0..N-1), K[b][k][col][row] with K being m x n
+ *    (what KnotPointFunctions::GetFeedbackGain() returns per knot,
+ *    altro/ilqr/knot_point_function_type.hpp:265).
+ *  - "N" is the number of SEGMENTS, as in the reference (altro/ilqr/ilqr.hpp:788); the
+ *    trajectory has N+1 knot points.
+ *  - The time step is a 32-bit float, as in the reference (altro/common/knotpoint.hpp:179-180,
+ *    altro/common/trajectory.hpp:122-130); it is promoted to the compute dtype inside RK4.
+ *  - A handle is bound to one device and one HIP stream; calls on one handle must be serialised
+ *    by the caller, distinct handles are independent.  solve calls are synchronous.
+ *  - The product has NO CPU fallback: every compute entry point fails with ALTRO_HIP_ERROR if no
+ *    HIP device is usable.
+ */
+#ifndef ALTRO_HIP_H_
+#define ALTRO_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct altro_solver_s* altro_handle;
+
+typedef enum altro_status {
+  ALTRO_OK = 0,
+  ALTRO_INVALID_ARG = 1,
+  ALTRO_HIP_ERROR = 2,
+  ALTRO_NOT_READY = 3,
+  ALTRO_UNSUPPORTED = 4
+} altro_status;
+
+/* Arithmetic type used on the device. */
+typedef enum altro_dtype { ALTRO_F64 = 0, ALTRO_F32 = 1 } altro_dtype;
+
+/* Closed registry of continuous-time models, all discretised with RK4
+ * (altro/problem/integration.hpp:123-169 via altro/problem/discretized_model.hpp:36-45). */
+typedef enum altro_model_kind {
+  ALTRO_MODEL_UNICYCLE = 1,          /* examples/unicycle.cpp:12-33, n=3 m=2 */
+  ALTRO_MODEL_TRIPLE_INTEGRATOR = 2, /* examples/triple_integrator.cpp:9-33, n=3*dof m=dof */
+  ALTRO_MODEL_QUADROTOR12 = 3        /* build-defined 12-state/4-control model (BASELINE config 5) */
+} altro_model_kind;
+
+/* Closed registry of constraints (examples/basic_constraints.hpp, obstacle_constraints.hpp). */
+typedef enum altro_constraint_kind {
+  ALTRO_CON_GOAL = 1,          /* equality   c = x - xf          basic_constraints.hpp:15-40   */
+  ALTRO_CON_CONTROL_BOUND = 2, /* inequality c = [lb-u; u-ub]    basic_constraints.hpp:42-151  */
+  ALTRO_CON_CIRCLE = 3         /* inequality c_i = r^2 - |p-c_i|^2  obstacle_constraints.hpp:69-127 */
+} altro_constraint_kind;
+
+/* altro::SolverStatus, altro/common/solver_stats.hpp:20-31 (same numeric values). */
+typedef enum altro_solver_status {
+  ALTRO_SOLVED = 0,
+  ALTRO_UNSOLVED = 1,
+  ALTRO_STATE_LIMIT = 2,
+  ALTRO_CONTROL_LIMIT = 3,
+  ALTRO_COST_INCREASE = 4,
+  ALTRO_MAX_ITERATIONS = 5,
+  ALTRO_MAX_OUTER_ITERATIONS = 6,
+  ALTRO_MAX_INNER_ITERATIONS = 7,
+  ALTRO_MAX_PENALTY = 8,
+  ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED = 9
+} altro_solver_status;
+
+typedef struct altro_desc {
+  int n;         /* state dimension   */
+  int m;         /* control dimension */
+  int N;         /* number of segments (N+1 knot points) */
+  int batch;     /* number of independent problem instances */
+  int dtype;     /* altro_dtype */
+  int device_id; /* HIP device ordinal */
+} altro_desc;
+
+/* altro::SolverOptions, altro/common/solver_options.hpp:19-57, field for field (bools as int).
+ * Console/profiler-file fields are host-only in the reference and are not mirrored. */
+typedef struct altro_options {
+  int max_iterations_total;          /* 300  */
+  int max_iterations_outer;          /* 30   */
+  int max_iterations_inner;          /* 100  */
+  double cost_tolerance;             /* 1e-4 */
+  double gradient_tolerance;         /* 1e-2 */
+  double bp_reg_increase_factor;     /* 1.6  */
+  int bp_reg_enable;                 /* 1 (declared but never read by the reference) */
+  double bp_reg_initial;             /* 0.0  */
+  double bp_reg_max;                 /* 1e8  */
+  double bp_reg_min;                 /* 1e-8 */
+  int bp_reg_fail_threshold;         /* 100  */
+  int check_forwardpass_bounds;      /* 1    */
+  double state_max;                  /* 1e8  */
+  double control_max;                /* 1e8  */
+  int line_search_max_iterations;    /* 20   */
+  double line_search_lower_bound;    /* 1e-8 */
+  double line_search_upper_bound;    /* 10.0 */
+  double line_search_decrease_factor;/* 2    */
+  double constraint_tolerance;       /* 1e-4 */
+  double maximum_penalty;            /* 1e8  */
+  double initial_penalty;            /* 1.0  */
+  int reset_duals;                   /* 1    */
+  int profiler_enable;               /* 0: when 1, per-section device timings are recorded */
+} altro_options;
+
+/* Per-instance result record: the scalar members of altro::SolverStats
+ * (altro/common/solver_stats.hpp:52-63) plus the `.back()` value of each logged vector. */
+typedef struct altro_stats {
+  int status;           /* AL status after altro_solve_al, iLQR status after altro_solve_ilqr */
+  int status_ilqr;      /* status of the inner iLQR solver (ilqr.hpp:164) */
+  int iterations_inner; /* of the last inner solve */
+  int iterations_outer;
+  int iterations_total;
+  int reserved;
+  double cost;              /* stats.cost.back()            */
+  double initial_cost;      /* stats.initial_cost           */
+  double cost_decrease;     /* stats.cost_decrease.back()   */
+  double gradient;          /* stats.gradient.back()        */
+  double violation;         /* stats.violations.back()      */
+  double max_penalty;       /* stats.max_penalty.back()     */
+  double alpha;             /* stats.alpha.back()           */
+  double regularization;    /* stats.regularization.back()  */
+  double improvement_ratio; /* stats.improvement_ratio.back() ("z") */
+} altro_stats;
+
+/* Device timing of the last solve, section names after the reference's profiler tree
+ * (altro/ilqr/ilqr.hpp:294,351,386,513; altro/augmented_lagrangian/al_solver.hpp:289,309). */
+typedef struct altro_timing {
+  double total_ms;         /* "al" or "ilqr": wall time of the solve call                   */
+  double init_ms;          /* "init": AL Init + first rollout/cost                          */
+  double expansions_ms;    /* sum over sweeps of the expansions kernel (HIP events)         */
+  double backward_pass_ms; /* sum over sweeps of the backward-pass kernel                   */
+  double forward_pass_ms;  /* sum over sweeps of the forward-pass (+AL update) kernel       */
+  int sweeps;              /* number of batched iLQR sweeps launched                        */
+  int launches;            /* number of kernel launches                                     */
+  long long instance_iterations; /* sum over instances of iterations_total                  */
+} altro_timing;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Replaces AugmentedLagrangianiLQR<n,m>(int N) / iLQR<n,m>(int N)
+ * (al_solver.hpp:35, ilqr.hpp:50-55) with a batch dimension. */
+altro_status altro_create(const altro_desc* desc, altro_handle* out);
+void altro_destroy(altro_handle h);
+/* Text of the last error on this handle (or of the last failed altro_create when h == NULL). */
+const char* altro_last_error(altro_handle h);
+/* Fill *opts with the reference defaults (solver_options.hpp:23-56). */
+void altro_default_options(altro_options* opts);
+
+/* ---- problem definition (replaces altro::problem::Problem setters, problem.hpp:113-202) ------- */
+
+/* Problem::SetDynamics for all k with DiscretizedModel<Model, RungeKutta4> (problem.hpp:155-166).
+ * params: TRIPLE_INTEGRATOR -> {dof}; UNICYCLE -> none; QUADROTOR12 -> none. */
+altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams);
+
+/* Trajectory::SetUniformStep (trajectory.hpp:122-130). */
+altro_status altro_set_uniform_step(altro_handle h, float hstep);
+
+/* Problem::SetCostFunction(QuadraticCost::LQRCost(Q,R,xref,uref,terminal), k) for
+ * k_begin <= k < k_end (problem.hpp:113-127, examples/quadratic_cost.hpp:29-39).
+ * Q is n x n, R is m x m (column-major).  per_instance bit 0: xref is [B][n] instead of [n];
+ * bit 1: uref is [B][m] instead of [m]. */
+altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const double* Q,
+                                const double* R, const double* xref, const double* uref,
+                                int per_instance);
+
+/* Problem::SetConstraint(con, k) for k_begin <= k < k_end (problem.hpp:178-202).  Insertion order
+ * is kept: at each knot the AL cost visits all equalities, then all inequalities, each in
+ * insertion order (al_cost.hpp:267-272).
+ *   GOAL:          params = xf[n]                         (per_instance: [B][n])
+ *   CONTROL_BOUND: params = lb[m], ub[m]  (+-inf allowed; only finite bounds produce rows)
+ *   CIRCLE:        params = (cx, cy, r) x nobs            (per_instance: [B][3*nobs])
+ * nparams is the length of ONE instance's block. */
+altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_end,
+                                  const double* params, int nparams, int per_instance);
+
+/* Problem::SetInitialState (problem.hpp:100-106).  per_instance: x0 is [B][n] instead of [n]. */
+altro_status altro_set_initial_state(altro_handle h, const double* x0, int per_instance);
+
+/* iLQR::SetTrajectory (ilqr.hpp:231-235): initial guess.  X may be NULL (zeros); U is [N][m] or,
+ * with per_instance, [B][N][m] (X: [N+1][n] / [B][N+1][n]). */
+altro_status altro_set_trajectory(altro_handle h, const double* X, const double* U,
+                                  int per_instance);
+
+/* solver.GetOptions() (al_solver.hpp:44, ilqr.hpp:161). */
+altro_status altro_set_options(altro_handle h, const altro_options* opts);
+altro_status altro_get_options(altro_handle h, altro_options* opts);
+
+/* AugmentedLagrangianiLQR::SetPenalty / SetPenaltyScaling (al_solver.hpp:271-285). */
+altro_status altro_set_penalty(altro_handle h, double rho);
+altro_status altro_set_penalty_scaling(altro_handle h, double phi);
+
+/* ---- solves ---------------------------------------------------------------------------------- */
+
+/* AugmentedLagrangianiLQR::Solve (al_solver.hpp:304-334) for every instance. */
+altro_status altro_solve_al(altro_handle h);
+/* iLQR::Solve (ilqr.hpp:284-316) on the AL cost with the current duals/penalties. */
+altro_status altro_solve_ilqr(altro_handle h);
+
+/* ---- step-level entry points (used by the parity tests the way the reference tests use the
+ *      public methods of iLQR / AugmentedLagrangianiLQR) ---------------------------------------- */
+altro_status altro_al_init(altro_handle h);            /* AL Init           al_solver.hpp:287-302 */
+altro_status altro_solve_setup(altro_handle h);        /* iLQR::SolveSetup  ilqr.hpp:629-645      */
+altro_status altro_rollout(altro_handle h);            /* iLQR::Rollout     ilqr.hpp:453-459      */
+altro_status altro_cost(altro_handle h, double* J);    /* iLQR::Cost        ilqr.hpp:326-334; J[B] may be NULL */
+altro_status altro_update_expansions(altro_handle h);  /* iLQR::UpdateExpansions ilqr.hpp:350-366 */
+altro_status altro_backward_pass(altro_handle h);      /* iLQR::BackwardPass     ilqr.hpp:385-445 */
+altro_status altro_forward_pass(altro_handle h);       /* iLQR::ForwardPass      ilqr.hpp:512-558 */
+altro_status altro_update_convergence_statistics(altro_handle h); /* ilqr.hpp:568-587 */
+altro_status altro_update_duals(altro_handle h);       /* al_solver.hpp:336-345 */
+altro_status altro_update_penalties(altro_handle h);   /* al_solver.hpp:347-355 */
+/* GetMaxViolation (stored c_, al_solver.hpp:417-424) / MaxViolation (re-evaluates the cost first,
+ * al_solver.hpp:403-408) / GetMaxPenalty (al_solver.hpp:426-434); out[B]. */
+altro_status altro_get_max_violation(altro_handle h, double* out);
+altro_status altro_max_violation(altro_handle h, double* out);
+altro_status altro_get_max_penalty(altro_handle h, double* out);
+
+/* ---- results --------------------------------------------------------------------------------- */
+altro_status altro_get_trajectory(altro_handle h, double* X, double* U); /* ilqr.hpp:140 */
+/* GetFeedbackGain / GetFeedforwardGain (knot_point_function_type.hpp:265-268): K[B][N][n][m]
+ * column-major m x n per knot, d[B][N][m]. */
+altro_status altro_get_gains(altro_handle h, double* K, double* d);
+/* GetCostToGoHessian / Gradient (knot_point_function_type.hpp:254-255): P[B][N+1][n*n],
+ * p[B][N+1][n].  Only recorded for every knot when altro_set_record_ctg(h, 1) was called. */
+altro_status altro_set_record_ctg(altro_handle h, int enable);
+altro_status altro_get_ctg(altro_handle h, double* P, double* p);
+/* GetDynamicsExpansion / GetCostExpansion of knot k (knot_point_function_type.hpp:249-252):
+ * AB[B][n*(n+m)] column-major n x (n+m); lxx[B][n*n], lxu[B][n*m], luu[B][m*m], lx[B][n],
+ * lu[B][m].  Any pointer may be NULL. */
+altro_status altro_get_expansion(altro_handle h, int k, double* AB, double* lxx, double* lxu,
+                                 double* luu, double* lx, double* lu);
+/* costs_ (ilqr.hpp:163): costs[B][N+1]. */
+altro_status altro_get_knot_costs(altro_handle h, double* costs);
+/* Total number of constraint rows of one instance (al_solver.hpp:262-269) and at knot k. */
+int altro_num_constraints(altro_handle h);
+int altro_num_constraints_at(altro_handle h, int k);
+/* Duals / penalties / stored constraint values, [B][rows]; rows ordered by knot, then equalities,
+ * then inequalities, each in insertion order (constraint_values.hpp:58-60). */
+altro_status altro_get_duals(altro_handle h, double* lambda);
+altro_status altro_set_duals(altro_handle h, const double* lambda);
+altro_status altro_get_penalties(altro_handle h, double* rho);
+altro_status altro_get_constraint_values(altro_handle h, double* c);
+altro_status altro_get_stats(altro_handle h, altro_stats* stats /*[B]*/);
+altro_status altro_get_timing(altro_handle h, altro_timing* t);
+
+/* Per-iteration history of one instance (SolverStats vectors, solver_stats.hpp:56-63).  Recording
+ * is off by default; altro_set_record_history(h, capacity) allocates capacity rows per instance.
+ * field: 0 cost, 1 alpha, 2 improvement_ratio, 3 gradient, 4 cost_decrease, 5 regularization,
+ * 6 violations, 7 max_penalty.  Returns the number of rows written to out (<= cap). */
+altro_status altro_set_record_history(altro_handle h, int capacity);
+int altro_get_history(altro_handle h, int instance, int field, double* out, int cap);
+
+/* ---- device interop (multi-GPU gather without a host round trip) ------------------------------ */
+/* Pack {cost, violation, iterations_total, status} as 4 fp64 per instance into caller-provided
+ * DEVICE memory dst[B][4] on this handle's device (e.g. a torch tensor's data_ptr) so it can be
+ * fed to an RCCL all_gather. */
+altro_status altro_pack_results_device(altro_handle h, void* dst_device);
+/* Device name and multiprocessor count of the handle's device. */
+altro_status altro_device_info(altro_handle h, char* name, int name_len, int* cu_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALTRO_HIP_H_ */

@@ -1,0 +1,1438 @@
+// oracle/altro_oracle.cpp
+//
+// TEST INFRASTRUCTURE ONLY.  CPU restatement of the AL-iLQR hot path of optimusride/altro-cpp
+// (AltroCpp v0.3.4).  It is the parity checker for the HIP product and the timed "port" CPU
+// baseline of bench.py.  Nothing under altro-cpp_amd/ or include/altro/ may include, link or call
+// this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+//
+// The reference itself cannot be compiled in this image (it hard-requires Eigen >= 3.3 and
+// fmt 6.1.2, neither of which is installed and neither of which is vendored:
+// /root/reference/CMakeLists.txt:50-57), so this file restates the algorithm in plain C++17 with
+// explicit loops, following the reference file:line cited at each function.  PARITY IS PINNED:
+// tests/test_oracle_reference_constants.py checks this restatement against every known-answer
+// constant the reference's own tests hold for the path (the
+// constants are data copied into tests/golden/reference_constants.json with their test file:line).
+//
+// Arithmetic: IEEE fp64 (or fp32 when the handle is created with ALTRO_F32) except the time step
+// h, which is a 32-bit float exactly as in the reference (altro/common/knotpoint.hpp:179-180).
+// All reference quirks Q1-Q12 of SURVEY.md section 8(a) are reproduced on purpose.
+//
+// The C API below mirrors include/altro_hip.h one-to-one with the prefix `oracle_` so that the
+// parity tests drive both implementations through the same Python code.
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/altro_hip.h"  // POD structs and enums only
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Continuous-time models.  jac is n x (n+m), column-major, fully written.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct UnicycleModel {  // examples/unicycle.cpp:12-33
+  static constexpr int n = 3, m = 2;
+  int dof = 0;
+  void f(const T* x, const T* u, T* xd) const {
+    T theta = x[2], v = u[0], omega = u[1];
+    xd[0] = v * std::cos(theta);
+    xd[1] = v * std::sin(theta);
+    xd[2] = omega;
+  }
+  void jac(const T* x, const T* u, T* J) const {
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+    T theta = x[2], v = u[0];
+    J[0 + 2 * n] = -v * std::sin(theta);
+    J[0 + 3 * n] = std::cos(theta);
+    J[1 + 2 * n] = v * std::cos(theta);
+    J[1 + 3 * n] = std::sin(theta);
+    J[2 + 4 * n] = T(1);
+  }
+};
+
+template <class T, int DOF>
+struct TripleIntegratorModel {  // examples/triple_integrator.cpp:9-33
+  static constexpr int n = 3 * DOF, m = DOF;
+  void f(const T* x, const T* u, T* xd) const {
+    for (int i = 0; i < DOF; ++i) {
+      xd[i] = x[i + DOF];
+      xd[i + DOF] = x[i + 2 * DOF];
+      xd[i + 2 * DOF] = u[i];
+    }
+  }
+  void jac(const T*, const T*, T* J) const {
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+    for (int i = 0; i < DOF; ++i) {
+      J[i + (i + DOF) * n] = T(1);
+      J[(i + DOF) + (i + 2 * DOF) * n] = T(1);
+      J[(i + 2 * DOF) + (i + 3 * DOF) * n] = T(1);
+    }
+  }
+};
+
+// Build-defined 12-state / 4-control "quadrotor-like" model for BASELINE config 5 (the reference
+// has no such model; parity for it is oracle-vs-GPU only).  State x = (p[3], phi[3], v[3], w[3]),
+// control u = (a, tau[3]): small-angle attitude, gravity linearised about hover, with the
+// bilinear attitude x thrust coupling kept:
+//   p' = v,  phi' = w,  v' = ((g + a) * phi_y, -(g + a) * phi_x, a),  w' = tau.
+template <class T>
+struct Quadrotor12Model {
+  static constexpr int n = 12, m = 4;
+  static constexpr double g = 9.81;
+  void f(const T* x, const T* u, T* xd) const {
+    T a = u[0];
+    for (int i = 0; i < 3; ++i) {
+      xd[i] = x[6 + i];
+      xd[3 + i] = x[9 + i];
+      xd[9 + i] = u[1 + i];
+    }
+    xd[6] = (T(g) + a) * x[4];
+    xd[7] = -(T(g) + a) * x[3];
+    xd[8] = a;
+  }
+  void jac(const T* x, const T* u, T* J) const {
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+    T a = u[0];
+    for (int i = 0; i < 3; ++i) {
+      J[i + (6 + i) * n] = T(1);
+      J[(3 + i) + (9 + i) * n] = T(1);
+      J[(9 + i) + (n + 1 + i) * n] = T(1);
+    }
+    J[6 + 4 * n] = T(g) + a;
+    J[7 + 3 * n] = -(T(g) + a);
+    J[6 + n * n] = x[4];
+    J[7 + n * n] = -x[3];
+    J[8 + n * n] = T(1);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Host-side problem specification (dtype independent, fp64).
+// ------------------------------------------------------------------------------------------------
+struct CostSpec {
+  int k_begin, k_end;
+  std::vector<double> Q, R, xref, uref;
+  int per_instance;
+};
+struct ConSpec {
+  int kind, k_begin, k_end, nparams, per_instance;
+  std::vector<double> params;
+};
+
+// SolverStats Log / NewIteration semantics (altro/common/solver_stats.hpp:133-136,192-203,
+// solver_stats.cpp:31-66): every Log writes the LAST row; NewIteration appends a copy of it.
+enum Field { F_COST = 0, F_ALPHA, F_Z, F_GRAD, F_DJ, F_REG, F_VIOL, F_PEN, F_COUNT };
+struct Stats {
+  double initial_cost = 0.0;
+  int iterations_inner = 0, iterations_outer = 0, iterations_total = 0;
+  int len = 0;
+  std::vector<double> v[F_COUNT];
+  void Reset() {
+    initial_cost = 0.0;
+    iterations_inner = iterations_outer = iterations_total = 0;
+    len = 0;
+    for (auto& x : v) x.clear();
+  }
+  void NewIteration() {
+    len++;
+    for (auto& x : v) {
+      x.resize(len);
+      x.back() = (len > 1) ? x[len - 2] : 0.0;
+    }
+  }
+  void Touch() {  // Log of a non-float entry ("iters", "iter_al") still registers the first row
+    if (len == 0) NewIteration();
+  }
+  void Log(Field f, double value) {
+    if (len == 0) NewIteration();
+    v[f].back() = value;
+  }
+  double Back(Field f) const { return v[f].empty() ? 0.0 : v[f].back(); }
+};
+
+struct SolverBase {
+  virtual ~SolverBase() {}
+  virtual void AlInit() = 0;
+  virtual void SolveSetup() = 0;
+  virtual void Rollout() = 0;
+  virtual double Cost() = 0;
+  virtual void UpdateExpansions() = 0;
+  virtual void BackwardPass() = 0;
+  virtual void ForwardPass() = 0;
+  virtual void UpdateConvergenceStatistics() = 0;
+  virtual void UpdateDuals() = 0;
+  virtual void UpdatePenalties() = 0;
+  virtual double GetMaxViolation() = 0;
+  virtual double MaxViolation() = 0;
+  virtual double GetMaxPenalty() = 0;
+  virtual void SolveILQR() = 0;
+  virtual void SolveAL() = 0;
+  virtual void SetPenalty(double rho) = 0;
+  virtual void SetPenaltyScaling(double phi) = 0;
+  virtual void SetTrajectory(const double* X, const double* U) = 0;
+  virtual void SetInitialState(const double* x0) = 0;
+  virtual void GetTrajectory(double* X, double* U) = 0;
+  virtual void GetGains(double* K, double* d) = 0;
+  virtual void GetCtg(double* P, double* p) = 0;
+  virtual void GetExpansion(int k, double* AB, double* lxx, double* lxu, double* luu, double* lx,
+                            double* lu) = 0;
+  virtual void GetKnotCosts(double* c) = 0;
+  virtual int NumRows() = 0;
+  virtual int NumRowsAt(int k) = 0;
+  virtual void GetDuals(double* out) = 0;
+  virtual void SetDuals(const double* in) = 0;
+  virtual void GetPenalties(double* out) = 0;
+  virtual void GetConVals(double* out) = 0;
+  virtual void GetStats(altro_stats* s) = 0;
+  virtual Stats& RawStats() = 0;
+  altro_options opts;
+};
+
+// ------------------------------------------------------------------------------------------------
+// One problem instance.
+// ------------------------------------------------------------------------------------------------
+template <class T, class Model>
+struct Instance final : SolverBase {
+  static constexpr int n = Model::n, m = Model::m, nm = n + m;
+  Model model;
+  int N;
+  std::vector<float> h;  // N+1 entries, h[N] = 0 (trajectory.hpp:122-130)
+
+  struct QCost {  // examples/quadratic_cost.hpp:13-27
+    T Q[n * n], R[m * m], H[n * m], q[n], r[m], c;
+  };
+  struct Con {  // altro/constraints/constraint_values.hpp:39-51
+    int kind, type /*0 equality, 1 inequality*/, p;
+    std::vector<T> par;         // GOAL: xf[n]; CIRCLE: (cx,cy,r)*; BOUND: finite lb values, finite ub values
+    std::vector<int> lo, hi;    // BOUND: finite index lists (basic_constraints.hpp:138-145)
+    std::vector<T> c, lam, pen; // c_, lambda_, penalty_
+    T phi = T(10);              // kDefaultPenaltyScaling, constraint_values.hpp:30
+  };
+  std::vector<QCost> cost;             // N+1
+  std::vector<std::vector<Con>> cons;  // N+1, equalities first then inequalities (al_cost.hpp:267-272)
+
+  std::vector<T> x0;
+  std::vector<T> X, U, Xb, Ub;  // (N+1)*n, (N+1)*m (u_N == 0)
+  // expansions
+  std::vector<T> AB, lxx, lxu, luu, lx, lu, costs;
+  // gains and cost-to-go (knot_point_function_type.hpp:293-298)
+  std::vector<T> K, d, P, p;
+  T deltaV[2] = {0, 0};
+  T rho_ = 0, drho_ = 0;
+  int status_ = ALTRO_UNSOLVED;     // iLQR status_ (ilqr.hpp:798)
+  int status_al_ = ALTRO_UNSOLVED;  // AL status_ (al_solver.hpp:222)
+  Stats stats;
+
+  Instance(int N_, const Model& mdl) : model(mdl), N(N_) {
+    h.assign(N + 1, 0.0f);
+    cost.resize(N + 1);
+    cons.resize(N + 1);
+    x0.assign(n, T(0));
+    X.assign((N + 1) * n, T(0));
+    U.assign((N + 1) * m, T(0));
+    Xb = X;
+    Ub = U;
+    AB.assign((N + 1) * n * nm, T(0));
+    lxx.assign((N + 1) * n * n, T(0));
+    lxu.assign((N + 1) * n * m, T(0));
+    luu.assign((N + 1) * m * m, T(0));
+    lx.assign((N + 1) * n, T(0));
+    lu.assign((N + 1) * m, T(0));
+    costs.assign(N + 1, T(0));
+    K.assign((N + 1) * m * n, T(0));  // zero-initialised: knot_point_function_type.hpp:271-278
+    d.assign((N + 1) * m, T(0));
+    P.assign((N + 1) * n * n, T(0));
+    p.assign((N + 1) * n, T(0));
+    altro_options o;
+    std::memset(&o, 0, sizeof(o));
+    opts = o;
+  }
+  Stats& RawStats() override { return stats; }
+
+  // ---- problem definition -----------------------------------------------------------------
+  void SetLQRCost(int k, const double* Q, const double* R, const double* xref, const double* uref) {
+    // QuadraticCost::LQRCost, examples/quadratic_cost.hpp:29-39
+    QCost& c = cost[k];
+    for (int i = 0; i < n * n; ++i) c.Q[i] = T(Q[i]);
+    for (int i = 0; i < m * m; ++i) c.R[i] = T(R[i]);
+    for (int i = 0; i < n * m; ++i) c.H[i] = T(0);
+    T xr[n], ur[m], Qx[n], Ru[m];
+    for (int i = 0; i < n; ++i) xr[i] = T(xref[i]);
+    for (int i = 0; i < m; ++i) ur[i] = T(uref[i]);
+    for (int i = 0; i < n; ++i) {
+      T s = 0;
+      for (int j = 0; j < n; ++j) s += c.Q[i + j * n] * xr[j];
+      Qx[i] = s;
+      c.q[i] = -s;
+    }
+    for (int i = 0; i < m; ++i) {
+      T s = 0;
+      for (int j = 0; j < m; ++j) s += c.R[i + j * m] * ur[j];
+      Ru[i] = s;
+      c.r[i] = -s;
+    }
+    T a = 0, b = 0;
+    for (int i = 0; i < n; ++i) a += xr[i] * Qx[i];
+    for (int i = 0; i < m; ++i) b += ur[i] * Ru[i];
+    c.c = T(0.5) * a + T(0.5) * b;
+  }
+  void AddConstraint(int k, int kind, const double* par, int npar) {
+    Con c;
+    c.kind = kind;
+    if (kind == ALTRO_CON_GOAL) {
+      c.type = 0;
+      c.p = n;
+      c.par.resize(n);
+      for (int i = 0; i < n; ++i) c.par[i] = T(par[i]);
+    } else if (kind == ALTRO_CON_CONTROL_BOUND) {
+      c.type = 1;
+      // GetFiniteIndices, basic_constraints.hpp:138-145
+      for (int j = 0; j < m; ++j)
+        if (std::abs(par[j]) < std::numeric_limits<double>::max()) c.lo.push_back(j);
+      for (int j = 0; j < m; ++j)
+        if (std::abs(par[m + j]) < std::numeric_limits<double>::max()) c.hi.push_back(j);
+      for (int j : c.lo) c.par.push_back(T(par[j]));
+      for (int j : c.hi) c.par.push_back(T(par[m + j]));
+      c.p = (int)(c.lo.size() + c.hi.size());
+    } else {  // CIRCLE
+      c.type = 1;
+      c.p = npar / 3;
+      c.par.resize(npar);
+      for (int i = 0; i < npar; ++i) c.par[i] = T(par[i]);
+    }
+    c.c.assign(c.p, T(0));
+    c.lam.assign(c.p, T(0));
+    c.pen.assign(c.p, T(1));  // penalty_.setOnes, constraint_values.hpp:44
+    // keep equalities before inequalities, insertion order within each (al_cost.hpp:267-272)
+    std::vector<Con>& v = cons[k];
+    if (c.type == 0) {
+      size_t pos = 0;
+      while (pos < v.size() && v[pos].type == 0) ++pos;
+      v.insert(v.begin() + pos, std::move(c));
+    } else {
+      v.push_back(std::move(c));
+    }
+  }
+  void SetInitialState(const double* x) override {
+    for (int i = 0; i < n; ++i) x0[i] = T(x[i]);
+  }
+  void SetTrajectory(const double* Xin, const double* Uin) override {
+    for (int i = 0; i < (N + 1) * n; ++i) X[i] = Xin ? T(Xin[i]) : T(0);
+    for (int i = 0; i < (N + 1) * m; ++i) U[i] = T(0);
+    if (Uin)
+      for (int i = 0; i < N * m; ++i) U[i] = T(Uin[i]);
+    // SetTrajectory: Zbar_ = copy of Z_, SetZero (ilqr.hpp:231-235)
+    std::fill(Xb.begin(), Xb.end(), T(0));
+    std::fill(Ub.begin(), Ub.end(), T(0));
+  }
+
+  // ---- constraint evaluation ---------------------------------------------------------------
+  // con_->Evaluate (basic_constraints.hpp:27-31,98-111; obstacle_constraints.hpp:99-107)
+  static void ConEval(Con& c, const T* x, const T* u) {
+    if (c.kind == ALTRO_CON_GOAL) {
+      for (int i = 0; i < n; ++i) c.c[i] = x[i] - c.par[i];
+    } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
+      int nl = (int)c.lo.size();
+      for (int i = 0; i < nl; ++i) c.c[i] = c.par[i] - u[c.lo[i]];
+      for (size_t i = 0; i < c.hi.size(); ++i) c.c[nl + i] = u[c.hi[i]] - c.par[nl + i];
+    } else {
+      T px = x[0], py = x[1];
+      for (int i = 0; i < c.p; ++i) {
+        T dx = px - c.par[3 * i], dy = py - c.par[3 * i + 1], r = c.par[3 * i + 2];
+        c.c[i] = -(dx * dx + dy * dy - r * r);  // -Distance2, obstacle_constraints.hpp:42-44
+      }
+    }
+  }
+  // con_->Jacobian; jac is p x (n+m), row r at jac[r*nm .. r*nm+nm)
+  static void ConJac(const Con& c, const T* x, const T*, T* jac) {
+    for (int i = 0; i < c.p * nm; ++i) jac[i] = T(0);
+    if (c.kind == ALTRO_CON_GOAL) {
+      for (int i = 0; i < n; ++i) jac[i * nm + i] = T(1);
+    } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
+      int nl = (int)c.lo.size();
+      for (int i = 0; i < nl; ++i) jac[i * nm + n + c.lo[i]] = T(-1);
+      for (size_t i = 0; i < c.hi.size(); ++i) jac[(nl + i) * nm + n + c.hi[i]] = T(1);
+    } else {
+      T px = x[0], py = x[1];
+      for (int i = 0; i < c.p; ++i) {
+        jac[i * nm + 0] = 2 * (c.par[3 * i] - px);  // obstacle_constraints.hpp:117-118
+        jac[i * nm + 1] = 2 * (c.par[3 * i + 1] - py);
+      }
+    }
+  }
+  // DualCone::Projection (constraint.hpp:70-73 identity for equalities, :103-108 for inequalities)
+  static T DualProj(const Con& c, T v) { return c.type == 0 ? v : std::min(T(0), v); }
+  // DualCone::Jacobian diagonal (constraint.hpp:74-78, :109-114; quirk Q5: v == 0 is active)
+  static T DualProjJac(const Con& c, T v) { return c.type == 0 ? T(1) : (v > 0 ? T(0) : T(1)); }
+
+  // ConstraintValues::AugLag, constraint_values.hpp:111-119 (quirk Q2: scalar rho = penalty_(0))
+  static T AugLag(Con& c, const T* x, const T* u) {
+    const T rho = c.pen[0];
+    ConEval(c, x, u);
+    T a = 0, b = 0;
+    for (int i = 0; i < c.p; ++i) {
+      T lp = DualProj(c, c.lam[i] - rho * c.c[i]);
+      a += lp * lp;
+      b += c.lam[i] * c.lam[i];
+    }
+    T J = a - b;
+    return J / (2 * rho);
+  }
+
+  // QuadraticCost::Evaluate, examples/quadratic_cost.cpp:8-11
+  static T QuadEval(const QCost& c, const T* x, const T* u) {
+    T xQx = 0, xHu = 0, uRu = 0, qx = 0, ru = 0;
+    for (int i = 0; i < n; ++i) {
+      T s = 0;
+      for (int j = 0; j < n; ++j) s += c.Q[i + j * n] * x[j];
+      xQx += x[i] * s;
+      T t = 0;
+      for (int j = 0; j < m; ++j) t += c.H[i + j * n] * u[j];
+      xHu += x[i] * t;
+      qx += c.q[i] * x[i];
+    }
+    for (int i = 0; i < m; ++i) {
+      T s = 0;
+      for (int j = 0; j < m; ++j) s += c.R[i + j * m] * u[j];
+      uRu += u[i] * s;
+      ru += c.r[i] * u[i];
+    }
+    return T(0.5) * xQx + xHu + T(0.5) * uRu + qx + ru + c.c;
+  }
+
+  // ALCost::Evaluate, al_cost.hpp:264-274.  Side effect: stores c_ of every constraint (quirk Q6).
+  T KnotCost(int k, const T* x, const T* u) {
+    T J = QuadEval(cost[k], x, u);
+    for (Con& c : cons[k]) J += AugLag(c, x, u);
+    return J;
+  }
+
+  // CostExpansion::CalcExpansion -> ALCost::Gradient / Hessian (cost_expansion.hpp:118-125,
+  // al_cost.hpp:276-308, quadratic_cost.cpp:13-28, constraint_values.hpp:131-177)
+  void CostExpansion(int k, const T* x, const T* u) {
+    const QCost& qc = cost[k];
+    T* gx = &lx[k * n];
+    T* gu = &lu[k * m];
+    T* hxx = &lxx[k * n * n];
+    T* hxu = &lxu[k * n * m];
+    T* huu = &luu[k * m * m];
+    for (int i = 0; i < n; ++i) {
+      T s = 0, t = 0;
+      for (int j = 0; j < n; ++j) s += qc.Q[i + j * n] * x[j];
+      for (int j = 0; j < m; ++j) t += qc.H[i + j * n] * u[j];
+      gx[i] = s + qc.q[i] + t;
+    }
+    for (int i = 0; i < m; ++i) {
+      T s = 0, t = 0;
+      for (int j = 0; j < m; ++j) s += qc.R[i + j * m] * u[j];
+      for (int j = 0; j < n; ++j) t += qc.H[j + i * n] * x[j];
+      gu[i] = s + qc.r[i] + t;
+    }
+    for (int i = 0; i < n * n; ++i) hxx[i] = qc.Q[i];
+    for (int i = 0; i < n * m; ++i) hxu[i] = qc.H[i];
+    for (int i = 0; i < m * m; ++i) huu[i] = qc.R[i];
+    std::vector<T> jac, jp, lp;
+    for (Con& c : cons[k]) {
+      const T rho = c.pen[0];
+      ConEval(c, x, u);
+      jac.resize(c.p * nm);
+      jp.resize(c.p * nm);
+      lp.resize(c.p);
+      ConJac(c, x, u, jac.data());
+      for (int r = 0; r < c.p; ++r) {
+        T v = c.lam[r] - rho * c.c[r];
+        lp[r] = DualProj(c, v);
+        T pj = DualProjJac(c, v);
+        for (int j = 0; j < nm; ++j) jp[r * nm + j] = pj * jac[r * nm + j];
+      }
+      // gradient: dx = -(P Cx)^T lambda_bar, du likewise (constraint_values.hpp:141-142)
+      for (int i = 0; i < n; ++i) {
+        T s = 0;
+        for (int r = 0; r < c.p; ++r) s += jp[r * nm + i] * lp[r];
+        gx[i] += -s;
+      }
+      for (int i = 0; i < m; ++i) {
+        T s = 0;
+        for (int r = 0; r < c.p; ++r) s += jp[r * nm + n + i] * lp[r];
+        gu[i] += -s;
+      }
+      // Gauss-Newton Hessian rho (PC)^T (PC) (constraint_values.hpp:165-172)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = 0;
+          for (int r = 0; r < c.p; ++r) s += (rho * jp[r * nm + i]) * jp[r * nm + j];
+          hxx[i + j * n] += s;
+        }
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = 0;
+          for (int r = 0; r < c.p; ++r) s += (rho * jp[r * nm + i]) * jp[r * nm + n + j];
+          hxu[i + j * n] += s;
+        }
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) {
+          T s = 0;
+          for (int r = 0; r < c.p; ++r) s += (rho * jp[r * nm + n + i]) * jp[r * nm + n + j];
+          huu[i + j * m] += s;
+        }
+    }
+  }
+
+  // ---- dynamics ------------------------------------------------------------------------------
+  // RungeKutta4::Integrate, altro/problem/integration.hpp:123-131
+  void Dynamics(const T* x, const T* u, float hf, T* xn) const {
+    const T hh = T(hf);
+    T k1[n], k2[n], k3[n], k4[n], xt[n];
+    model.f(x, u, k1);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
+    model.f(xt, u, k2);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
+    model.f(xt, u, k3);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
+    model.f(xt, u, k4);
+    for (int i = 0; i < n; ++i) xn[i] = x[i] + hh * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+  }
+  // RungeKutta4::Jacobian, integration.hpp:132-169
+  void DynamicsJacobian(const T* x, const T* u, float hf, T* J) const {
+    const T hh = T(hf);
+    T k1[n], k2[n], k3[n], xt[n];
+    T Jc[4][n * nm];
+    model.f(x, u, k1);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
+    model.f(xt, u, k2);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
+    model.f(xt, u, k3);
+    model.jac(x, u, Jc[0]);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k1[i] * hh;
+    model.jac(xt, u, Jc[1]);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k2[i] * hh;
+    model.jac(xt, u, Jc[2]);
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
+    model.jac(xt, u, Jc[3]);
+    const T* A[4];
+    const T* B[4];
+    for (int s = 0; s < 4; ++s) {
+      A[s] = Jc[s];
+      B[s] = Jc[s] + n * n;
+    }
+    T dA[4][n * n], dB[4][n * m], M[n * n];
+    auto matmul_nn = [](const T* a, const T* b, T* c) {  // c = a*b, all n x n
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = 0;
+          for (int l = 0; l < n; ++l) s += a[i + l * n] * b[l + j * n];
+          c[i + j * n] = s;
+        }
+    };
+    auto matmul_nm = [](const T* a, const T* b, T* c) {  // c = a(n x n) * b(n x m)
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) {
+          T s = 0;
+          for (int l = 0; l < n; ++l) s += a[i + l * n] * b[l + j * n];
+          c[i + j * n] = s;
+        }
+    };
+    for (int i = 0; i < n * n; ++i) dA[0][i] = A[0][i] * hh;
+    const T coef[4] = {T(0), T(0.5), T(0.5), T(1)};
+    for (int s = 1; s < 4; ++s) {
+      // dA[s] = A[s] * (I + coef*dA[s-1]) * h
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) M[i + j * n] = (i == j ? T(1) : T(0)) + coef[s] * dA[s - 1][i + j * n];
+      T tmp[n * n];
+      matmul_nn(A[s], M, tmp);
+      for (int i = 0; i < n * n; ++i) dA[s][i] = tmp[i] * hh;
+    }
+    for (int i = 0; i < n * m; ++i) dB[0][i] = B[0][i] * hh;
+    for (int s = 1; s < 4; ++s) {
+      // dB[s] = B[s]*h + coef * A[s] * dB[s-1] * h
+      T tmp[n * m];
+      matmul_nm(A[s], dB[s - 1], tmp);
+      for (int i = 0; i < n * m; ++i) dB[s][i] = B[s][i] * hh + coef[s] * tmp[i] * hh;
+    }
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        int e = i + j * n;
+        J[e] = (i == j ? T(1) : T(0)) + (dA[0][e] + 2 * dA[1][e] + 2 * dA[2][e] + dA[3][e]) / 6;
+      }
+    for (int e = 0; e < n * m; ++e)
+      J[n * n + e] = (dB[0][e] + 2 * dB[1][e] + 2 * dB[2][e] + dB[3][e]) / 6;
+  }
+
+  // ---- iLQR -----------------------------------------------------------------------------------
+  // iLQR::Rollout, ilqr.hpp:453-459
+  void Rollout() override {
+    for (int i = 0; i < n; ++i) X[i] = x0[i];
+    for (int k = 0; k < N; ++k) Dynamics(&X[k * n], &U[k * m], h[k], &X[(k + 1) * n]);
+  }
+  // iLQR::Cost / CalcIndividualCosts, ilqr.hpp:326-334, 758-763
+  T CostOf(const std::vector<T>& Xs, const std::vector<T>& Us) {
+    T J = 0;
+    for (int k = 0; k <= N; ++k) {
+      costs[k] = KnotCost(k, &Xs[k * n], &Us[k * m]);
+      J += costs[k];
+    }
+    return J;
+  }
+  double Cost() override { return (double)CostOf(X, U); }
+
+  // iLQR::UpdateExpansionsBlock, ilqr.hpp:670-677
+  void UpdateExpansions() override {
+    for (int k = 0; k <= N; ++k) {
+      const T* x = &X[k * n];
+      const T* u = &U[k * m];
+      CostExpansion(k, x, u);
+      if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm]);
+      costs[k] = KnotCost(k, x, u);
+    }
+  }
+
+  // iLQR::IncreaseRegularization / DecreaseRegularization, ilqr.hpp:770-786
+  void IncreaseRegularization() {
+    drho_ = std::max(drho_ * T(opts.bp_reg_increase_factor), T(opts.bp_reg_increase_factor));
+    rho_ = std::max(rho_ * drho_, T(opts.bp_reg_min));
+    rho_ = std::min(rho_, T(opts.bp_reg_max));
+  }
+  void DecreaseRegularization() {
+    drho_ = std::min(drho_ / T(opts.bp_reg_increase_factor), 1 / T(opts.bp_reg_increase_factor));
+    rho_ = std::max(rho_ * drho_, T(opts.bp_reg_min));
+    rho_ = std::min(rho_, T(opts.bp_reg_max));
+  }
+
+  // One knot of the backward pass: CalcActionValueExpansion, RegularizeActionValue, CalcGains,
+  // CalcCostToGo, AddCostToGo (knot_point_function_type.hpp:149-235).  Returns false on Cholesky
+  // failure (Eigen::NumericalIssue), in which case K, d, P, p of this knot are left unchanged.
+  bool BackwardKnot(int k, const T* Pn, const T* pn) {
+    const T* A = &AB[k * n * nm];
+    const T* B = A + n * n;
+    T AtP[n * n], BtP[m * n];
+    for (int j = 0; j < n; ++j) {
+      for (int i = 0; i < n; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += A[l + i * n] * Pn[l + j * n];
+        AtP[i + j * n] = s;
+      }
+      for (int i = 0; i < m; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += B[l + i * n] * Pn[l + j * n];
+        BtP[i + j * m] = s;
+      }
+    }
+    T Qxx[n * n], Qxu[n * m], Quu[m * m], Qx[n], Qu[m];
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += AtP[i + l * n] * A[l + j * n];
+        Qxx[i + j * n] = lxx[k * n * n + i + j * n] + s;
+      }
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < n; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += AtP[i + l * n] * B[l + j * n];
+        Qxu[i + j * n] = lxu[k * n * m + i + j * n] + s;
+      }
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += BtP[i + l * m] * B[l + j * n];
+        Quu[i + j * m] = luu[k * m * m + i + j * m] + s;
+      }
+    for (int i = 0; i < n; ++i) {
+      T s = 0;
+      for (int l = 0; l < n; ++l) s += A[l + i * n] * pn[l];
+      Qx[i] = lx[k * n + i] + s;
+    }
+    for (int i = 0; i < m; ++i) {
+      T s = 0;
+      for (int l = 0; l < n; ++l) s += B[l + i * n] * pn[l];
+      Qu[i] = lu[k * m + i] + s;
+    }
+    // RegularizeActionValue (control-only): Quu_reg = Quu + rho I
+    T L[m * m];
+    for (int i = 0; i < m * m; ++i) L[i] = Quu[i];
+    for (int i = 0; i < m; ++i) L[i + i * m] += rho_;
+    // Eigen::LLT (lower): fails when a pivot is <= 0
+    for (int j = 0; j < m; ++j) {
+      T x = L[j + j * m];
+      for (int l = 0; l < j; ++l) x -= L[j + l * m] * L[j + l * m];
+      if (x <= T(0)) return false;
+      T ljj = std::sqrt(x);
+      L[j + j * m] = ljj;
+      for (int i = j + 1; i < m; ++i) {
+        T s = L[i + j * m];
+        for (int l = 0; l < j; ++l) s -= L[i + l * m] * L[j + l * m];
+        L[i + j * m] = s / ljj;
+      }
+    }
+    auto solve = [&](T* b) {  // in place: b <- (L L^T)^-1 b
+      for (int i = 0; i < m; ++i) {
+        T s = b[i];
+        for (int l = 0; l < i; ++l) s -= L[i + l * m] * b[l];
+        b[i] = s / L[i + i * m];
+      }
+      for (int i = m - 1; i >= 0; --i) {
+        T s = b[i];
+        for (int l = i + 1; l < m; ++l) s -= L[l + i * m] * b[l];
+        b[i] = s / L[i + i * m];
+      }
+    };
+    T* Kk = &K[k * m * n];
+    T* dk = &d[k * m];
+    for (int j = 0; j < n; ++j) {  // K = -Quu_reg^-1 Qxu^T (regularised Q: quirk Q3)
+      T col[m];
+      for (int i = 0; i < m; ++i) col[i] = Qxu[j + i * n];
+      solve(col);
+      for (int i = 0; i < m; ++i) Kk[i + j * m] = -col[i];
+    }
+    {
+      T col[m];
+      for (int i = 0; i < m; ++i) col[i] = Qu[i];
+      solve(col);
+      for (int i = 0; i < m; ++i) dk[i] = -col[i];
+    }
+    // CalcCostToGo with the UN-regularised Q (knot_point_function_type.hpp:220-230)
+    T KtQuu[n * m];
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < n; ++i) {
+        T s = 0;
+        for (int l = 0; l < m; ++l) s += Kk[l + i * m] * Quu[l + j * m];
+        KtQuu[i + j * n] = s;
+      }
+    T* pk = &p[k * n];
+    T* Pk = &P[k * n * n];
+    for (int i = 0; i < n; ++i) {
+      T a = 0, b = 0, c = 0;
+      for (int l = 0; l < m; ++l) {
+        a += KtQuu[i + l * n] * dk[l];
+        b += Kk[l + i * m] * Qu[l];
+        c += Qxu[i + l * n] * dk[l];
+      }
+      pk[i] = Qx[i] + a + b + c;
+    }
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        T a = 0, b = 0, c = 0;
+        for (int l = 0; l < m; ++l) {
+          a += KtQuu[i + l * n] * Kk[l + j * m];
+          b += Kk[l + i * m] * Qxu[j + l * n];
+          c += Qxu[i + l * n] * Kk[l + j * m];
+        }
+        Pk[i + j * n] = Qxx[i + j * n] + a + b + c;
+      }
+    T dv0 = 0, dv1 = 0;
+    for (int i = 0; i < m; ++i) {
+      dv0 += dk[i] * Qu[i];
+      T s = 0;
+      for (int l = 0; l < m; ++l) s += Quu[i + l * m] * dk[l];
+      dv1 += dk[i] * s;
+    }
+    deltaV[0] += dv0;
+    deltaV[1] += T(0.5) * dv1;
+    return true;
+  }
+
+  // iLQR::BackwardPass, ilqr.hpp:385-445
+  void BackwardPass() override {
+    // CalcTerminalCostToGo, knot_point_function_type.hpp:135-138
+    for (int i = 0; i < n * n; ++i) P[N * n * n + i] = lxx[N * n * n + i];
+    for (int i = 0; i < n; ++i) p[N * n + i] = lx[N * n + i];
+    int max_reg_count = 0;
+    deltaV[0] = 0;  // zeroed ONCE, not per retry (quirk Q4)
+    deltaV[1] = 0;
+    bool repeat = true;
+    while (repeat) {
+      const T* Pn = &P[N * n * n];
+      const T* pn = &p[N * n];
+      for (int k = N - 1; k >= 0; --k) {
+        if (!BackwardKnot(k, Pn, pn)) {
+          IncreaseRegularization();
+          if (rho_ >= T(opts.bp_reg_max)) max_reg_count++;
+          if (max_reg_count >= opts.bp_reg_fail_threshold) {
+            status_ = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
+            repeat = false;
+          }
+          break;
+        }
+        Pn = &P[k * n * n];
+        pn = &p[k * n];
+        if (k == 0) repeat = false;
+      }
+      if (N == 0) repeat = false;
+    }
+    stats.Log(F_REG, (double)rho_);
+    DecreaseRegularization();
+  }
+
+  // iLQR::RolloutClosedLoop, ilqr.hpp:468-499
+  bool RolloutClosedLoop(T alpha) {
+    for (int i = 0; i < n; ++i) Xb[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      const T* Kk = &K[k * m * n];
+      const T* dk = &d[k * m];
+      T dx[n];
+      for (int i = 0; i < n; ++i) dx[i] = Xb[k * n + i] - X[k * n + i];
+      for (int i = 0; i < m; ++i) {
+        T s = 0;
+        for (int l = 0; l < n; ++l) s += Kk[i + l * m] * dx[l];
+        Ub[k * m + i] = U[k * m + i] + s + dk[i] * alpha;
+      }
+      Dynamics(&Xb[k * n], &Ub[k * m], h[k], &Xb[(k + 1) * n]);
+      if (opts.check_forwardpass_bounds) {
+        T sx = 0, su = 0;
+        for (int i = 0; i < n; ++i) sx += Xb[(k + 1) * n + i] * Xb[(k + 1) * n + i];
+        for (int i = 0; i < m; ++i) su += Ub[k * m + i] * Ub[k * m + i];
+        if (std::sqrt(sx) > T(opts.state_max)) {
+          status_ = ALTRO_STATE_LIMIT;
+          return false;
+        }
+        if (std::sqrt(su) > T(opts.control_max)) {
+          status_ = ALTRO_CONTROL_LIMIT;
+          return false;
+        }
+      }
+    }
+    status_ = ALTRO_UNSOLVED;
+    return true;
+  }
+
+  // iLQR::ForwardPass, ilqr.hpp:512-558
+  void ForwardPass() override {
+    T J0 = 0;
+    for (int k = 0; k <= N; ++k) J0 += costs[k];
+    T alpha = 1, z = -1, J = J0;
+    bool success = false;
+    for (int it = 0; it < opts.line_search_max_iterations; ++it) {
+      if (RolloutClosedLoop(alpha)) {
+        J = CostOf(Xb, Ub);
+        T expected = -alpha * (deltaV[0] + alpha * deltaV[1]);
+        z = expected > T(0) ? (J0 - J) / expected : T(-1);
+        if (T(opts.line_search_lower_bound) <= z && z <= T(opts.line_search_upper_bound) && J < J0) {
+          success = true;
+          stats.Log(F_COST, (double)J);
+          stats.Log(F_ALPHA, (double)alpha);
+          stats.Log(F_Z, (double)z);
+          break;
+        }
+      }
+      alpha /= T(opts.line_search_decrease_factor);
+    }
+    if (success) {
+      X = Xb;
+      U = Ub;
+    } else {
+      IncreaseRegularization();
+      J = J0;
+    }
+    if (J > J0) status_ = ALTRO_COST_INCREASE;
+  }
+
+  // iLQR::NormalizedFeedforwardGain + UpdateConvergenceStatistics, ilqr.hpp:568-587, 662-668
+  void UpdateConvergenceStatistics() override {
+    T g = 0;
+    for (int k = 0; k < N; ++k) {
+      T mx = -std::numeric_limits<T>::infinity();
+      for (int i = 0; i < m; ++i) mx = std::max(mx, std::abs(d[k * m + i]) / (std::abs(U[k * m + i]) + 1));
+      g += mx;
+    }
+    double dgrad = N > 0 ? (double)(g / T(N)) : 0.0;
+    double dJ;
+    if (stats.iterations_inner == 0) {
+      dJ = stats.initial_cost - stats.Back(F_COST);
+    } else {
+      dJ = stats.v[F_COST][stats.len - 2] - stats.v[F_COST][stats.len - 1];
+    }
+    stats.iterations_inner++;
+    stats.iterations_total++;
+    stats.Log(F_DJ, dJ);
+    stats.Log(F_VIOL, GetMaxViolation());  // max_violation_callback_ (stored c_, quirk Q6)
+    stats.Log(F_GRAD, dgrad);
+    stats.NewIteration();
+  }
+  // iLQR::IsDone, ilqr.hpp:597-619
+  bool IsDone() {
+    bool cost_decrease = stats.Back(F_DJ) < opts.cost_tolerance;
+    bool gradient = stats.Back(F_GRAD) < opts.gradient_tolerance;
+    if (cost_decrease && gradient) {
+      status_ = ALTRO_SOLVED;
+      return true;
+    } else if (stats.iterations_inner >= opts.max_iterations_inner) {
+      status_ = ALTRO_MAX_INNER_ITERATIONS;
+      return true;
+    } else if (stats.iterations_total >= opts.max_iterations_total) {
+      status_ = ALTRO_MAX_ITERATIONS;
+      return true;
+    } else if (status_ != ALTRO_UNSOLVED) {
+      return true;
+    }
+    return false;
+  }
+  // iLQR::SolveSetup + ResetInternalVariables, ilqr.hpp:629-645, 680-690
+  void SolveSetup() override {
+    stats.iterations_inner = 0;
+    status_ = ALTRO_UNSOLVED;
+    std::fill(costs.begin(), costs.end(), T(0));
+    deltaV[0] = deltaV[1] = 0;
+    rho_ = T(opts.bp_reg_initial);
+    drho_ = 0;
+  }
+  // iLQR::Solve, ilqr.hpp:284-316
+  void SolveILQR() override {
+    SolveSetup();
+    Rollout();
+    stats.initial_cost = Cost();
+    for (int iter = 0; iter < opts.max_iterations_inner; ++iter) {
+      UpdateExpansions();
+      BackwardPass();
+      ForwardPass();
+      UpdateConvergenceStatistics();
+      if (IsDone()) break;
+    }
+  }
+
+  // ---- augmented Lagrangian outer loop -----------------------------------------------------
+  void SetPenalty(double rho) override {  // al_solver.hpp:271-277
+    for (auto& v : cons)
+      for (Con& c : v) std::fill(c.pen.begin(), c.pen.end(), T(rho));
+  }
+  void SetPenaltyScaling(double phi) override {  // al_solver.hpp:279-285
+    for (auto& v : cons)
+      for (Con& c : v) c.phi = T(phi);
+  }
+  // ConstraintValues::UpdateDuals, constraint_values.hpp:192-194 (per-row penalty, stored c_)
+  void UpdateDuals() override {
+    for (auto& v : cons)
+      for (Con& c : v)
+        for (int i = 0; i < c.p; ++i) c.lam[i] = DualProj(c, c.lam[i] - c.pen[i] * c.c[i]);
+  }
+  void UpdatePenalties() override {  // constraint_values.hpp:202-207
+    for (auto& v : cons)
+      for (Con& c : v)
+        for (int i = 0; i < c.p; ++i) c.pen[i] *= c.phi;
+  }
+  // ConstraintValues::MaxViolation / ALCost::MaxViolation / GetMaxViolation
+  // (constraint_values.hpp:215-220, al_cost.hpp:343-353, al_solver.hpp:417-424)
+  double GetMaxViolation() override {
+    T mx = 0;
+    for (auto& v : cons)
+      for (Con& c : v)
+        for (int i = 0; i < c.p; ++i) {
+          T viol = c.type == 0 ? std::abs(c.c[i]) : std::abs(c.c[i] - std::min(T(0), c.c[i]));
+          mx = std::max(mx, viol);
+        }
+    return (double)mx;
+  }
+  double MaxViolation() override {  // al_solver.hpp:403-408
+    Cost();
+    return GetMaxViolation();
+  }
+  double GetMaxPenalty() override {  // al_solver.hpp:426-434
+    T mx = 0;
+    for (auto& v : cons)
+      for (Con& c : v)
+        for (int i = 0; i < c.p; ++i) mx = std::max(mx, c.pen[i]);
+    return (double)mx;
+  }
+  // AugmentedLagrangianiLQR::Init, al_solver.hpp:287-302
+  void AlInit() override {
+    if (opts.reset_duals)
+      for (auto& v : cons)
+        for (Con& c : v) std::fill(c.lam.begin(), c.lam.end(), T(0));
+    if (opts.initial_penalty > 0) SetPenalty(opts.initial_penalty);  // quirk Q8
+    stats.Reset();
+    stats.Touch();  // Log("iter_al", 0)
+    stats.Log(F_VIOL, MaxViolation());
+    stats.Log(F_PEN, GetMaxPenalty());
+  }
+  // AugmentedLagrangianiLQR::IsDone, al_solver.hpp:368-401
+  bool AlIsDone() {
+    const bool satisfied = stats.Back(F_VIOL) < opts.constraint_tolerance;
+    const bool max_pen = stats.Back(F_PEN) > opts.maximum_penalty;
+    const bool max_outer = stats.iterations_outer >= opts.max_iterations_outer;
+    const bool max_total = stats.iterations_total >= opts.max_iterations_total;
+    if (status_ != ALTRO_SOLVED) {
+      status_al_ = status_;
+      return true;
+    }
+    if (satisfied) {
+      status_al_ = ALTRO_SOLVED;
+      return true;
+    }
+    if (max_pen) {
+      status_al_ = ALTRO_MAX_PENALTY;
+      return true;
+    }
+    if (max_outer) {
+      status_al_ = ALTRO_MAX_OUTER_ITERATIONS;
+      return true;
+    }
+    if (max_total) {
+      status_al_ = ALTRO_MAX_ITERATIONS;
+      return true;
+    }
+    return false;
+  }
+  // AugmentedLagrangianiLQR::Solve, al_solver.hpp:304-334
+  void SolveAL() override {
+    AlInit();
+    for (int it = 0; it < opts.max_iterations_outer; ++it) {
+      SolveILQR();
+      UpdateDuals();
+      // UpdateConvergenceStatistics, al_solver.hpp:357-366
+      stats.iterations_outer++;
+      stats.Log(F_VIOL, GetMaxViolation());
+      stats.Log(F_PEN, GetMaxPenalty());
+      if (AlIsDone()) break;
+      UpdatePenalties();
+    }
+  }
+
+  // ---- getters -------------------------------------------------------------------------------
+  void GetTrajectory(double* Xo, double* Uo) override {
+    if (Xo)
+      for (int i = 0; i < (N + 1) * n; ++i) Xo[i] = (double)X[i];
+    if (Uo)
+      for (int i = 0; i < N * m; ++i) Uo[i] = (double)U[i];
+  }
+  void GetGains(double* Ko, double* dout) override {
+    if (Ko)
+      for (int i = 0; i < N * m * n; ++i) Ko[i] = (double)K[i];
+    if (dout)
+      for (int i = 0; i < N * m; ++i) dout[i] = (double)d[i];
+  }
+  void GetCtg(double* Po, double* po) override {
+    if (Po)
+      for (int i = 0; i < (N + 1) * n * n; ++i) Po[i] = (double)P[i];
+    if (po)
+      for (int i = 0; i < (N + 1) * n; ++i) po[i] = (double)p[i];
+  }
+  void GetExpansion(int k, double* ABo, double* a, double* b, double* c, double* gx, double* gu) override {
+    if (ABo)
+      for (int i = 0; i < n * nm; ++i) ABo[i] = (double)AB[k * n * nm + i];
+    if (a)
+      for (int i = 0; i < n * n; ++i) a[i] = (double)lxx[k * n * n + i];
+    if (b)
+      for (int i = 0; i < n * m; ++i) b[i] = (double)lxu[k * n * m + i];
+    if (c)
+      for (int i = 0; i < m * m; ++i) c[i] = (double)luu[k * m * m + i];
+    if (gx)
+      for (int i = 0; i < n; ++i) gx[i] = (double)lx[k * n + i];
+    if (gu)
+      for (int i = 0; i < m; ++i) gu[i] = (double)lu[k * m + i];
+  }
+  void GetKnotCosts(double* c) override {
+    for (int k = 0; k <= N; ++k) c[k] = (double)costs[k];
+  }
+  int NumRowsAt(int k) override {
+    int r = 0;
+    for (Con& c : cons[k]) r += c.p;
+    return r;
+  }
+  int NumRows() override {
+    int r = 0;
+    for (int k = 0; k <= N; ++k) r += NumRowsAt(k);
+    return r;
+  }
+  template <class F>
+  void ForRows(F f) {
+    int r = 0;
+    for (auto& v : cons)
+      for (Con& c : v)
+        for (int i = 0; i < c.p; ++i) f(r++, c, i);
+  }
+  void GetDuals(double* out) override {
+    ForRows([&](int r, Con& c, int i) { out[r] = (double)c.lam[i]; });
+  }
+  void SetDuals(const double* in) override {
+    ForRows([&](int r, Con& c, int i) { c.lam[i] = T(in[r]); });
+  }
+  void GetPenalties(double* out) override {
+    ForRows([&](int r, Con& c, int i) { out[r] = (double)c.pen[i]; });
+  }
+  void GetConVals(double* out) override {
+    ForRows([&](int r, Con& c, int i) { out[r] = (double)c.c[i]; });
+  }
+  void GetStats(altro_stats* s) override {
+    s->status = status_al_;
+    s->status_ilqr = status_;
+    s->iterations_inner = stats.iterations_inner;
+    s->iterations_outer = stats.iterations_outer;
+    s->iterations_total = stats.iterations_total;
+    s->reserved = 0;
+    s->cost = stats.Back(F_COST);
+    s->initial_cost = stats.initial_cost;
+    s->cost_decrease = stats.Back(F_DJ);
+    s->gradient = stats.Back(F_GRAD);
+    s->violation = stats.Back(F_VIOL);
+    s->max_penalty = stats.Back(F_PEN);
+    s->alpha = stats.Back(F_ALPHA);
+    s->regularization = stats.Back(F_REG);
+    s->improvement_ratio = stats.Back(F_Z);
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C API (mirror of include/altro_hip.h with the prefix oracle_)
+// ------------------------------------------------------------------------------------------------
+struct oracle_solver_s {
+  altro_desc desc;
+  int model_kind = 0;
+  int dof = 0;
+  float hstep = 0.0f;
+  std::vector<CostSpec> costs;
+  std::vector<ConSpec> cons;
+  std::vector<double> x0;
+  int x0_per_instance = 0;
+  std::vector<double> X, U;
+  int traj_per_instance = 0;
+  bool has_X = false;
+  altro_options opts;
+  double penalty = -1.0, phi = -1.0;
+  int nthreads = 1;
+  bool built = false;
+  bool ilqr_mode = false;
+  std::vector<std::unique_ptr<SolverBase>> inst;
+  std::string err;
+};
+typedef oracle_solver_s* oracle_handle;
+
+namespace {
+
+template <class T, class Model>
+std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& mdl) {
+  const altro_desc& D = h->desc;
+  auto up = std::make_unique<Instance<T, Model>>(D.N, mdl);
+  Instance<T, Model>& I = *up;
+  constexpr int n = Model::n, m = Model::m;
+  for (int k = 0; k < D.N; ++k) I.h[k] = h->hstep;
+  I.h[D.N] = 0.0f;
+  for (const CostSpec& c : h->costs) {
+    const double* xr = c.xref.data() + ((c.per_instance & 1) ? (size_t)b * n : 0);
+    const double* ur = c.uref.data() + ((c.per_instance & 2) ? (size_t)b * m : 0);
+    for (int k = c.k_begin; k < c.k_end; ++k) I.SetLQRCost(k, c.Q.data(), c.R.data(), xr, ur);
+  }
+  for (const ConSpec& c : h->cons) {
+    const double* par = c.params.data() + (c.per_instance ? (size_t)b * c.nparams : 0);
+    for (int k = c.k_begin; k < c.k_end; ++k) I.AddConstraint(k, c.kind, par, c.nparams);
+  }
+  if (!h->x0.empty()) I.SetInitialState(h->x0.data() + (h->x0_per_instance ? (size_t)b * n : 0));
+  const double* X = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * n : 0) : nullptr;
+  const double* U = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * m : 0);
+  I.SetTrajectory(X, U);
+  I.opts = h->opts;
+  return up;
+}
+
+template <class T>
+std::unique_ptr<SolverBase> MakeForModel(oracle_handle h, int b) {
+  const altro_desc& D = h->desc;
+  if (h->model_kind == ALTRO_MODEL_UNICYCLE && D.n == 3 && D.m == 2)
+    return MakeInstance<T>(h, b, UnicycleModel<T>());
+  if (h->model_kind == ALTRO_MODEL_TRIPLE_INTEGRATOR && h->dof == 2 && D.n == 6 && D.m == 2)
+    return MakeInstance<T>(h, b, TripleIntegratorModel<T, 2>());
+  if (h->model_kind == ALTRO_MODEL_TRIPLE_INTEGRATOR && h->dof == 1 && D.n == 3 && D.m == 1)
+    return MakeInstance<T>(h, b, TripleIntegratorModel<T, 1>());
+  if (h->model_kind == ALTRO_MODEL_QUADROTOR12 && D.n == 12 && D.m == 4)
+    return MakeInstance<T>(h, b, Quadrotor12Model<T>());
+  return nullptr;
+}
+
+altro_status Build(oracle_handle h) {
+  if (h->built) {
+    for (auto& I : h->inst) I->opts = h->opts;
+    return ALTRO_OK;
+  }
+  h->inst.clear();
+  for (int b = 0; b < h->desc.batch; ++b) {
+    std::unique_ptr<SolverBase> I =
+        h->desc.dtype == ALTRO_F32 ? MakeForModel<float>(h, b) : MakeForModel<double>(h, b);
+    if (!I) {
+      h->err = "unsupported (model, n, m) combination";
+      return ALTRO_UNSUPPORTED;
+    }
+    if (h->penalty >= 0) I->SetPenalty(h->penalty);
+    if (h->phi >= 0) I->SetPenaltyScaling(h->phi);
+    h->inst.push_back(std::move(I));
+  }
+  h->built = true;
+  return ALTRO_OK;
+}
+
+template <class F>
+altro_status ForAll(oracle_handle h, F f) {
+  if (!h) return ALTRO_INVALID_ARG;
+  altro_status st = Build(h);
+  if (st != ALTRO_OK) return st;
+  const int B = h->desc.batch;
+  const int nt = std::max(1, std::min(h->nthreads, B));
+  if (nt == 1) {
+    for (int b = 0; b < B; ++b) f(*h->inst[b], b);
+  } else {
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&]() {
+        for (;;) {
+          int b = next.fetch_add(1);
+          if (b >= B) break;
+          f(*h->inst[b], b);
+        }
+      });
+    for (auto& t : th) t.join();
+  }
+  return ALTRO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void oracle_default_options(altro_options* o) {  // altro/common/solver_options.hpp:23-56
+  std::memset(o, 0, sizeof(*o));
+  o->max_iterations_total = 300;
+  o->max_iterations_outer = 30;
+  o->max_iterations_inner = 100;
+  o->cost_tolerance = 1e-4;
+  o->gradient_tolerance = 1e-2;
+  o->bp_reg_increase_factor = 1.6;
+  o->bp_reg_enable = 1;
+  o->bp_reg_initial = 0.0;
+  o->bp_reg_max = 1e8;
+  o->bp_reg_min = 1e-8;
+  o->bp_reg_fail_threshold = 100;
+  o->check_forwardpass_bounds = 1;
+  o->state_max = 1e8;
+  o->control_max = 1e8;
+  o->line_search_max_iterations = 20;
+  o->line_search_lower_bound = 1e-8;
+  o->line_search_upper_bound = 10.0;
+  o->line_search_decrease_factor = 2;
+  o->constraint_tolerance = 1e-4;
+  o->maximum_penalty = 1e8;
+  o->initial_penalty = 1.0;
+  o->reset_duals = 1;
+  o->profiler_enable = 0;
+}
+
+altro_status oracle_create(const altro_desc* desc, oracle_handle* out) {
+  if (!desc || !out || desc->n <= 0 || desc->m <= 0 || desc->N <= 0 || desc->batch <= 0)
+    return ALTRO_INVALID_ARG;
+  oracle_handle h = new oracle_solver_s();
+  h->desc = *desc;
+  oracle_default_options(&h->opts);
+  *out = h;
+  return ALTRO_OK;
+}
+void oracle_destroy(oracle_handle h) { delete h; }
+const char* oracle_last_error(oracle_handle h) { return h ? h->err.c_str() : ""; }
+altro_status oracle_set_threads(oracle_handle h, int nthreads) {
+  h->nthreads = nthreads;
+  return ALTRO_OK;
+}
+
+altro_status oracle_set_model(oracle_handle h, int kind, const double* params, int nparams) {
+  h->model_kind = kind;
+  h->dof = (kind == ALTRO_MODEL_TRIPLE_INTEGRATOR && nparams > 0) ? (int)params[0] : 0;
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_uniform_step(oracle_handle h, float hstep) {
+  h->hstep = hstep;
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_lqr_cost(oracle_handle h, int k_begin, int k_end, const double* Q,
+                                 const double* R, const double* xref, const double* uref,
+                                 int per_instance) {
+  const int n = h->desc.n, m = h->desc.m, B = h->desc.batch;
+  if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
+  CostSpec c;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.per_instance = per_instance;
+  c.Q.assign(Q, Q + n * n);
+  c.R.assign(R, R + m * m);
+  c.xref.assign(xref, xref + (size_t)n * ((per_instance & 1) ? B : 1));
+  c.uref.assign(uref, uref + (size_t)m * ((per_instance & 2) ? B : 1));
+  h->costs.push_back(std::move(c));
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_add_constraint(oracle_handle h, int kind, int k_begin, int k_end,
+                                   const double* params, int nparams, int per_instance) {
+  if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
+  ConSpec c;
+  c.kind = kind;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.nparams = nparams;
+  c.per_instance = per_instance;
+  c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
+  h->cons.push_back(std::move(c));
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_initial_state(oracle_handle h, const double* x0, int per_instance) {
+  const int n = h->desc.n;
+  h->x0.assign(x0, x0 + (size_t)n * (per_instance ? h->desc.batch : 1));
+  h->x0_per_instance = per_instance;
+  if (h->built)
+    for (int b = 0; b < h->desc.batch; ++b)
+      h->inst[b]->SetInitialState(h->x0.data() + (per_instance ? (size_t)b * n : 0));
+  return ALTRO_OK;
+}
+altro_status oracle_set_trajectory(oracle_handle h, const double* X, const double* U, int per_instance) {
+  const altro_desc& D = h->desc;
+  const size_t mult = per_instance ? D.batch : 1;
+  h->has_X = X != nullptr;
+  if (X) h->X.assign(X, X + mult * (D.N + 1) * D.n);
+  if (U)
+    h->U.assign(U, U + mult * D.N * D.m);
+  else
+    h->U.clear();
+  h->traj_per_instance = per_instance;
+  if (h->built)
+    for (int b = 0; b < D.batch; ++b) {
+      const double* Xb = X ? h->X.data() + (per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
+      const double* Ub = U ? h->U.data() + (per_instance ? (size_t)b * D.N * D.m : 0) : nullptr;
+      h->inst[b]->SetTrajectory(Xb, Ub);
+    }
+  return ALTRO_OK;
+}
+altro_status oracle_set_options(oracle_handle h, const altro_options* o) {
+  h->opts = *o;
+  for (auto& I : h->inst) I->opts = *o;
+  return ALTRO_OK;
+}
+altro_status oracle_get_options(oracle_handle h, altro_options* o) {
+  *o = h->opts;
+  return ALTRO_OK;
+}
+altro_status oracle_set_penalty(oracle_handle h, double rho) {
+  h->penalty = rho;
+  return ForAll(h, [&](SolverBase& s, int) { s.SetPenalty(rho); });
+}
+altro_status oracle_set_penalty_scaling(oracle_handle h, double phi) {
+  h->phi = phi;
+  return ForAll(h, [&](SolverBase& s, int) { s.SetPenaltyScaling(phi); });
+}
+
+altro_status oracle_solve_al(oracle_handle h) {
+  h->ilqr_mode = false;
+  return ForAll(h, [](SolverBase& s, int) { s.SolveAL(); });
+}
+altro_status oracle_solve_ilqr(oracle_handle h) {
+  h->ilqr_mode = true;
+  return ForAll(h, [](SolverBase& s, int) { s.SolveILQR(); });
+}
+altro_status oracle_al_init(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.AlInit(); }); }
+altro_status oracle_solve_setup(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.SolveSetup(); }); }
+altro_status oracle_rollout(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.Rollout(); }); }
+altro_status oracle_cost(oracle_handle h, double* J) {
+  return ForAll(h, [&](SolverBase& s, int b) {
+    double v = s.Cost();
+    if (J) J[b] = v;
+  });
+}
+altro_status oracle_update_expansions(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.UpdateExpansions(); }); }
+altro_status oracle_backward_pass(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.BackwardPass(); }); }
+altro_status oracle_forward_pass(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.ForwardPass(); }); }
+altro_status oracle_update_convergence_statistics(oracle_handle h) {
+  return ForAll(h, [](SolverBase& s, int) { s.UpdateConvergenceStatistics(); });
+}
+altro_status oracle_update_duals(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.UpdateDuals(); }); }
+altro_status oracle_update_penalties(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.UpdatePenalties(); }); }
+altro_status oracle_get_max_violation(oracle_handle h, double* out) {
+  return ForAll(h, [&](SolverBase& s, int b) { out[b] = s.GetMaxViolation(); });
+}
+altro_status oracle_max_violation(oracle_handle h, double* out) {
+  return ForAll(h, [&](SolverBase& s, int b) { out[b] = s.MaxViolation(); });
+}
+altro_status oracle_get_max_penalty(oracle_handle h, double* out) {
+  return ForAll(h, [&](SolverBase& s, int b) { out[b] = s.GetMaxPenalty(); });
+}
+
+altro_status oracle_get_trajectory(oracle_handle h, double* X, double* U) {
+  const altro_desc& D = h->desc;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    s.GetTrajectory(X ? X + (size_t)b * (D.N + 1) * D.n : nullptr, U ? U + (size_t)b * D.N * D.m : nullptr);
+  });
+}
+altro_status oracle_get_gains(oracle_handle h, double* K, double* d) {
+  const altro_desc& D = h->desc;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    s.GetGains(K ? K + (size_t)b * D.N * D.m * D.n : nullptr, d ? d + (size_t)b * D.N * D.m : nullptr);
+  });
+}
+altro_status oracle_set_record_ctg(oracle_handle, int) { return ALTRO_OK; }
+altro_status oracle_get_ctg(oracle_handle h, double* P, double* p) {
+  const altro_desc& D = h->desc;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    s.GetCtg(P ? P + (size_t)b * (D.N + 1) * D.n * D.n : nullptr, p ? p + (size_t)b * (D.N + 1) * D.n : nullptr);
+  });
+}
+altro_status oracle_get_expansion(oracle_handle h, int k, double* AB, double* lxx, double* lxu,
+                                  double* luu, double* lx, double* lu) {
+  const int n = h->desc.n, m = h->desc.m;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    s.GetExpansion(k, AB ? AB + (size_t)b * n * (n + m) : nullptr, lxx ? lxx + (size_t)b * n * n : nullptr,
+                   lxu ? lxu + (size_t)b * n * m : nullptr, luu ? luu + (size_t)b * m * m : nullptr,
+                   lx ? lx + (size_t)b * n : nullptr, lu ? lu + (size_t)b * m : nullptr);
+  });
+}
+altro_status oracle_get_knot_costs(oracle_handle h, double* costs) {
+  const int N = h->desc.N;
+  return ForAll(h, [&](SolverBase& s, int b) { s.GetKnotCosts(costs + (size_t)b * (N + 1)); });
+}
+int oracle_num_constraints(oracle_handle h) {
+  if (Build(h) != ALTRO_OK) return -1;
+  return h->inst[0]->NumRows();
+}
+int oracle_num_constraints_at(oracle_handle h, int k) {
+  if (Build(h) != ALTRO_OK) return -1;
+  return h->inst[0]->NumRowsAt(k);
+}
+altro_status oracle_get_duals(oracle_handle h, double* lam) {
+  int rows = oracle_num_constraints(h);
+  return ForAll(h, [&](SolverBase& s, int b) { s.GetDuals(lam + (size_t)b * rows); });
+}
+altro_status oracle_set_duals(oracle_handle h, const double* lam) {
+  int rows = oracle_num_constraints(h);
+  return ForAll(h, [&](SolverBase& s, int b) { s.SetDuals(lam + (size_t)b * rows); });
+}
+altro_status oracle_get_penalties(oracle_handle h, double* rho) {
+  int rows = oracle_num_constraints(h);
+  return ForAll(h, [&](SolverBase& s, int b) { s.GetPenalties(rho + (size_t)b * rows); });
+}
+altro_status oracle_get_constraint_values(oracle_handle h, double* c) {
+  int rows = oracle_num_constraints(h);
+  return ForAll(h, [&](SolverBase& s, int b) { s.GetConVals(c + (size_t)b * rows); });
+}
+altro_status oracle_get_stats(oracle_handle h, altro_stats* st) {
+  const bool ilqr = h->ilqr_mode;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    s.GetStats(&st[b]);
+    if (ilqr) st[b].status = st[b].status_ilqr;
+  });
+}
+altro_status oracle_set_record_history(oracle_handle, int) { return ALTRO_OK; }
+int oracle_get_history(oracle_handle h, int instance, int field, double* out, int cap) {
+  if (Build(h) != ALTRO_OK || instance < 0 || instance >= h->desc.batch || field < 0 || field >= F_COUNT)
+    return -1;
+  static const Field map[8] = {F_COST, F_ALPHA, F_Z, F_GRAD, F_DJ, F_REG, F_VIOL, F_PEN};
+  const std::vector<double>& v = h->inst[instance]->RawStats().v[map[field]];
+  int cnt = std::min<int>(cap, (int)v.size());
+  for (int i = 0; i < cnt; ++i) out[i] = v[i];
+  return cnt;
+}
+
+}  // extern "C"
