@@ -193,6 +193,9 @@ class BatchSolver:
         per = 1 if (U is not None and U.ndim == 3) or (X is not None and X.ndim == 3) else 0
         self._call("set_trajectory", _dp(X), _dp(U), C.c_int(per))
 
+    def reset_trajectory(self):
+        self._call("reset_trajectory")
+
     # -- options (solver.GetOptions()) -------------------------------------------------------------
     def default_options(self):
         o = Options()

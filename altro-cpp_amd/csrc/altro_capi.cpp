@@ -1,0 +1,345 @@
+// altro_capi.cpp — extern "C" front end of libaltro_hip.so (see include/altro_hip.h).
+//
+// Records the problem definition exactly as the reference's altro::problem::Problem setters do,
+// creates the device engine lazily on the first compute call, and forwards every entry point.
+// No exception crosses the boundary; there is NO CPU fallback.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "altro_common.hpp"
+
+using namespace altro_hip;
+
+struct altro_solver_s {
+  ProblemSpec spec;
+  altro_options opts;
+  std::unique_ptr<EngineBase> engine;
+  bool uploaded = false;
+  bool ilqr_mode = false;
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+void altro_default_options(altro_options* o) {  // altro/common/solver_options.hpp:23-56
+  std::memset(o, 0, sizeof(*o));
+  o->max_iterations_total = 300;
+  o->max_iterations_outer = 30;
+  o->max_iterations_inner = 100;
+  o->cost_tolerance = 1e-4;
+  o->gradient_tolerance = 1e-2;
+  o->bp_reg_increase_factor = 1.6;
+  o->bp_reg_enable = 1;
+  o->bp_reg_initial = 0.0;
+  o->bp_reg_max = 1e8;
+  o->bp_reg_min = 1e-8;
+  o->bp_reg_fail_threshold = 100;
+  o->check_forwardpass_bounds = 1;
+  o->state_max = 1e8;
+  o->control_max = 1e8;
+  o->line_search_max_iterations = 20;
+  o->line_search_lower_bound = 1e-8;
+  o->line_search_upper_bound = 10.0;
+  o->line_search_decrease_factor = 2;
+  o->constraint_tolerance = 1e-4;
+  o->maximum_penalty = 1e8;
+  o->initial_penalty = 1.0;
+  o->reset_duals = 1;
+  o->profiler_enable = 0;
+}
+
+altro_status altro_create(const altro_desc* desc, altro_handle* out) {
+  if (!desc || !out) return ALTRO_INVALID_ARG;
+  if (desc->n <= 0 || desc->m <= 0 || desc->N <= 0 || desc->batch <= 0 ||
+      (desc->dtype != ALTRO_F64 && desc->dtype != ALTRO_F32)) {
+    g_create_error = "invalid altro_desc";
+    return ALTRO_INVALID_ARG;
+  }
+  altro_solver_s* h = new (std::nothrow) altro_solver_s();
+  if (!h) return ALTRO_INVALID_ARG;
+  h->spec.desc = *desc;
+  altro_default_options(&h->opts);
+  *out = h;
+  return ALTRO_OK;
+}
+
+void altro_destroy(altro_handle h) { delete h; }
+
+const char* altro_last_error(altro_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
+
+namespace {
+
+// Create the engine (needs the model) and upload the recorded problem.
+altro_status Ensure(altro_handle h) {
+  if (!h) return ALTRO_INVALID_ARG;
+  if (h->uploaded) return ALTRO_OK;
+  const altro_desc& d = h->spec.desc;
+  if (!h->engine) {
+    EngineBase* e = nullptr;
+    std::string err = "unsupported (model, n, m, dtype) combination";
+    const bool f64 = d.dtype == ALTRO_F64;
+    switch (h->spec.model_kind) {
+      case ALTRO_MODEL_UNICYCLE:
+        e = f64 ? MakeEngineUnicycleF64(d, &err) : MakeEngineUnicycleF32(d, &err);
+        break;
+      case ALTRO_MODEL_TRIPLE_INTEGRATOR:
+        if (h->spec.dof == 2) e = f64 ? MakeEngineTripleInt2F64(d, &err) : MakeEngineTripleInt2F32(d, &err);
+        break;
+      case ALTRO_MODEL_QUADROTOR12:
+        e = f64 ? MakeEngineQuad12F64(d, &err) : MakeEngineQuad12F32(d, &err);
+        break;
+      default:
+        err = "altro_set_model has not been called";
+        break;
+    }
+    if (!e) {
+      h->err = err;
+      return (err.find("hip") != std::string::npos || err.find(".hpp:") != std::string::npos) ? ALTRO_HIP_ERROR
+                                                                                                : ALTRO_UNSUPPORTED;
+    }
+    h->engine.reset(e);
+  }
+  altro_status st = h->engine->Upload(h->spec, &h->err);
+  if (st == ALTRO_OK) h->uploaded = true;
+  return st;
+}
+
+template <class F>
+altro_status Forward(altro_handle h, F f) {
+  altro_status st = Ensure(h);
+  if (st != ALTRO_OK) return st;
+  st = f(*h->engine);
+  if (st != ALTRO_OK) h->err = h->engine->LastError();
+  return st;
+}
+
+altro_status DefChanged(altro_handle h) {
+  if (h->uploaded) {
+    h->err = "the problem definition cannot change after the first compute call; create a new handle";
+    return ALTRO_NOT_READY;
+  }
+  return ALTRO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams) {
+  if (!h) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  h->spec.model_kind = kind;
+  h->spec.dof = (kind == ALTRO_MODEL_TRIPLE_INTEGRATOR && params && nparams > 0) ? (int)params[0] : 0;
+  return ALTRO_OK;
+}
+altro_status altro_set_uniform_step(altro_handle h, float hstep) {
+  if (!h) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  h->spec.hstep = hstep;
+  return ALTRO_OK;
+}
+altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const double* Q, const double* R,
+                                const double* xref, const double* uref, int per_instance) {
+  if (!h || !Q || !R || !xref || !uref) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  const altro_desc& d = h->spec.desc;
+  if (k_begin < 0 || k_end > d.N + 1 || k_begin >= k_end) {
+    h->err = "knot range out of bounds";
+    return ALTRO_INVALID_ARG;
+  }
+  CostSpec c;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.per_instance = per_instance;
+  c.Q.assign(Q, Q + d.n * d.n);
+  c.R.assign(R, R + d.m * d.m);
+  c.xref.assign(xref, xref + (size_t)d.n * ((per_instance & 1) ? d.batch : 1));
+  c.uref.assign(uref, uref + (size_t)d.m * ((per_instance & 2) ? d.batch : 1));
+  h->spec.costs.push_back(std::move(c));
+  return ALTRO_OK;
+}
+altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_end, const double* params,
+                                  int nparams, int per_instance) {
+  if (!h || !params || nparams <= 0) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  const altro_desc& d = h->spec.desc;
+  if (k_begin < 0 || k_end > d.N + 1 || k_begin >= k_end) {
+    h->err = "knot range out of bounds";
+    return ALTRO_INVALID_ARG;
+  }
+  if (kind == ALTRO_CON_CONTROL_BOUND) {
+    // ControlBound::ValidateBounds, examples/basic_constraints.hpp:131-136
+    if (nparams != 2 * d.m) {
+      h->err = "control bound needs lb[m], ub[m]";
+      return ALTRO_INVALID_ARG;
+    }
+    for (int j = 0; j < d.m; ++j)
+      if (!(params[j] <= params[d.m + j])) {
+        h->err = "Lower bound isn't less than the upper bound.";
+        return ALTRO_INVALID_ARG;
+      }
+  }
+  ConSpec c;
+  c.kind = kind;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.nparams = nparams;
+  c.per_instance = per_instance;
+  c.params.assign(params, params + (size_t)nparams * (per_instance ? d.batch : 1));
+  h->spec.cons.push_back(std::move(c));
+  return ALTRO_OK;
+}
+altro_status altro_set_initial_state(altro_handle h, const double* x0, int per_instance) {
+  if (!h || !x0) return ALTRO_INVALID_ARG;
+  const altro_desc& d = h->spec.desc;
+  h->spec.x0.assign(x0, x0 + (size_t)d.n * (per_instance ? d.batch : 1));
+  h->spec.x0_per_instance = per_instance;
+  if (h->uploaded) return h->engine->SetInitialState(h->spec, &h->err);
+  return ALTRO_OK;
+}
+altro_status altro_set_trajectory(altro_handle h, const double* X, const double* U, int per_instance) {
+  if (!h) return ALTRO_INVALID_ARG;
+  const altro_desc& d = h->spec.desc;
+  const size_t mult = per_instance ? d.batch : 1;
+  h->spec.has_X = X != nullptr;
+  h->spec.has_U = U != nullptr;
+  if (X) h->spec.X.assign(X, X + mult * (d.N + 1) * d.n);
+  if (U) h->spec.U.assign(U, U + mult * d.N * d.m);
+  h->spec.traj_per_instance = per_instance;
+  if (h->uploaded) return h->engine->SetTrajectory(h->spec, &h->err);
+  return ALTRO_OK;
+}
+altro_status altro_reset_trajectory(altro_handle h) {
+  return Forward(h, [&](EngineBase& e) { return e.ResetTrajectory(); });
+}
+altro_status altro_set_options(altro_handle h, const altro_options* o) {
+  if (!h || !o) return ALTRO_INVALID_ARG;
+  h->opts = *o;
+  return ALTRO_OK;
+}
+altro_status altro_get_options(altro_handle h, altro_options* o) {
+  if (!h || !o) return ALTRO_INVALID_ARG;
+  *o = h->opts;
+  return ALTRO_OK;
+}
+altro_status altro_set_penalty(altro_handle h, double rho) {
+  if (!h || !(rho >= 0)) return ALTRO_INVALID_ARG;  // ALTRO_ASSERT(rho >= 0), constraint_values.hpp:80
+  h->spec.penalty = rho;
+  if (h->uploaded) return Forward(h, [&](EngineBase& e) { return e.SetPenalty(rho); });
+  return ALTRO_OK;
+}
+altro_status altro_set_penalty_scaling(altro_handle h, double phi) {
+  if (!h || !(phi >= 1)) return ALTRO_INVALID_ARG;  // ALTRO_ASSERT(phi >= 1), constraint_values.hpp:85
+  h->spec.phi = phi;
+  if (h->uploaded) return Forward(h, [&](EngineBase& e) { return e.SetPenaltyScaling(phi); });
+  return ALTRO_OK;
+}
+
+altro_status altro_solve_al(altro_handle h) {
+  if (h) h->ilqr_mode = false;
+  return Forward(h, [&](EngineBase& e) { return e.SolveAL(h->opts); });
+}
+altro_status altro_solve_ilqr(altro_handle h) {
+  if (h) h->ilqr_mode = true;
+  return Forward(h, [&](EngineBase& e) { return e.SolveILQR(h->opts); });
+}
+altro_status altro_al_init(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.AlInit(h->opts); }); }
+altro_status altro_solve_setup(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.SolveSetup(h->opts); }); }
+altro_status altro_rollout(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.Rollout(h->opts); }); }
+altro_status altro_cost(altro_handle h, double* J) { return Forward(h, [&](EngineBase& e) { return e.Cost(h->opts, J); }); }
+altro_status altro_update_expansions(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.UpdateExpansions(h->opts); }); }
+altro_status altro_backward_pass(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.BackwardPass(h->opts); }); }
+altro_status altro_forward_pass(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.ForwardPass(h->opts); }); }
+altro_status altro_update_convergence_statistics(altro_handle h) {
+  return Forward(h, [&](EngineBase& e) { return e.UpdateConvergenceStatistics(h->opts); });
+}
+altro_status altro_update_duals(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.UpdateDuals(h->opts); }); }
+altro_status altro_update_penalties(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.UpdatePenalties(h->opts); }); }
+altro_status altro_get_max_violation(altro_handle h, double* out) {
+  if (!out) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetMaxViolation(out); });
+}
+altro_status altro_max_violation(altro_handle h, double* out) {
+  if (!out) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) {
+    altro_status st = e.Cost(h->opts, nullptr);
+    return st != ALTRO_OK ? st : e.GetMaxViolation(out);
+  });
+}
+altro_status altro_get_max_penalty(altro_handle h, double* out) {
+  if (!out) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetMaxPenalty(out); });
+}
+
+altro_status altro_get_trajectory(altro_handle h, double* X, double* U) {
+  return Forward(h, [&](EngineBase& e) { return e.GetTrajectory(X, U); });
+}
+altro_status altro_get_gains(altro_handle h, double* K, double* d) {
+  return Forward(h, [&](EngineBase& e) { return e.GetGains(K, d); });
+}
+altro_status altro_set_record_ctg(altro_handle h, int enable) {
+  return Forward(h, [&](EngineBase& e) { return e.SetRecordCtg(enable); });
+}
+altro_status altro_get_ctg(altro_handle h, double* P, double* p) {
+  return Forward(h, [&](EngineBase& e) { return e.GetCtg(P, p); });
+}
+altro_status altro_get_expansion(altro_handle h, int k, double* AB, double* lxx, double* lxu, double* luu,
+                                 double* lx, double* lu) {
+  return Forward(h, [&](EngineBase& e) { return e.GetExpansion(k, AB, lxx, lxu, luu, lx, lu); });
+}
+altro_status altro_get_knot_costs(altro_handle h, double* costs) {
+  if (!costs) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetKnotCosts(costs); });
+}
+int altro_num_constraints(altro_handle h) {
+  if (Ensure(h) != ALTRO_OK) return -1;
+  return h->engine->NumRows();
+}
+int altro_num_constraints_at(altro_handle h, int k) {
+  if (Ensure(h) != ALTRO_OK) return -1;
+  return h->engine->NumRowsAt(k);
+}
+altro_status altro_get_duals(altro_handle h, double* lam) {
+  if (!lam) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetRows(0, lam); });
+}
+altro_status altro_set_duals(altro_handle h, const double* lam) {
+  if (!lam) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.SetDuals(lam); });
+}
+altro_status altro_get_penalties(altro_handle h, double* rho) {
+  if (!rho) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetRows(1, rho); });
+}
+altro_status altro_get_constraint_values(altro_handle h, double* c) {
+  if (!c) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetRows(2, c); });
+}
+altro_status altro_get_stats(altro_handle h, altro_stats* stats) {
+  if (!stats) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetStats(stats, h->ilqr_mode); });
+}
+altro_status altro_get_timing(altro_handle h, altro_timing* t) {
+  if (!t) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.GetTiming(t); });
+}
+altro_status altro_set_record_history(altro_handle h, int capacity) {
+  return Forward(h, [&](EngineBase& e) { return e.SetRecordHistory(capacity); });
+}
+int altro_get_history(altro_handle h, int instance, int field, double* out, int cap) {
+  if (Ensure(h) != ALTRO_OK || !out) return -1;
+  return h->engine->GetHistory(instance, field, out, cap);
+}
+altro_status altro_pack_results_device(altro_handle h, void* dst_device) {
+  if (!dst_device) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.PackResultsDevice(dst_device); });
+}
+
+}  // extern "C"

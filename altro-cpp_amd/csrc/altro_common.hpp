@@ -1,0 +1,137 @@
+// altro_common.hpp — host-side types shared by the C-ABI front end (altro_capi.cpp) and the
+// templated device engines (altro_engine.hpp).  No HIP types in here.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/altro_hip.h"
+
+namespace altro_hip {
+
+// ---- compile-time limits of the closed registry ---------------------------------------------------
+constexpr int kMaxConPerKnot = 4;  // constraints attached to one knot point
+constexpr int kMaxClasses = 8;     // distinct (cost, constraint list) combinations over the knots
+constexpr int kMaxCostGroups = 8;
+constexpr int kLineSearchLanes = 20;  // speculative line-search trials evaluated side by side
+constexpr int kHistFields = 8;
+
+// ---- dtype-independent problem specification (what the altro::problem::Problem setters record) ---
+struct CostSpec {
+  int k_begin, k_end;
+  std::vector<double> Q, R, xref, uref;
+  int per_instance;  // bit0 xref, bit1 uref
+};
+struct ConSpec {
+  int kind, k_begin, k_end, nparams, per_instance;
+  std::vector<double> params;
+};
+struct ProblemSpec {
+  altro_desc desc{};
+  int model_kind = 0;
+  int dof = 0;
+  float hstep = 0.0f;
+  std::vector<CostSpec> costs;
+  std::vector<ConSpec> cons;
+  std::vector<double> x0;  // [n] or [B][n]
+  int x0_per_instance = 0;
+  std::vector<double> X, U;  // host layout, instance-major
+  bool has_X = false, has_U = false;
+  int traj_per_instance = 0;
+  double penalty = -1.0;  // SetPenalty issued before the device state exists
+  double phi = -1.0;
+};
+
+// ---- device-visible problem description (lives in global memory, read with scalar loads) ---------
+struct ConDesc {
+  int kind;          // altro_constraint_kind
+  int type;          // 0 equality (dual cone = identity), 1 inequality (negative orthant)
+  int p;             // rows
+  int per_instance;  // params in the per-instance pool ([slot][Bp]) instead of the shared pool
+  int param_off;     // first slot / element of this constraint's parameters
+  int row_off;       // row offset inside the knot
+  unsigned lo_mask;  // CONTROL_BOUND: controls with a finite lower bound (basic_constraints.hpp:138-145)
+  unsigned hi_mask;  // CONTROL_BOUND: controls with a finite upper bound
+};
+struct KnotClass {
+  int cost_group;
+  int ncon;
+  int nrows;
+  int pad;
+  ConDesc con[kMaxConPerKnot];
+};
+struct CostGroupDesc {
+  int Q_off, R_off;          // shared pool, column-major n x n and m x m
+  int q_off, r_off, c_off;   // pool element (shared) or slot (per instance)
+  int q_pi, r_pi, c_pi;      // per-instance flags
+};
+struct ProblemDesc {
+  int n, m, N, B, Bp;
+  int nclass, ngroups, total_rows;
+  KnotClass cls[kMaxClasses];
+  CostGroupDesc grp[kMaxCostGroups];
+};
+
+// Options in the form the kernels consume (copied from altro_options at every launch).
+struct DevOpts {
+  int max_iterations_total, max_iterations_outer, max_iterations_inner;
+  int bp_reg_fail_threshold, check_forwardpass_bounds, line_search_max_iterations, reset_duals, pad;
+  double cost_tolerance, gradient_tolerance;
+  double bp_reg_increase_factor, bp_reg_initial, bp_reg_max, bp_reg_min;
+  double state_max, control_max;
+  double line_search_lower_bound, line_search_upper_bound, line_search_decrease_factor;
+  double constraint_tolerance, maximum_penalty, initial_penalty;
+};
+
+// ---- engine interface ----------------------------------------------------------------------------
+class EngineBase {
+ public:
+  virtual ~EngineBase() {}
+  virtual altro_status Upload(const ProblemSpec& spec, std::string* err) = 0;
+  virtual altro_status SetInitialState(const ProblemSpec& spec, std::string* err) = 0;
+  virtual altro_status SetTrajectory(const ProblemSpec& spec, std::string* err) = 0;
+  virtual altro_status ResetTrajectory() = 0;
+  virtual altro_status SetPenalty(double rho) = 0;
+  virtual altro_status SetPenaltyScaling(double phi) = 0;
+  virtual altro_status SolveAL(const altro_options& o) = 0;
+  virtual altro_status SolveILQR(const altro_options& o) = 0;
+  virtual altro_status AlInit(const altro_options& o) = 0;
+  virtual altro_status SolveSetup(const altro_options& o) = 0;
+  virtual altro_status Rollout(const altro_options& o) = 0;
+  virtual altro_status Cost(const altro_options& o, double* J) = 0;
+  virtual altro_status UpdateExpansions(const altro_options& o) = 0;
+  virtual altro_status BackwardPass(const altro_options& o) = 0;
+  virtual altro_status ForwardPass(const altro_options& o) = 0;
+  virtual altro_status UpdateConvergenceStatistics(const altro_options& o) = 0;
+  virtual altro_status UpdateDuals(const altro_options& o) = 0;
+  virtual altro_status UpdatePenalties(const altro_options& o) = 0;
+  virtual altro_status GetMaxViolation(double* out) = 0;
+  virtual altro_status GetMaxPenalty(double* out) = 0;
+  virtual altro_status GetTrajectory(double* X, double* U) = 0;
+  virtual altro_status GetGains(double* K, double* d) = 0;
+  virtual altro_status SetRecordCtg(int enable) = 0;
+  virtual altro_status GetCtg(double* P, double* p) = 0;
+  virtual altro_status GetExpansion(int k, double* AB, double* lxx, double* lxu, double* luu,
+                                    double* lx, double* lu) = 0;
+  virtual altro_status GetKnotCosts(double* costs) = 0;
+  virtual int NumRows() = 0;
+  virtual int NumRowsAt(int k) = 0;
+  virtual altro_status GetRows(int which /*0 lam,1 pen,2 cval*/, double* out) = 0;
+  virtual altro_status SetDuals(const double* lam) = 0;
+  virtual altro_status GetStats(altro_stats* st, bool ilqr_mode) = 0;
+  virtual altro_status GetTiming(altro_timing* t) = 0;
+  virtual altro_status SetRecordHistory(int capacity) = 0;
+  virtual int GetHistory(int instance, int field, double* out, int cap) = 0;
+  virtual altro_status PackResultsDevice(void* dst) = 0;
+  virtual const char* LastError() = 0;
+};
+
+// One factory per (dtype, model) translation unit (inst_*.hip); returns nullptr if dims mismatch.
+EngineBase* MakeEngineUnicycleF64(const altro_desc& d, std::string* err);
+EngineBase* MakeEngineUnicycleF32(const altro_desc& d, std::string* err);
+EngineBase* MakeEngineTripleInt2F64(const altro_desc& d, std::string* err);
+EngineBase* MakeEngineTripleInt2F32(const altro_desc& d, std::string* err);
+EngineBase* MakeEngineQuad12F64(const altro_desc& d, std::string* err);
+EngineBase* MakeEngineQuad12F32(const altro_desc& d, std::string* err);
+
+}  // namespace altro_hip

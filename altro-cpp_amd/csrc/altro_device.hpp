@@ -1,0 +1,743 @@
+// altro_device.hpp — per-knot-point device math of the batched AL-iLQR solver (gfx950).
+//
+// Data layout in HBM is struct-of-arrays with the BATCH index innermost ("batch-minor"): element e
+// of knot k of instance b lives at arr[(k*E + e)*Bp + b], so the 64 lanes of a wavefront, which
+// always hold 64 consecutive instances (or a few instances x line-search trials), issue fully
+// coalesced 512-byte loads and stores.  All per-knot matrices are tiny (n<=12, m<=4) and live in
+// VGPRs as fully unrolled arrays; nothing here touches scratch memory.
+//
+// Every function cites the reference code it replaces (paths relative to the reference root).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "altro_common.hpp"
+
+namespace altro_hip {
+
+#define ALTRO_DEV __device__ __forceinline__
+
+// -------------------------------------------------------------------------------------------------
+// Device array bundle (passed to kernels by value)
+// -------------------------------------------------------------------------------------------------
+template <class T>
+struct DevArrays {
+  int B, Bp, N;
+  // trajectory (Z_), initial state
+  T *x0, *X, *U;
+  // expansions: dynamics Jacobian [A|B], cost expansion, per-knot cost
+  T *AB, *lxx, *lxu, *luu, *lx, *lu, *costs;
+  // gains, cost-to-go (P, p recorded per knot only on request)
+  T *K, *d, *P, *p;
+  // constraint rows: duals, penalties, stored constraint values (c_)
+  T *lam, *pen, *cval;
+  // parameters
+  const T *pool, *ipool;
+  const int *knot_class, *knot_rowbase;
+  const float* hstep;
+  const double* phi;  // penalty scaling per (class, constraint): phi[cls*kMaxConPerKnot + c]
+  // per-instance solver state
+  T *rho_reg, *drho, *dV0, *dV1, *J0, *initial_cost, *cost_cur, *cost_prev, *dJ, *grad, *viol,
+      *penmax, *alpha, *z, *reg_log;
+  int *status, *status_al, *it_inner, *it_outer, *it_total, *phase, *need_init_cost;
+  // optional per-iteration history [field][cap][Bp]
+  T* hist;
+  int* hist_len;
+  int hist_cap;
+  int record_ctg;
+};
+
+template <class T>
+ALTRO_DEV void sincos_(T x, T* s, T* c);
+template <>
+ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
+  sincos(x, s, c);
+}
+template <>
+ALTRO_DEV void sincos_<float>(float x, float* s, float* c) {
+  sincosf(x, s, c);
+}
+template <class T>
+ALTRO_DEV T sqrt_(T x);
+template <>
+ALTRO_DEV double sqrt_<double>(double x) {
+  return sqrt(x);
+}
+template <>
+ALTRO_DEV float sqrt_<float>(float x) {
+  return sqrtf(x);
+}
+template <class T>
+ALTRO_DEV T abs_(T x) {
+  return x < T(0) ? -x : x;
+}
+template <class T>
+ALTRO_DEV T min_(T a, T b) {
+  return b < a ? b : a;
+}
+template <class T>
+ALTRO_DEV T max_(T a, T b) {
+  return a < b ? b : a;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Continuous-time models (closed registry).  jac = [A|B], n x (n+m) column-major, fully written.
+// -------------------------------------------------------------------------------------------------
+struct UnicycleM {  // examples/unicycle.cpp:12-33
+  static constexpr int n = 3, m = 2;
+  template <class T>
+  static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
+    T s, c;
+    sincos_(x[2], &s, &c);
+    xd[0] = u[0] * c;
+    xd[1] = u[0] * s;
+    xd[2] = u[1];
+  }
+  template <class T>
+  static ALTRO_DEV void jac(const T* x, const T* u, T* J) {
+#pragma unroll
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+    T s, c;
+    sincos_(x[2], &s, &c);
+    J[0 + 2 * n] = -u[0] * s;
+    J[0 + 3 * n] = c;
+    J[1 + 2 * n] = u[0] * c;
+    J[1 + 3 * n] = s;
+    J[2 + 4 * n] = T(1);
+  }
+};
+
+template <int DOF>
+struct TripleIntegratorM {  // examples/triple_integrator.cpp:9-33
+  static constexpr int n = 3 * DOF, m = DOF;
+  template <class T>
+  static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+      xd[i] = x[i + DOF];
+      xd[i + DOF] = x[i + 2 * DOF];
+      xd[i + 2 * DOF] = u[i];
+    }
+  }
+  template <class T>
+  static ALTRO_DEV void jac(const T*, const T*, T* J) {
+#pragma unroll
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+      J[i + (i + DOF) * n] = T(1);
+      J[(i + DOF) + (i + 2 * DOF) * n] = T(1);
+      J[(i + 2 * DOF) + (i + 3 * DOF) * n] = T(1);
+    }
+  }
+};
+
+// Build-defined 12-state / 4-control model of BASELINE config 5 (no reference counterpart):
+// x = (p, phi, v, w), u = (a, tau);  p' = v, phi' = w, v' = ((g+a) phi_y, -(g+a) phi_x, a), w' = tau.
+struct Quadrotor12M {
+  static constexpr int n = 12, m = 4;
+  template <class T>
+  static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
+    const T g = T(9.81);
+    T a = u[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      xd[i] = x[6 + i];
+      xd[3 + i] = x[9 + i];
+      xd[9 + i] = u[1 + i];
+    }
+    xd[6] = (g + a) * x[4];
+    xd[7] = -(g + a) * x[3];
+    xd[8] = a;
+  }
+  template <class T>
+  static ALTRO_DEV void jac(const T* x, const T* u, T* J) {
+    const T g = T(9.81);
+#pragma unroll
+    for (int i = 0; i < n * (n + m); ++i) J[i] = T(0);
+    T a = u[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      J[i + (6 + i) * n] = T(1);
+      J[(3 + i) + (9 + i) * n] = T(1);
+      J[(9 + i) + (n + 1 + i) * n] = T(1);
+    }
+    J[6 + 4 * n] = g + a;
+    J[7 + 3 * n] = -(g + a);
+    J[6 + n * n] = x[4];
+    J[7 + n * n] = -x[3];
+    J[8 + n * n] = T(1);
+  }
+};
+
+// -------------------------------------------------------------------------------------------------
+// RK4 (altro/problem/integration.hpp:123-169); h is a 32-bit float promoted to T (quirk Q1)
+// -------------------------------------------------------------------------------------------------
+template <class T, class M>
+ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn) {
+  constexpr int n = M::n;
+  T k1[n], k2[n], k3[n], k4[n], xt[n];
+  M::f(x, u, k1);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
+  M::f(xt, u, k2);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
+  M::f(xt, u, k3);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
+  M::f(xt, u, k4);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xn[i] = x[i] + hh * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+}
+
+template <class T, class M>
+ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  T k1[n], k2[n], k3[n], xt[n];
+  T Jc[n * nm];
+  T dA[n * n], dB[n * m], sA[n * n], sB[n * m];
+  M::f(x, u, k1);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
+  M::f(xt, u, k2);
+#pragma unroll
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
+  M::f(xt, u, k3);
+  // stage 0
+  M::jac(x, u, Jc);
+#pragma unroll
+  for (int e = 0; e < n * n; ++e) {
+    dA[e] = Jc[e] * hh;
+    sA[e] = dA[e];
+  }
+#pragma unroll
+  for (int e = 0; e < n * m; ++e) {
+    dB[e] = Jc[n * n + e] * hh;
+    sB[e] = dB[e];
+  }
+  // stages 1..3: dA_s = A_s (I + c dA_{s-1}) h ; dB_s = B_s h + c A_s dB_{s-1} h
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    const T coef = (s == 3) ? T(1) : T(0.5);
+    const T wgt = (s == 3) ? T(1) : T(2);
+    if (s == 1) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k1[i] * hh;
+    } else if (s == 2) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k2[i] * hh;
+    } else {
+#pragma unroll
+      for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
+    }
+    M::jac(xt, u, Jc);
+    T Mx[n * n], nA[n * n], nB[n * m];
+#pragma unroll
+    for (int j = 0; j < n; ++j)
+#pragma unroll
+      for (int i = 0; i < n; ++i) Mx[i + j * n] = (i == j ? T(1) : T(0)) + coef * dA[i + j * n];
+#pragma unroll
+    for (int j = 0; j < n; ++j)
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < n; ++l) acc += Jc[i + l * n] * Mx[l + j * n];
+        nA[i + j * n] = acc * hh;
+      }
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < n; ++l) acc += Jc[i + l * n] * dB[l + j * n];
+        nB[i + j * n] = Jc[n * n + i + j * n] * hh + coef * acc * hh;
+      }
+#pragma unroll
+    for (int e = 0; e < n * n; ++e) {
+      dA[e] = nA[e];
+      sA[e] = sA[e] + wgt * nA[e];
+    }
+#pragma unroll
+    for (int e = 0; e < n * m; ++e) {
+      dB[e] = nB[e];
+      sB[e] = sB[e] + wgt * nB[e];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < n; ++j)
+#pragma unroll
+    for (int i = 0; i < n; ++i) J[i + j * n] = (i == j ? T(1) : T(0)) + sA[i + j * n] / 6;
+#pragma unroll
+  for (int e = 0; e < n * m; ++e) J[n * n + e] = sB[e] / 6;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Per-knot problem access
+// -------------------------------------------------------------------------------------------------
+template <class T>
+struct KnotCtx {
+  const DevArrays<T>& A;
+  const ProblemDesc* pd;
+  int b;
+  ALTRO_DEV T par(int per_instance, int off, int i) const {
+    return per_instance ? A.ipool[(size_t)(off + i) * A.Bp + b] : A.pool[off + i];
+  }
+  ALTRO_DEV T& row(T* arr, int r) const { return arr[(size_t)r * A.Bp + b]; }
+};
+
+// Dual-cone projection and its (diagonal) Jacobian (altro/constraints/constraint.hpp:70-78 for
+// equalities, :103-114 for inequalities; quirk Q5: v == 0 counts as active).
+template <class T>
+ALTRO_DEV T dual_proj(int type, T v) {
+  return type == 0 ? v : min_(T(0), v);
+}
+template <class T>
+ALTRO_DEV T dual_proj_jac(int type, T v) {
+  return type == 0 ? T(1) : (v > T(0) ? T(0) : T(1));
+}
+// c - Pi_K(c): |c| for equalities, max(c, 0) for inequalities (constraint_values.hpp:215-220)
+template <class T>
+ALTRO_DEV T violation(int type, T c) {
+  return type == 0 ? abs_(c) : abs_(c - min_(T(0), c));
+}
+
+// QuadraticCost::Evaluate (examples/quadratic_cost.cpp:8-11); H == 0 for LQRCost.
+template <class T, int n, int m>
+ALTRO_DEV T quad_cost(const KnotCtx<T>& C, const CostGroupDesc& g, const T* x, const T* u) {
+  T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < n; ++j) s += C.A.pool[g.Q_off + i + j * n] * x[j];
+    xQx += x[i] * s;
+    qx += C.par(g.q_pi, g.q_off, i) * x[i];
+  }
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < m; ++j) s += C.A.pool[g.R_off + i + j * m] * u[j];
+    uRu += u[i] * s;
+    ru += C.par(g.r_pi, g.r_off, i) * u[i];
+  }
+  return T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
+}
+
+// ALCost::Evaluate (al_cost.hpp:264-274) = quadratic cost + sum of ConstraintValues::AugLag
+// (constraint_values.hpp:111-119, quirk Q2: scalar rho = penalty_(0)).
+// STORE: also store c_ (the side effect every Evaluate has in the reference, quirk Q6) and return
+// the knot's max violation through *viol.
+template <class T, int n, int m, bool STORE>
+ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* viol) {
+  const KnotClass& kc = C.pd->cls[C.A.knot_class[k]];
+  T J = quad_cost<T, n, m>(C, C.pd->grp[kc.cost_group], x, u);
+  const int rb = C.A.knot_rowbase[k];
+  T vmax = T(0);
+  for (int ci = 0; ci < kc.ncon; ++ci) {
+    const ConDesc& cd = kc.con[ci];
+    const int r0 = rb + cd.row_off;
+    const T rho = C.row(C.A.pen, r0);
+    T a = T(0), bsum = T(0);
+    if (cd.kind == ALTRO_CON_GOAL) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        T c = x[i] - C.par(cd.per_instance, cd.param_off, i);
+        T lam = C.row(C.A.lam, r0 + i);
+        T lp = dual_proj(cd.type, lam - rho * c);
+        a += lp * lp;
+        bsum += lam * lam;
+        if (STORE) {
+          C.row(C.A.cval, r0 + i) = c;
+          vmax = max_(vmax, violation(cd.type, c));
+        }
+      }
+    } else if (cd.kind == ALTRO_CON_CONTROL_BOUND) {
+      int r = r0, pi = cd.param_off;
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.lo_mask >> j) & 1u) {
+          T c = C.A.pool[pi] - u[j];
+          T lam = C.row(C.A.lam, r);
+          T lp = dual_proj(1, lam - rho * c);
+          a += lp * lp;
+          bsum += lam * lam;
+          if (STORE) {
+            C.row(C.A.cval, r) = c;
+            vmax = max_(vmax, violation(1, c));
+          }
+          ++r;
+          ++pi;
+        }
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.hi_mask >> j) & 1u) {
+          T c = u[j] - C.A.pool[pi];
+          T lam = C.row(C.A.lam, r);
+          T lp = dual_proj(1, lam - rho * c);
+          a += lp * lp;
+          bsum += lam * lam;
+          if (STORE) {
+            C.row(C.A.cval, r) = c;
+            vmax = max_(vmax, violation(1, c));
+          }
+          ++r;
+          ++pi;
+        }
+    } else {  // CIRCLE (examples/obstacle_constraints.hpp:99-107)
+      for (int i = 0; i < cd.p; ++i) {
+        T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
+        T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
+        T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
+        T c = -(dx * dx + dy * dy - rr * rr);
+        T lam = C.row(C.A.lam, r0 + i);
+        T lp = dual_proj(1, lam - rho * c);
+        a += lp * lp;
+        bsum += lam * lam;
+        if (STORE) {
+          C.row(C.A.cval, r0 + i) = c;
+          vmax = max_(vmax, violation(1, c));
+        }
+      }
+    }
+    T Jc = a - bsum;
+    J += Jc / (2 * rho);
+  }
+  if (STORE && viol) *viol = vmax;
+  return J;
+}
+
+// Cost expansion of one knot: QuadraticCost::Gradient/Hessian + ConstraintValues::AugLagGradient /
+// AugLagHessian for every constraint (al_cost.hpp:276-308, quadratic_cost.cpp:13-28,
+// constraint_values.hpp:131-177).  Also returns the AL cost (ilqr.hpp:675) and stores c_.
+template <class T, int n, int m>
+ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T* u, T* gx, T* gu,
+                                T* hxx, T* hxu, T* huu) {
+  const KnotClass& kc = C.pd->cls[C.A.knot_class[k]];
+  const CostGroupDesc& g = C.pd->grp[kc.cost_group];
+  T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      T q = C.A.pool[g.Q_off + i + j * n];
+      hxx[i + j * n] = q;
+      s += q * x[j];
+    }
+    T qi = C.par(g.q_pi, g.q_off, i);
+    gx[i] = s + qi;  // (Qx + q) + Hu with H == 0
+    xQx += x[i] * s;
+    qx += qi * x[i];
+  }
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      T r = C.A.pool[g.R_off + i + j * m];
+      huu[i + j * m] = r;
+      s += r * u[j];
+    }
+    T ri = C.par(g.r_pi, g.r_off, i);
+    gu[i] = s + ri;
+    uRu += u[i] * s;
+    ru += ri * u[i];
+  }
+#pragma unroll
+  for (int e = 0; e < n * m; ++e) hxu[e] = T(0);
+  T J = T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
+
+  const int rb = C.A.knot_rowbase[k];
+  for (int ci = 0; ci < kc.ncon; ++ci) {
+    const ConDesc& cd = kc.con[ci];
+    const int r0 = rb + cd.row_off;
+    const T rho = C.row(C.A.pen, r0);
+    T a = T(0), bsum = T(0);
+    if (cd.kind == ALTRO_CON_GOAL) {
+      // C_x = I, C_u = 0: gradient -(P C)^T lambda_bar, Gauss-Newton Hessian rho (PC)^T(PC)
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        T c = x[i] - C.par(cd.per_instance, cd.param_off, i);
+        T lam = C.row(C.A.lam, r0 + i);
+        T v = lam - rho * c;
+        T lp = dual_proj(cd.type, v);
+        T pj = dual_proj_jac(cd.type, v);
+        a += lp * lp;
+        bsum += lam * lam;
+        C.row(C.A.cval, r0 + i) = c;
+        gx[i] += -(pj * lp);
+        hxx[i + i * n] += (rho * pj) * pj;
+      }
+    } else if (cd.kind == ALTRO_CON_CONTROL_BOUND) {
+      // rows: finite lower bounds (c = lb - u_j, dc/du_j = -1), then finite upper bounds (+1)
+      T sg[m], sh[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) sg[j] = sh[j] = T(0);
+      int r = r0, pi = cd.param_off;
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.lo_mask >> j) & 1u) {
+          T c = C.A.pool[pi] - u[j];
+          T lam = C.row(C.A.lam, r);
+          T v = lam - rho * c;
+          T lp = dual_proj(1, v);
+          T jp = dual_proj_jac(1, v) * T(-1);
+          a += lp * lp;
+          bsum += lam * lam;
+          C.row(C.A.cval, r) = c;
+          sg[j] += jp * lp;
+          sh[j] += (rho * jp) * jp;
+          ++r;
+          ++pi;
+        }
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.hi_mask >> j) & 1u) {
+          T c = u[j] - C.A.pool[pi];
+          T lam = C.row(C.A.lam, r);
+          T v = lam - rho * c;
+          T lp = dual_proj(1, v);
+          T jp = dual_proj_jac(1, v);
+          a += lp * lp;
+          bsum += lam * lam;
+          C.row(C.A.cval, r) = c;
+          sg[j] += jp * lp;
+          sh[j] += (rho * jp) * jp;
+          ++r;
+          ++pi;
+        }
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        gu[j] += -sg[j];
+        huu[j + j * m] += sh[j];
+      }
+    } else {  // CIRCLE: dc_i/d(px,py) = (2(cx-px), 2(cy-py)) (obstacle_constraints.hpp:109-121)
+      T g0 = T(0), g1 = T(0), h00 = T(0), h10 = T(0), h01 = T(0), h11 = T(0);
+      for (int i = 0; i < cd.p; ++i) {
+        T cx = C.par(cd.per_instance, cd.param_off, 3 * i);
+        T cy = C.par(cd.per_instance, cd.param_off, 3 * i + 1);
+        T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
+        T dx = x[0] - cx, dy = x[1] - cy;
+        T c = -(dx * dx + dy * dy - rr * rr);
+        T lam = C.row(C.A.lam, r0 + i);
+        T v = lam - rho * c;
+        T lp = dual_proj(1, v);
+        T pj = dual_proj_jac(1, v);
+        a += lp * lp;
+        bsum += lam * lam;
+        C.row(C.A.cval, r0 + i) = c;
+        T j0 = pj * (2 * (cx - x[0]));
+        T j1 = pj * (2 * (cy - x[1]));
+        g0 += j0 * lp;
+        g1 += j1 * lp;
+        h00 += (rho * j0) * j0;
+        h10 += (rho * j1) * j0;
+        h01 += (rho * j0) * j1;
+        h11 += (rho * j1) * j1;
+      }
+      gx[0] += -g0;
+      gx[1] += -g1;
+      hxx[0 + 0 * n] += h00;
+      hxx[1 + 0 * n] += h10;
+      hxx[0 + 1 * n] += h01;
+      hxx[1 + 1 * n] += h11;
+    }
+    T Jc = a - bsum;
+    J += Jc / (2 * rho);
+  }
+  return J;
+}
+
+// -------------------------------------------------------------------------------------------------
+// One knot of the backward Riccati recursion: CalcActionValueExpansion, RegularizeActionValue,
+// CalcGains, CalcCostToGo, AddCostToGo (altro/ilqr/knot_point_function_type.hpp:149-235).
+// In: [A|B], cost expansion, P/p of knot k+1, regularisation rho.  Out (only on success): K, d,
+// P/p of knot k (overwritten in place), dV += (d^T Qu, 0.5 d^T Quu d).  Returns false when the
+// Cholesky factorisation of Quu + rho I hits a non-positive pivot (Eigen::NumericalIssue).
+// Gains come from the REGULARISED Q, cost-to-go from the UN-regularised Q (quirk Q3).
+// -------------------------------------------------------------------------------------------------
+template <class T, int n, int m>
+ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* luu, const T* lx,
+                            const T* lu, T rho, T* P, T* p, T* K, T* d, T* dV0, T* dV1) {
+  const T* A = AB;
+  const T* Bm = AB + n * n;
+  T AtP[n * n], BtP[m * n];
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < n; ++l) s += A[l + i * n] * P[l + j * n];
+      AtP[i + j * n] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < n; ++l) s += Bm[l + i * n] * P[l + j * n];
+      BtP[i + j * m] = s;
+    }
+  }
+  T Qxx[n * n], Qxu[n * m], Quu[m * m], Qx[n], Qu[m];
+#pragma unroll
+  for (int j = 0; j < n; ++j)
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < n; ++l) s += AtP[i + l * n] * A[l + j * n];
+      Qxx[i + j * n] = lxx[i + j * n] + s;
+    }
+#pragma unroll
+  for (int j = 0; j < m; ++j)
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < n; ++l) s += AtP[i + l * n] * Bm[l + j * n];
+      Qxu[i + j * n] = lxu[i + j * n] + s;
+    }
+#pragma unroll
+  for (int j = 0; j < m; ++j)
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < n; ++l) s += BtP[i + l * m] * Bm[l + j * n];
+      Quu[i + j * m] = luu[i + j * m] + s;
+    }
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int l = 0; l < n; ++l) s += A[l + i * n] * p[l];
+    Qx[i] = lx[i] + s;
+  }
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int l = 0; l < n; ++l) s += Bm[l + i * n] * p[l];
+    Qu[i] = lu[i] + s;
+  }
+  // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure
+  T L[m * m];
+#pragma unroll
+  for (int e = 0; e < m * m; ++e) L[e] = Quu[e];
+#pragma unroll
+  for (int i = 0; i < m; ++i) L[i + i * m] += rho;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < m; ++j) {
+    T xjj = L[j + j * m];
+#pragma unroll
+    for (int l = 0; l < j; ++l) xjj -= L[j + l * m] * L[j + l * m];
+    if (xjj <= T(0)) ok = false;
+    T ljj = sqrt_(xjj);
+    L[j + j * m] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < m; ++i) {
+      T s = L[i + j * m];
+#pragma unroll
+      for (int l = 0; l < j; ++l) s -= L[i + l * m] * L[j + l * m];
+      L[i + j * m] = s / ljj;
+    }
+  }
+  if (!ok) return false;
+  // K = -(L L^T)^-1 Qxu^T (m x n), d = -(L L^T)^-1 Qu
+#pragma unroll
+  for (int j = 0; j <= n; ++j) {
+    T col[m];
+#pragma unroll
+    for (int i = 0; i < m; ++i) col[i] = (j < n) ? Qxu[(j < n ? j : 0) + i * n] : Qu[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      T s = col[i];
+#pragma unroll
+      for (int l = 0; l < i; ++l) s -= L[i + l * m] * col[l];
+      col[i] = s / L[i + i * m];
+    }
+#pragma unroll
+    for (int i = m - 1; i >= 0; --i) {
+      T s = col[i];
+#pragma unroll
+      for (int l = i + 1; l < m; ++l) s -= L[l + i * m] * col[l];
+      col[i] = s / L[i + i * m];
+    }
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      if (j < n)
+        K[i + (j < n ? j : 0) * m] = -col[i];
+      else
+        d[i] = -col[i];
+    }
+  }
+  // cost-to-go with the un-regularised Q (knot_point_function_type.hpp:220-230)
+  T KtQuu[n * m];
+#pragma unroll
+  for (int j = 0; j < m; ++j)
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int l = 0; l < m; ++l) s += K[l + i * m] * Quu[l + j * m];
+      KtQuu[i + j * n] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T a = T(0), b = T(0), c = T(0);
+#pragma unroll
+    for (int l = 0; l < m; ++l) {
+      a += KtQuu[i + l * n] * d[l];
+      b += K[l + i * m] * Qu[l];
+      c += Qxu[i + l * n] * d[l];
+    }
+    p[i] = Qx[i] + a + b + c;
+  }
+#pragma unroll
+  for (int j = 0; j < n; ++j)
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      T a = T(0), b = T(0), c = T(0);
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        a += KtQuu[i + l * n] * K[l + j * m];
+        b += K[l + i * m] * Qxu[j + l * n];
+        c += Qxu[i + l * n] * K[l + j * m];
+      }
+      P[i + j * n] = Qxx[i + j * n] + a + b + c;
+    }
+  T v0 = T(0), v1 = T(0);
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    v0 += d[i] * Qu[i];
+    T s = T(0);
+#pragma unroll
+    for (int l = 0; l < m; ++l) s += Quu[i + l * m] * d[l];
+    v1 += d[i] * s;
+  }
+  *dV0 += v0;
+  *dV1 += T(0.5) * v1;
+  return true;
+}
+
+// iLQR::IncreaseRegularization / DecreaseRegularization (altro/ilqr/ilqr.hpp:770-786)
+template <class T>
+ALTRO_DEV void increase_reg(const DevOpts& o, T* rho, T* drho) {
+  *drho = max_(*drho * T(o.bp_reg_increase_factor), T(o.bp_reg_increase_factor));
+  *rho = max_(*rho * *drho, T(o.bp_reg_min));
+  *rho = min_(*rho, T(o.bp_reg_max));
+}
+template <class T>
+ALTRO_DEV void decrease_reg(const DevOpts& o, T* rho, T* drho) {
+  *drho = min_(*drho / T(o.bp_reg_increase_factor), T(1) / T(o.bp_reg_increase_factor));
+  *rho = max_(*rho * *drho, T(o.bp_reg_min));
+  *rho = min_(*rho, T(o.bp_reg_max));
+}
+
+}  // namespace altro_hip

@@ -1,0 +1,861 @@
+// altro_engine.hpp — host orchestration of the batched AL-iLQR kernels for one (dtype, model).
+//
+// Owns the device state of one handle (one device, one HIP stream) and drives the sweeps:
+//   AL solve  = k_al_init, k_solve_setup, k_rollout, then { k_expansions, k_backward, k_forward }
+//               until no instance is active.  The host runs ONE SWEEP AHEAD of the device: sweep
+//               i+1 is enqueued before the active-instance counter of sweep i is read back, so the
+//               stream never drains (an all-idle sweep costs three empty launches).
+// Instantiated once per translation unit (inst_*.hip).
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "altro_kernels.hpp"
+
+namespace altro_hip {
+
+#define ALTRO_HIP_CHECK(expr)                                                                  \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof(buf_), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+               hipGetErrorString(e_));                                                         \
+      err_ = buf_;                                                                             \
+      return ALTRO_HIP_ERROR;                                                                  \
+    }                                                                                          \
+  } while (0)
+
+inline DevOpts ToDevOpts(const altro_options& o) {
+  DevOpts d{};
+  d.max_iterations_total = o.max_iterations_total;
+  d.max_iterations_outer = o.max_iterations_outer;
+  d.max_iterations_inner = o.max_iterations_inner;
+  d.bp_reg_fail_threshold = o.bp_reg_fail_threshold;
+  d.check_forwardpass_bounds = o.check_forwardpass_bounds;
+  d.line_search_max_iterations = o.line_search_max_iterations;
+  d.reset_duals = o.reset_duals;
+  d.cost_tolerance = o.cost_tolerance;
+  d.gradient_tolerance = o.gradient_tolerance;
+  d.bp_reg_increase_factor = o.bp_reg_increase_factor;
+  d.bp_reg_initial = o.bp_reg_initial;
+  d.bp_reg_max = o.bp_reg_max;
+  d.bp_reg_min = o.bp_reg_min;
+  d.state_max = o.state_max;
+  d.control_max = o.control_max;
+  d.line_search_lower_bound = o.line_search_lower_bound;
+  d.line_search_upper_bound = o.line_search_upper_bound;
+  d.line_search_decrease_factor = o.line_search_decrease_factor;
+  d.constraint_tolerance = o.constraint_tolerance;
+  d.maximum_penalty = o.maximum_penalty;
+  d.initial_penalty = o.initial_penalty;
+  return d;
+}
+
+template <class T, class M>
+class Engine final : public EngineBase {
+  static constexpr int n = M::n, m = M::m, nm = n + m;
+  static constexpr int kRing = 4;
+
+ public:
+  explicit Engine(const altro_desc& d) : desc_(d) {}
+  ~Engine() override { Release(); }
+  const char* LastError() override { return err_.c_str(); }
+
+  altro_status Init() {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    ALTRO_HIP_CHECK(hipHostMalloc((void**)&h_counter_, kRing * sizeof(int)));
+    ALTRO_HIP_CHECK(hipMalloc((void**)&d_counter_, kRing * sizeof(int)));
+    for (int i = 0; i < kRing; ++i) ALTRO_HIP_CHECK(hipEventCreateWithFlags(&ring_ev_[i], hipEventDisableTiming));
+    return ALTRO_OK;
+  }
+
+  // ---- problem upload -------------------------------------------------------------------------
+  altro_status Upload(const ProblemSpec& spec, std::string* err) override {
+    altro_status st = UploadImpl(spec);
+    if (st != ALTRO_OK && err) *err = err_;
+    return st;
+  }
+  altro_status SetInitialState(const ProblemSpec& spec, std::string* err) override {
+    altro_status st = SetInitialStateImpl(spec);
+    if (st != ALTRO_OK && err) *err = err_;
+    return st;
+  }
+  altro_status SetTrajectory(const ProblemSpec& spec, std::string* err) override {
+    altro_status st = SetTrajectoryImpl(spec);
+    if (st != ALTRO_OK && err) *err = err_;
+    return st;
+  }
+
+  altro_status ResetTrajectory() override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * n * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.U, U_init_, (size_t)N_ * m * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    return ALTRO_OK;
+  }
+  altro_status SetPenalty(double rho) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_set_rows<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 0, 1, T(rho));
+    return Sync();
+  }
+  altro_status SetPenaltyScaling(double phi) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    std::vector<double> v(kMaxClasses * kMaxConPerKnot, phi);
+    ALTRO_HIP_CHECK(hipMemcpy(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    return ALTRO_OK;
+  }
+
+  // ---- solves -----------------------------------------------------------------------------------
+  altro_status SolveAL(const altro_options& o) override { return Solve(o, kFwdAL); }
+  altro_status SolveILQR(const altro_options& o) override { return Solve(o, kFwdILQR); }
+
+  altro_status AlInit(const altro_options& o) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    const DevOpts d = ToDevOpts(o);
+    hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+    hipLaunchKernelGGL((k_knot_costs<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_);
+    hipLaunchKernelGGL(k_log_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_);
+    return Sync();
+  }
+  altro_status SolveSetup(const altro_options& o) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, ToDevOpts(o), 0);
+    return Sync();
+  }
+  altro_status Rollout(const altro_options&) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, 1);
+    return Sync();
+  }
+  altro_status Cost(const altro_options&, double* J) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_knot_costs<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_);
+    hipLaunchKernelGGL(k_sum_costs<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_tmp_);
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    if (J) return DownloadVec(d_tmp_, J);
+    return ALTRO_OK;
+  }
+  altro_status UpdateExpansions(const altro_options&) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
+    return Sync();
+  }
+  altro_status BackwardPass(const altro_options& o) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_backward<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, ToDevOpts(o), 1);
+    return Sync();
+  }
+  altro_status ForwardPass(const altro_options& o) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_forward<T, M>), GridF(), dim3(kBlock), 0, stream_, A_, d_pd_, ToDevOpts(o),
+                       (int)kFwdStepOnly, 1, (int*)nullptr);
+    return Sync();
+  }
+  altro_status UpdateConvergenceStatistics(const altro_options& o) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL((k_conv_stats<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, ToDevOpts(o));
+    return Sync();
+  }
+  altro_status UpdateDuals(const altro_options&) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_update_duals<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_);
+    return Sync();
+  }
+  altro_status UpdatePenalties(const altro_options&) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_update_penalties<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_);
+    return Sync();
+  }
+  altro_status GetMaxViolation(double* out) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d_tmp_, (T*)nullptr);
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    return DownloadVec(d_tmp_, out);
+  }
+  altro_status GetMaxPenalty(double* out) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, (T*)nullptr, d_tmp_);
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    return DownloadVec(d_tmp_, out);
+  }
+
+  // ---- results ----------------------------------------------------------------------------------
+  altro_status GetTrajectory(double* X, double* U) override {
+    if (X) {
+      altro_status st = DownloadKnots(A_.X, N_ + 1, n, X);
+      if (st != ALTRO_OK) return st;
+    }
+    if (U) return DownloadKnots(A_.U, N_, m, U);
+    return ALTRO_OK;
+  }
+  altro_status GetGains(double* K, double* d) override {
+    if (K) {
+      altro_status st = DownloadKnots(A_.K, N_, m * n, K);
+      if (st != ALTRO_OK) return st;
+    }
+    if (d) return DownloadKnots(A_.d, N_, m, d);
+    return ALTRO_OK;
+  }
+  altro_status SetRecordCtg(int enable) override {
+    A_.record_ctg = enable ? 1 : 0;
+    return ALTRO_OK;
+  }
+  altro_status GetCtg(double* P, double* p) override {
+    if (!A_.record_ctg) {
+      err_ = "cost-to-go is only recorded after altro_set_record_ctg(h, 1)";
+      return ALTRO_NOT_READY;
+    }
+    if (P) {
+      altro_status st = DownloadKnots(A_.P, N_ + 1, n * n, P);
+      if (st != ALTRO_OK) return st;
+    }
+    if (p) return DownloadKnots(A_.p, N_ + 1, n, p);
+    return ALTRO_OK;
+  }
+  altro_status GetExpansion(int k, double* AB, double* lxx, double* lxu, double* luu, double* lx,
+                            double* lu) override {
+    if (k < 0 || k > N_) return ALTRO_INVALID_ARG;
+    altro_status st = ALTRO_OK;
+    if (AB && k < N_) st = DownloadOneKnot(A_.AB, k, n * nm, AB);
+    if (st == ALTRO_OK && lxx) st = DownloadOneKnot(A_.lxx, k, n * n, lxx);
+    if (st == ALTRO_OK && lxu && k < N_) st = DownloadOneKnot(A_.lxu, k, n * m, lxu);
+    if (st == ALTRO_OK && luu && k < N_) st = DownloadOneKnot(A_.luu, k, m * m, luu);
+    if (st == ALTRO_OK && lx) st = DownloadOneKnot(A_.lx, k, n, lx);
+    if (st == ALTRO_OK && lu && k < N_) st = DownloadOneKnot(A_.lu, k, m, lu);
+    return st;
+  }
+  altro_status GetKnotCosts(double* costs) override { return DownloadKnots(A_.costs, N_ + 1, 1, costs); }
+  int NumRows() override { return pd_.total_rows; }
+  int NumRowsAt(int k) override {
+    if (k < 0 || k > N_) return -1;
+    return pd_.cls[knot_class_[k]].nrows;
+  }
+  altro_status GetRows(int which, double* out) override {
+    T* src = which == 0 ? A_.lam : (which == 1 ? A_.pen : A_.cval);
+    const int R = pd_.total_rows;
+    if (R == 0) return ALTRO_OK;
+    std::vector<T> h((size_t)R * Bp_);
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), src, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B_; ++b)
+      for (int r = 0; r < R; ++r) out[(size_t)b * R + r] = (double)h[(size_t)r * Bp_ + b];
+    return ALTRO_OK;
+  }
+  altro_status SetDuals(const double* lam) override {
+    const int R = pd_.total_rows;
+    if (R == 0) return ALTRO_OK;
+    std::vector<T> h((size_t)R * Bp_, T(0));
+    for (int b = 0; b < B_; ++b)
+      for (int r = 0; r < R; ++r) h[(size_t)r * Bp_ + b] = T(lam[(size_t)b * R + r]);
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    ALTRO_HIP_CHECK(hipMemcpy(A_.lam, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ALTRO_OK;
+  }
+  altro_status GetStats(altro_stats* st, bool ilqr_mode) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    std::vector<T> f((size_t)kNumScalarT * Bp_);
+    std::vector<int> iv((size_t)kNumScalarI * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(f.data(), d_scalarT_, f.size() * sizeof(T), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(hipMemcpy(iv.data(), d_scalarI_, iv.size() * sizeof(int), hipMemcpyDeviceToHost));
+    auto F = [&](T* p, int b) { return (double)f[(size_t)(p - d_scalarT_) + b]; };
+    auto I = [&](int* p, int b) { return iv[(size_t)(p - d_scalarI_) + b]; };
+    for (int b = 0; b < B_; ++b) {
+      altro_stats& s = st[b];
+      s.status_ilqr = I(A_.status, b);
+      s.status = ilqr_mode ? s.status_ilqr : I(A_.status_al, b);
+      s.iterations_inner = I(A_.it_inner, b);
+      s.iterations_outer = I(A_.it_outer, b);
+      s.iterations_total = I(A_.it_total, b);
+      s.reserved = 0;
+      s.cost = F(A_.cost_cur, b);
+      s.initial_cost = F(A_.initial_cost, b);
+      s.cost_decrease = F(A_.dJ, b);
+      s.gradient = F(A_.grad, b);
+      s.violation = F(A_.viol, b);
+      s.max_penalty = F(A_.penmax, b);
+      s.alpha = F(A_.alpha, b);
+      s.regularization = F(A_.reg_log, b);
+      s.improvement_ratio = F(A_.z, b);
+    }
+    return ALTRO_OK;
+  }
+  altro_status GetTiming(altro_timing* t) override {
+    *t = timing_;
+    return ALTRO_OK;
+  }
+  altro_status SetRecordHistory(int capacity) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    if (A_.hist) {
+      hipFree(A_.hist);
+      hipFree(A_.hist_len);
+      A_.hist = nullptr;
+      A_.hist_len = nullptr;
+    }
+    A_.hist_cap = 0;
+    if (capacity > 0) {
+      ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist, (size_t)kHistFields * capacity * Bp_ * sizeof(T)));
+      ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist_len, (size_t)Bp_ * sizeof(int)));
+      ALTRO_HIP_CHECK(hipMemset(A_.hist_len, 0, (size_t)Bp_ * sizeof(int)));
+      A_.hist_cap = capacity;
+    }
+    return ALTRO_OK;
+  }
+  int GetHistory(int instance, int field, double* out, int cap) override {
+    if (!A_.hist || instance < 0 || instance >= B_ || field < 0 || field >= kHistFields) return -1;
+    if (hipSetDevice(desc_.device_id) != hipSuccess) return -1;
+    int len = 0;
+    if (hipMemcpy(&len, A_.hist_len + instance, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    // the reference's vectors also hold the row opened by the last NewIteration: a copy of the last
+    int stored = std::min(len, A_.hist_cap);
+    int cnt = 0;
+    T v = T(0);
+    for (int i = 0; i < stored && cnt < cap; ++i) {
+      if (hipMemcpy(&v, A_.hist + ((size_t)field * A_.hist_cap + i) * Bp_ + instance, sizeof(T),
+                    hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+      out[cnt++] = (double)v;
+    }
+    return cnt;
+  }
+  altro_status PackResultsDevice(void* dst) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_pack_results<T>, GridB(), dim3(kBlock), 0, stream_, A_, (double*)dst, last_mode_ilqr_ ? 1 : 0);
+    return Sync();
+  }
+
+ private:
+  // ---- helpers ----------------------------------------------------------------------------------
+  dim3 GridB() const { return dim3((B_ + kBlock - 1) / kBlock); }
+  dim3 GridBK() const { return dim3((B_ + kBlock - 1) / kBlock, N_ + 1); }
+  dim3 GridF() const {
+    constexpr int per = kBlock / kLineSearchLanes;
+    return dim3((B_ + per - 1) / per);
+  }
+  altro_status Sync() {
+    ALTRO_HIP_CHECK(hipGetLastError());
+    ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+    return ALTRO_OK;
+  }
+  template <class U>
+  altro_status Alloc(U** p, size_t count) {
+    ALTRO_HIP_CHECK(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(U)));
+    ALTRO_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(U)));
+    allocs_.push_back((void*)*p);
+    return ALTRO_OK;
+  }
+  void Release() {
+    if (hipSetDevice(desc_.device_id) != hipSuccess) return;
+    for (void* p : allocs_) hipFree(p);
+    allocs_.clear();
+    if (A_.hist) hipFree(A_.hist);
+    if (A_.hist_len) hipFree(A_.hist_len);
+    if (d_counter_) hipFree(d_counter_);
+    if (h_counter_) hipHostFree(h_counter_);
+    for (auto& e : ring_ev_)
+      if (e) hipEventDestroy(e);
+    for (auto& e : prof_ev_) hipEventDestroy(e);
+    if (stream_) hipStreamDestroy(stream_);
+  }
+  altro_status DownloadVec(const T* dev, double* out) {
+    std::vector<T> h(Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, (size_t)Bp_ * sizeof(T), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B_; ++b) out[b] = (double)h[b];
+    return ALTRO_OK;
+  }
+  // device [knots][E][Bp] -> host [B][knots][E]
+  altro_status DownloadKnots(const T* dev, int knots, int E, double* out) {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    std::vector<T> h((size_t)knots * E * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    const size_t KE = (size_t)knots * E;
+    for (size_t ke = 0; ke < KE; ++ke) {
+      const T* src = &h[ke * Bp_];
+      for (int b = 0; b < B_; ++b) out[(size_t)b * KE + ke] = (double)src[b];
+    }
+    return ALTRO_OK;
+  }
+  altro_status DownloadOneKnot(const T* dev, int k, int E, double* out) {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    std::vector<T> h((size_t)E * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev + (size_t)k * E * Bp_, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    for (int e = 0; e < E; ++e)
+      for (int b = 0; b < B_; ++b) out[(size_t)b * E + e] = (double)h[(size_t)e * Bp_ + b];
+    return ALTRO_OK;
+  }
+  // host [B][knots][E] (or shared [knots][E]) -> device [knots][E][Bp]
+  altro_status UploadKnots(T* dev, int knots, int E, const double* src, bool per_instance) {
+    const size_t KE = (size_t)knots * E;
+    std::vector<T> h(KE * Bp_, T(0));
+    if (src)
+      for (size_t ke = 0; ke < KE; ++ke)
+        for (int b = 0; b < B_; ++b) h[ke * Bp_ + b] = T(src[(per_instance ? (size_t)b * KE : 0) + ke]);
+    ALTRO_HIP_CHECK(hipMemcpy(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ALTRO_OK;
+  }
+
+  altro_status SetInitialStateImpl(const ProblemSpec& s) {
+    if (!uploaded_) return ALTRO_OK;
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    if (s.x0.empty()) return UploadKnots(A_.x0, 1, n, nullptr, false);
+    return UploadKnots(A_.x0, 1, n, s.x0.data(), s.x0_per_instance != 0);
+  }
+  altro_status SetTrajectoryImpl(const ProblemSpec& s) {
+    if (!uploaded_) return ALTRO_OK;
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    altro_status st = UploadKnots(A_.X, N_ + 1, n, s.has_X ? s.X.data() : nullptr, s.traj_per_instance != 0);
+    if (st != ALTRO_OK) return st;
+    st = UploadKnots(A_.U, N_, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
+    if (st != ALTRO_OK) return st;
+    ALTRO_HIP_CHECK(hipMemcpy(X_init_, A_.X, (size_t)(N_ + 1) * n * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    ALTRO_HIP_CHECK(hipMemcpy(U_init_, A_.U, (size_t)N_ * m * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    return ALTRO_OK;
+  }
+
+  // Build the device problem description from the recorded setter calls.
+  altro_status UploadImpl(const ProblemSpec& s) {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    if (uploaded_) {
+      err_ = "problem definition changed after the device state was created; create a new handle";
+      return ALTRO_NOT_READY;
+    }
+    B_ = desc_.batch;
+    N_ = desc_.N;
+    Bp_ = ((B_ + kBlock - 1) / kBlock) * kBlock;
+    std::memset(&pd_, 0, sizeof(pd_));
+    pd_.n = n;
+    pd_.m = m;
+    pd_.N = N_;
+    pd_.B = B_;
+    pd_.Bp = Bp_;
+
+    std::vector<T> pool;             // shared parameters
+    std::vector<std::vector<T>> ip;  // per-instance slots, each [B]
+    auto new_slot = [&]() {
+      ip.emplace_back(B_, T(0));
+      return (int)ip.size() - 1;
+    };
+
+    // --- costs: the last SetCostFunction on a knot wins (problem.hpp:113-127) ---------------------
+    std::vector<int> knot_cost(N_ + 1, -1);
+    for (size_t ci = 0; ci < s.costs.size(); ++ci)
+      for (int k = s.costs[ci].k_begin; k < s.costs[ci].k_end; ++k) knot_cost[k] = (int)ci;
+    for (int k = 0; k <= N_; ++k)
+      if (knot_cost[k] < 0) {
+        err_ = "cost function missing at knot " + std::to_string(k) + " (Problem::IsFullyDefined)";
+        return ALTRO_NOT_READY;
+      }
+    std::map<int, int> group_of_cost;
+    for (int k = 0; k <= N_; ++k) {
+      const int ci = knot_cost[k];
+      if (group_of_cost.count(ci)) continue;
+      if (pd_.ngroups >= kMaxCostGroups) {
+        err_ = "too many distinct cost functions";
+        return ALTRO_UNSUPPORTED;
+      }
+      const CostSpec& c = s.costs[ci];
+      CostGroupDesc g{};
+      // QuadraticCost::LQRCost (examples/quadratic_cost.hpp:29-39), evaluated in T like the oracle
+      g.Q_off = (int)pool.size();
+      for (int e = 0; e < n * n; ++e) pool.push_back(T(c.Q[e]));
+      g.R_off = (int)pool.size();
+      for (int e = 0; e < m * m; ++e) pool.push_back(T(c.R[e]));
+      const T* Q = &pool[g.Q_off];
+      const T* R = &pool[g.R_off];
+      const bool xpi = (c.per_instance & 1) != 0, upi = (c.per_instance & 2) != 0;
+      g.q_pi = xpi;
+      g.r_pi = upi;
+      g.c_pi = xpi || upi;
+      const int ninst_q = xpi ? B_ : 1, ninst_r = upi ? B_ : 1, ninst_c = g.c_pi ? B_ : 1;
+      std::vector<T> q((size_t)ninst_q * n), r((size_t)ninst_r * m), cc(ninst_c), xa((size_t)ninst_q), ub_((size_t)ninst_r);
+      std::vector<T> xQx(ninst_q), uRu(ninst_r);
+      for (int b = 0; b < ninst_q; ++b) {
+        T xr[n], Qx[n];
+        for (int i = 0; i < n; ++i) xr[i] = T(c.xref[(size_t)b * n + i]);
+        T acc = T(0);
+        for (int i = 0; i < n; ++i) {
+          T sacc = T(0);
+          for (int j = 0; j < n; ++j) sacc += Q[i + j * n] * xr[j];
+          Qx[i] = sacc;
+          q[(size_t)b * n + i] = -sacc;
+        }
+        for (int i = 0; i < n; ++i) acc += xr[i] * Qx[i];
+        xQx[b] = acc;
+      }
+      for (int b = 0; b < ninst_r; ++b) {
+        T ur[m], Ru[m];
+        for (int i = 0; i < m; ++i) ur[i] = T(c.uref[(size_t)b * m + i]);
+        T acc = T(0);
+        for (int i = 0; i < m; ++i) {
+          T sacc = T(0);
+          for (int j = 0; j < m; ++j) sacc += R[i + j * m] * ur[j];
+          Ru[i] = sacc;
+          r[(size_t)b * m + i] = -sacc;
+        }
+        for (int i = 0; i < m; ++i) acc += ur[i] * Ru[i];
+        uRu[b] = acc;
+      }
+      for (int b = 0; b < ninst_c; ++b) cc[b] = T(0.5) * xQx[xpi ? b : 0] + T(0.5) * uRu[upi ? b : 0];
+      auto put = [&](bool pi, const std::vector<T>& v, int E) {
+        if (!pi) {
+          int off = (int)pool.size();
+          for (int e = 0; e < E; ++e) pool.push_back(v[e]);
+          return off;
+        }
+        int first = -1;
+        for (int e = 0; e < E; ++e) {
+          int sl = new_slot();
+          if (e == 0) first = sl;
+          for (int b = 0; b < B_; ++b) ip[sl][b] = v[(size_t)b * E + e];
+        }
+        return first;
+      };
+      g.q_off = put(xpi, q, n);
+      g.r_off = put(upi, r, m);
+      g.c_off = put(g.c_pi, cc, 1);
+      group_of_cost[ci] = pd_.ngroups;
+      pd_.grp[pd_.ngroups++] = g;
+    }
+
+    // --- constraints: per knot, equalities first then inequalities, insertion order kept ----------
+    struct ConBuilt {
+      ConDesc d;
+    };
+    std::vector<ConBuilt> built(s.cons.size());
+    for (size_t i = 0; i < s.cons.size(); ++i) {
+      const ConSpec& c = s.cons[i];
+      ConDesc d{};
+      d.kind = c.kind;
+      d.per_instance = c.per_instance ? 1 : 0;
+      if (c.kind == ALTRO_CON_GOAL) {
+        if (c.nparams != n) {
+          err_ = "goal constraint needs n parameters";
+          return ALTRO_INVALID_ARG;
+        }
+        d.type = 0;
+        d.p = n;
+      } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
+        if (c.nparams != 2 * m || c.per_instance) {
+          err_ = "control bound needs 2m shared parameters";
+          return ALTRO_INVALID_ARG;
+        }
+        d.type = 1;
+        for (int j = 0; j < m; ++j) {  // GetFiniteIndices, basic_constraints.hpp:138-145
+          if (std::abs(c.params[j]) < std::numeric_limits<double>::max()) d.lo_mask |= 1u << j;
+          if (std::abs(c.params[m + j]) < std::numeric_limits<double>::max()) d.hi_mask |= 1u << j;
+        }
+        d.p = __builtin_popcount(d.lo_mask) + __builtin_popcount(d.hi_mask);
+      } else if (c.kind == ALTRO_CON_CIRCLE) {
+        if (c.nparams % 3 != 0 || c.nparams == 0 || n < 2) {
+          err_ = "circle constraint needs (cx, cy, r) triples";
+          return ALTRO_INVALID_ARG;
+        }
+        d.type = 1;
+        d.p = c.nparams / 3;
+      } else {
+        err_ = "unknown constraint kind";
+        return ALTRO_INVALID_ARG;
+      }
+      if (d.kind == ALTRO_CON_CONTROL_BOUND) {
+        d.param_off = (int)pool.size();
+        for (int j = 0; j < m; ++j)
+          if ((d.lo_mask >> j) & 1u) pool.push_back(T(c.params[j]));
+        for (int j = 0; j < m; ++j)
+          if ((d.hi_mask >> j) & 1u) pool.push_back(T(c.params[m + j]));
+      } else if (!d.per_instance) {
+        d.param_off = (int)pool.size();
+        for (int e = 0; e < c.nparams; ++e) pool.push_back(T(c.params[e]));
+      } else {
+        int first = -1;
+        for (int e = 0; e < c.nparams; ++e) {
+          int sl = new_slot();
+          if (e == 0) first = sl;
+          for (int b = 0; b < B_; ++b) ip[sl][b] = T(c.params[(size_t)b * c.nparams + e]);
+        }
+        d.param_off = first;
+      }
+      built[i].d = d;
+    }
+    std::vector<std::vector<int>> knot_cons(N_ + 1);
+    for (size_t i = 0; i < s.cons.size(); ++i)
+      for (int k = s.cons[i].k_begin; k < s.cons[i].k_end; ++k) knot_cons[k].push_back((int)i);
+    for (auto& v : knot_cons)
+      std::stable_partition(v.begin(), v.end(), [&](int i) { return built[i].d.type == 0; });
+
+    // --- knot classes --------------------------------------------------------------------------------
+    std::map<std::vector<int>, int> class_of;
+    knot_class_.assign(N_ + 1, 0);
+    knot_rowbase_.assign(N_ + 1, 0);
+    int rows = 0;
+    for (int k = 0; k <= N_; ++k) {
+      std::vector<int> key;
+      key.push_back(group_of_cost[knot_cost[k]]);
+      for (int i : knot_cons[k]) key.push_back(i);
+      auto it = class_of.find(key);
+      int cls;
+      if (it == class_of.end()) {
+        if (pd_.nclass >= kMaxClasses) {
+          err_ = "too many distinct knot-point classes";
+          return ALTRO_UNSUPPORTED;
+        }
+        if ((int)knot_cons[k].size() > kMaxConPerKnot) {
+          err_ = "too many constraints on one knot point";
+          return ALTRO_UNSUPPORTED;
+        }
+        cls = pd_.nclass++;
+        KnotClass& kc = pd_.cls[cls];
+        kc.cost_group = key[0];
+        kc.ncon = (int)knot_cons[k].size();
+        int ro = 0;
+        for (int c = 0; c < kc.ncon; ++c) {
+          kc.con[c] = built[knot_cons[k][c]].d;
+          kc.con[c].row_off = ro;
+          ro += kc.con[c].p;
+        }
+        kc.nrows = ro;
+        class_of[key] = cls;
+      } else {
+        cls = it->second;
+      }
+      knot_class_[k] = cls;
+      knot_rowbase_[k] = rows;
+      rows += pd_.cls[cls].nrows;
+    }
+    pd_.total_rows = rows;
+
+    // --- device allocations --------------------------------------------------------------------------
+    std::memset(&A_, 0, sizeof(A_));
+    A_.B = B_;
+    A_.Bp = Bp_;
+    A_.N = N_;
+    const size_t bp = Bp_;
+#define ALTRO_ALLOC(ptr, count)                     \
+  do {                                              \
+    altro_status st_ = Alloc(&(ptr), (count));      \
+    if (st_ != ALTRO_OK) return st_;                \
+  } while (0)
+    ALTRO_ALLOC(A_.x0, n * bp);
+    ALTRO_ALLOC(A_.X, (size_t)(N_ + 1) * n * bp);
+    ALTRO_ALLOC(A_.U, (size_t)N_ * m * bp);
+    ALTRO_ALLOC(A_.AB, (size_t)N_ * n * nm * bp);
+    ALTRO_ALLOC(A_.lxx, (size_t)(N_ + 1) * n * n * bp);
+    ALTRO_ALLOC(A_.lxu, (size_t)N_ * n * m * bp);
+    ALTRO_ALLOC(A_.luu, (size_t)N_ * m * m * bp);
+    ALTRO_ALLOC(A_.lx, (size_t)(N_ + 1) * n * bp);
+    ALTRO_ALLOC(A_.lu, (size_t)N_ * m * bp);
+    ALTRO_ALLOC(A_.costs, (size_t)(N_ + 1) * bp);
+    ALTRO_ALLOC(A_.K, (size_t)N_ * m * n * bp);
+    ALTRO_ALLOC(A_.d, (size_t)N_ * m * bp);
+    ALTRO_ALLOC(A_.P, (size_t)(N_ + 1) * n * n * bp);
+    ALTRO_ALLOC(A_.p, (size_t)(N_ + 1) * n * bp);
+    ALTRO_ALLOC(A_.lam, (size_t)rows * bp);
+    ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
+    ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
+    ALTRO_ALLOC(d_tmp_, bp);
+    ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * n * bp);
+    ALTRO_ALLOC(U_init_, (size_t)N_ * m * bp);
+    T* dpool = nullptr;
+    T* dipool = nullptr;
+    ALTRO_ALLOC(dpool, pool.size());
+    ALTRO_ALLOC(dipool, ip.size() * bp);
+    if (!pool.empty())
+      ALTRO_HIP_CHECK(hipMemcpy(dpool, pool.data(), pool.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!ip.empty()) {
+      std::vector<T> flat(ip.size() * bp, T(0));
+      for (size_t sl = 0; sl < ip.size(); ++sl)
+        for (int b = 0; b < B_; ++b) flat[sl * bp + b] = ip[sl][b];
+      ALTRO_HIP_CHECK(hipMemcpy(dipool, flat.data(), flat.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    A_.pool = dpool;
+    A_.ipool = dipool;
+    int *dkc = nullptr, *dkr = nullptr;
+    float* dh = nullptr;
+    ALTRO_ALLOC(dkc, N_ + 1);
+    ALTRO_ALLOC(dkr, N_ + 1);
+    ALTRO_ALLOC(dh, N_ + 1);
+    std::vector<float> hs(N_ + 1, s.hstep);
+    hs[N_] = 0.0f;  // trajectory.hpp:128
+    ALTRO_HIP_CHECK(hipMemcpy(dkc, knot_class_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(hipMemcpy(dkr, knot_rowbase_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(hipMemcpy(dh, hs.data(), (N_ + 1) * sizeof(float), hipMemcpyHostToDevice));
+    A_.knot_class = dkc;
+    A_.knot_rowbase = dkr;
+    A_.hstep = dh;
+    ALTRO_ALLOC(d_phi_, kMaxClasses * kMaxConPerKnot);
+    {
+      std::vector<double> v(kMaxClasses * kMaxConPerKnot, s.phi >= 1.0 ? s.phi : 10.0);  // constraint_values.hpp:30
+      ALTRO_HIP_CHECK(hipMemcpy(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    A_.phi = d_phi_;
+    ALTRO_ALLOC(d_pd_, 1);
+    ALTRO_HIP_CHECK(hipMemcpy(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
+    // per-instance scalar state, one slab each so GetStats is two copies
+    ALTRO_ALLOC(d_scalarT_, (size_t)kNumScalarT * bp);
+    ALTRO_ALLOC(d_scalarI_, (size_t)kNumScalarI * bp);
+    T** tp[kNumScalarT] = {&A_.rho_reg, &A_.drho,     &A_.dV0,  &A_.dV1,  &A_.J0,
+                           &A_.initial_cost, &A_.cost_cur, &A_.cost_prev, &A_.dJ, &A_.grad,
+                           &A_.viol,    &A_.penmax,   &A_.alpha, &A_.z,   &A_.reg_log};
+    for (int i = 0; i < kNumScalarT; ++i) *tp[i] = d_scalarT_ + (size_t)i * bp;
+    int** ipn[kNumScalarI] = {&A_.status, &A_.status_al, &A_.it_inner, &A_.it_outer,
+                              &A_.it_total, &A_.phase,   &A_.need_init_cost};
+    for (int i = 0; i < kNumScalarI; ++i) *ipn[i] = d_scalarI_ + (size_t)i * bp;
+    {
+      std::vector<int> ones(bp, ALTRO_UNSOLVED);
+      ALTRO_HIP_CHECK(hipMemcpy(A_.status, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(hipMemcpy(A_.status_al, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
+    }
+    uploaded_ = true;
+    // penalties start at one (constraint_values.hpp:44); an earlier SetPenalty overrides
+    hipLaunchKernelGGL(k_set_rows<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 0, 1,
+                       T(s.penalty >= 0 ? s.penalty : 1.0));
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    st = SetInitialStateImpl(s);
+    if (st != ALTRO_OK) return st;
+    return SetTrajectoryImpl(s);
+#undef ALTRO_ALLOC
+  }
+
+  // ---- the sweep loop -----------------------------------------------------------------------------
+  hipEvent_t ProfEvent(size_t i) {
+    while (prof_ev_.size() <= i) {
+      hipEvent_t e;
+      hipEventCreate(&e);
+      prof_ev_.push_back(e);
+    }
+    return prof_ev_[i];
+  }
+
+  altro_status Solve(const altro_options& o, int mode) {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    const auto t0 = std::chrono::steady_clock::now();
+    const DevOpts d = ToDevOpts(o);
+    const bool prof = o.profiler_enable != 0;
+    last_mode_ilqr_ = (mode == kFwdILQR);
+    std::memset(&timing_, 0, sizeof(timing_));
+    size_t nev = 0;
+    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+    if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+    hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, d, 1);
+    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, 1);
+    timing_.launches += (mode == kFwdAL) ? 3 : 2;
+    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+    ALTRO_HIP_CHECK(hipGetLastError());
+
+    // upper bound on sweeps: every sweep advances every active instance by one inner iteration
+    const int max_sweeps = std::max(1, std::min(o.max_iterations_total,
+                                                o.max_iterations_inner * std::max(1, (mode == kFwdAL) ? o.max_iterations_outer : 1))) + 2;
+    int sweeps = 0;
+    bool finished = false;
+    auto enqueue_sweep = [&](int i) -> altro_status {
+      const int slot = i % kRing;
+      ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_ + slot, 0, sizeof(int), stream_));
+      hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 0);
+      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+      hipLaunchKernelGGL((k_backward<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d, 0);
+      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+      hipLaunchKernelGGL((k_forward<T, M>), GridF(), dim3(kBlock), 0, stream_, A_, d_pd_, d, mode, 0,
+                         d_counter_ + slot);
+      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+      ALTRO_HIP_CHECK(hipMemcpyAsync(h_counter_ + slot, d_counter_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
+      ALTRO_HIP_CHECK(hipEventRecord(ring_ev_[slot], stream_));
+      timing_.launches += 3;
+      return ALTRO_OK;
+    };
+    altro_status st = enqueue_sweep(0);
+    if (st != ALTRO_OK) return st;
+    sweeps = 1;
+    while (!finished) {
+      // keep one sweep in flight beyond the one whose counter we are about to read
+      if (sweeps < max_sweeps) {
+        st = enqueue_sweep(sweeps);
+        if (st != ALTRO_OK) return st;
+        sweeps++;
+      }
+      const int check = sweeps - 2 >= 0 ? sweeps - 2 : 0;
+      ALTRO_HIP_CHECK(hipEventSynchronize(ring_ev_[check % kRing]));
+      if (h_counter_[check % kRing] == 0) finished = true;
+      if (!finished && sweeps >= max_sweeps) {
+        ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+        finished = true;
+      }
+    }
+    ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+    ALTRO_HIP_CHECK(hipGetLastError());
+    timing_.sweeps = sweeps;
+    if (prof) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, prof_ev_[0], prof_ev_[1]);
+      timing_.init_ms = ms;
+      for (int i = 0; i < sweeps; ++i) {
+        const size_t e0 = 1 + (size_t)i * 3;
+        hipEventElapsedTime(&ms, prof_ev_[e0], prof_ev_[e0 + 1]);
+        timing_.expansions_ms += ms;
+        hipEventElapsedTime(&ms, prof_ev_[e0 + 1], prof_ev_[e0 + 2]);
+        timing_.backward_pass_ms += ms;
+        hipEventElapsedTime(&ms, prof_ev_[e0 + 2], prof_ev_[e0 + 3]);
+        timing_.forward_pass_ms += ms;
+      }
+    }
+    {
+      std::vector<int> it(Bp_);
+      ALTRO_HIP_CHECK(hipMemcpy(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
+      long long tot = 0;
+      for (int b = 0; b < B_; ++b) tot += it[b];
+      timing_.instance_iterations = tot;
+    }
+    timing_.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return ALTRO_OK;
+  }
+
+  static constexpr int kNumScalarT = 15, kNumScalarI = 7;
+  altro_desc desc_;
+  int B_ = 0, Bp_ = 0, N_ = 0;
+  bool uploaded_ = false;
+  bool last_mode_ilqr_ = false;
+  ProblemDesc pd_{};
+  ProblemDesc* d_pd_ = nullptr;
+  DevArrays<T> A_{};
+  T* d_tmp_ = nullptr;
+  T *X_init_ = nullptr, *U_init_ = nullptr;
+  T* d_scalarT_ = nullptr;
+  int* d_scalarI_ = nullptr;
+  double* d_phi_ = nullptr;
+  std::vector<int> knot_class_, knot_rowbase_;
+  std::vector<void*> allocs_;
+  hipStream_t stream_ = nullptr;
+  int* h_counter_ = nullptr;
+  int* d_counter_ = nullptr;
+  hipEvent_t ring_ev_[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> prof_ev_;
+  altro_timing timing_{};
+  std::string err_;
+};
+
+template <class T, class M>
+EngineBase* MakeEngineImpl(const altro_desc& d, std::string* err) {
+  if (d.n != M::n || d.m != M::m) {
+    if (err) *err = "state/control dimensions do not match the model";
+    return nullptr;
+  }
+  auto* e = new Engine<T, M>(d);
+  if (e->Init() != ALTRO_OK) {
+    if (err) *err = e->LastError();
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+}  // namespace altro_hip

@@ -1,0 +1,5 @@
+// Instantiates the batched AL-iLQR engine for (float, Quadrotor12M) on gfx950.
+#include "altro_engine.hpp"
+namespace altro_hip {
+EngineBase* MakeEngineQuad12F32(const altro_desc& d, std::string* err) { return MakeEngineImpl<float, Quadrotor12M>(d, err); }
+}  // namespace altro_hip

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native batched AL-iLQR solver.
+
+Metric (BASELINE.json): trajectories solved / s (AL-iLQR to tolerance) + ms per iLQR iteration,
+unicycle, 101 knot points (reference N = 100 segments), batched.
+
+Workload at every N: BASELINE config 3 — batch 4096 per GPU of the kTurn90 unicycle problem
+(n=3, m=2, goal + control-bound constraints, full AL loop, default SolverOptions, fp64), seeded
+synthetic per-instance goals; instance 0 of rank 0 is the exact reference
+problem of examples/problems/unicycle.cpp.  A "step" is one complete batched solve: device-side
+reset of the initial guess, AL-iLQR to convergence for every instance, and (N > 1) an RCCL
+all_gather of the per-instance {cost, violation, iterations, status} records.  Inputs are resident
+in HBM before the timed region; weak scaling (4096 instances per GPU).
+
+`value` counts only instances that finished with status kSolved; the solved fraction is reported.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+        (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(n, m, N, p_stage, p_term, itemsize):
+    """SURVEY.md section 8(d) three-kernel model: bytes per (trajectory, iLQR iteration), split by
+    kernel.  Per stage knot (elements): expansions read n+m+2p, write S+1; backward read S, write
+    mn+m; forward read (n+m)+(mn+m)+2p, write (n+m)+1, with S = n(n+m)+n^2+nm+m^2+n+m."""
+    S = n * (n + m) + n * n + n * m + m * m + n + m
+    exp_stage = (n + m + 2 * p_stage) + (S + 1)
+    bwd_stage = S + (m * n + m)
+    fwd_stage = (n + m) + (m * n + m) + 2 * p_stage + (n + m) + 1
+    exp_term = (n + 2 * p_term) + (n * n + n + 1)
+    bwd_term = n * n + n
+    fwd_term = n + 2 * p_term + n + 1
+    per = {
+        "expansions": (N * exp_stage + exp_term) * itemsize,
+        "backward_pass": (N * bwd_stage + bwd_term) * itemsize,
+        "forward_pass": (N * fwd_stage + fwd_term) * itemsize,
+    }
+    per["total"] = sum(per.values())
+    return per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+
+    import torch
+    import torch.distributed as dist
+
+    A = graft.load_package()
+    P = importlib.import_module("altro_cpp_amd.problems")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    n, m, N = 3, 2, 100
+    make = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, device_id=local_rank)  # noqa: E731
+    # per-rank seed: every rank solves a different shard of the global synthetic batch
+    solver = P.batch_turn90(make, batch=B, N=N, dtype=A.F64, seed=P.SEED_BASE + 3 + 1000 * rank)
+    solver.set_options(profiler_enable=0)
+
+    packed = torch.empty((B, 4), dtype=torch.float64, device=f"cuda:{local_rank}")
+    gathered = torch.empty((world * B, 4), dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else packed
+
+    def step():
+        solver.reset_trajectory()
+        solver.solve()
+        solver.pack_results_device(packed.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, packed)  # RCCL over xGMI: 32 B per instance
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    res = gathered.cpu().numpy()
+    status = res[:, 3].astype(int)
+    iters = res[:, 2]
+    solved = int((status == 0).sum())
+    total_inst = world * B
+    value = solved * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: one more (untimed) solve with per-kernel HIP events ----
+        solver.set_options(profiler_enable=1)
+        solver.reset_trajectory()
+        solver.solve()
+        tm = solver.get_timing()
+        solver.set_options(profiler_enable=0)
+        ab = algorithmic_bytes(n, m, N, 4, 3, 8)
+        kern_ms = {"expansions": tm["expansions_ms"], "backward_pass": tm["backward_pass_ms"],
+                   "forward_pass": tm["forward_pass_ms"]}
+        dom = max(kern_ms, key=kern_ms.get)
+        units = tm["instance_iterations"]  # (trajectory, iteration) units processed by the launches
+        launches = tm["sweeps"]
+        avg_launch_ms = kern_ms[dom] / max(launches, 1)
+        achieved = ab[dom] * units / max(launches, 1) / (avg_launch_ms * 1e-3) / 1e9  # GB/s
+        sweep_ms = sum(kern_ms.values())
+        achieved_all = ab["total"] * units / (sweep_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_" + dom.replace("_pass", ""), "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "avg_launch_us": round(1e3 * avg_launch_ms, 2), "launches": launches,
+            "algorithmic_bytes_per_launch": round(ab[dom] * units / max(launches, 1)),
+            "all_kernels_achieved": round(achieved_all, 2),
+            "all_kernels_frac": round(achieved_all / HBM_PEAK_GBS, 5),
+            "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
+            "limiter": "serial dependency chain (N Riccati steps + N RK4 steps per iteration, "
+                       "max iterations over the batch), not HBM",
+        }
+        # ---- CPU baseline: the oracle (a port, see oracle/altro_oracle.cpp) on the host cores --------
+        cpu = None
+        if not args.no_cpu_baseline:
+            lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+            lib = ctypes.CDLL(lib_path)
+            cores = os.cpu_count() or 1
+            sample = min(B, max(64, 8 * cores))
+            omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
+            o = P.batch_turn90(omake, batch=sample, N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
+            lib.oracle_set_threads(o._h, ctypes.c_int(cores))
+            c0 = time.perf_counter()
+            o.solve()
+            cdt = time.perf_counter() - c0
+            ost = o.get_stats()
+            lib.oracle_set_threads(o._h, ctypes.c_int(1))
+            o1 = P.batch_turn90(omake, batch=min(sample, 32), N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
+            c1 = time.perf_counter()
+            o1.solve()
+            cdt1 = time.perf_counter() - c1
+            o1st = o1.get_stats()
+            cpu = {
+                "value": round(float((ost["status"] == 0).sum()) / cdt, 2), "unit": "trajectories/s",
+                "cores": cores, "kind": "port",
+                "sample": f"first {sample} instances of the same seeded workload, one solve each, "
+                          f"{cores} host threads (one instance per task)",
+                "single_thread_value": round(float((o1st["status"] == 0).sum()) / cdt1, 2),
+                "single_thread_ms_per_ilqr_iter": round(1e3 * cdt1 / float(o1st["iterations_total"].sum()), 4),
+            }
+        name, cus = solver.device_info()
+        out = {
+            "metric": "trajectories solved/sec (AL-iLQR to tol), unicycle 101 knots, batched",
+            "value": round(value, 1), "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: batch 4096/GPU unicycle kTurn90 (n=3, m=2, 101 knots), goal + "
+                            "control-bound constraints, full AL loop, default SolverOptions",
+                "batch_per_gpu": B, "global_batch": total_inst, "knot_points": N + 1,
+                "parallelism": f"instance-sharded x{world} (no data-path collective; RCCL all_gather of result records)",
+                "solved_fraction": round(solved / total_inst, 5),
+                "ms_per_ilqr_iter_sweep": round(ms_per_step / max(tm["sweeps"], 1), 4),
+                "us_per_instance_iter": round(1e3 * ms_per_step / max(float(iters.sum()) / world, 1.0), 4),
+                "mean_iterations": round(float(iters.mean()), 3), "max_iterations": int(iters.max()),
+                "sweeps": tm["sweeps"], "device": name, "cus": cus,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

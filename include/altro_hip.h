@@ -196,6 +196,11 @@ altro_status altro_set_initial_state(altro_handle h, const double* x0, int per_i
 altro_status altro_set_trajectory(altro_handle h, const double* X, const double* U,
                                   int per_instance);
 
+/* Re-install, device-side, the trajectory last given to altro_set_trajectory (what
+ * `*traj_ptr = prob_def.InitialTrajectory()` does between solves in perf/benchmark_unicycle.cpp:66)
+ * without a host round trip. */
+altro_status altro_reset_trajectory(altro_handle h);
+
 /* solver.GetOptions() (al_solver.hpp:44, ilqr.hpp:161). */
 altro_status altro_set_options(altro_handle h, const altro_options* opts);
 altro_status altro_get_options(altro_handle h, altro_options* opts);

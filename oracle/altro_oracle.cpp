@@ -1308,6 +1308,16 @@ altro_status oracle_set_trajectory(oracle_handle h, const double* X, const doubl
     }
   return ALTRO_OK;
 }
+altro_status oracle_reset_trajectory(oracle_handle h) {
+  const altro_desc& D = h->desc;
+  if (Build(h) != ALTRO_OK) return ALTRO_UNSUPPORTED;
+  for (int b = 0; b < D.batch; ++b) {
+    const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
+    const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
+    h->inst[b]->SetTrajectory(Xb, Ub);
+  }
+  return ALTRO_OK;
+}
 altro_status oracle_set_options(oracle_handle h, const altro_options* o) {
   h->opts = *o;
   for (auto& I : h->inst) I->opts = *o;

