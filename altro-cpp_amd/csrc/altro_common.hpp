@@ -15,6 +15,8 @@ constexpr int kMaxClasses = 8;     // distinct (cost, constraint list) combinati
 constexpr int kMaxCostGroups = 8;
 constexpr int kLineSearchLanes = 20;  // speculative line-search trials evaluated side by side
 constexpr int kHistFields = 8;
+constexpr int kMaxRuns = 16;  // maximal runs of consecutive knots sharing one class
+constexpr int kMaxSharedPool = 128;  // shared parameters that travel to the forward kernel as kernel arguments
 
 // ---- dtype-independent problem specification (what the altro::problem::Problem setters record) ---
 struct CostSpec {
@@ -64,10 +66,30 @@ struct CostGroupDesc {
   int Q_off, R_off;          // shared pool, column-major n x n and m x m
   int q_off, r_off, c_off;   // pool element (shared) or slot (per instance)
   int q_pi, r_pi, c_pi;      // per-instance flags
+  int q_diag, r_diag;        // Q / R are diagonal (every off-diagonal entry is exactly zero)
+};
+// A run of consecutive knot points [k_begin, k_end) with the same class: rows of knot k start at
+// rowbase + (k - k_begin) * nrows(cls).  Lets the serial kernels keep the class in scalar registers.
+// `fast` selects a compile-time-specialised constraint layout for the serial rollout loop.
+enum FastKind {
+  kFastGeneric = 0,  // anything: table-driven evaluation
+  kFastNone = 1,     // no constraint on these knots
+  kFastB = 2,        // [CONTROL_BOUND with every lower and upper bound finite]
+  kFastCB = 3,       // [CIRCLE, CONTROL_BOUND(full)]
+  kFastBC = 4,       // [CONTROL_BOUND(full), CIRCLE]
+  kFastC = 5         // [CIRCLE]
+};
+struct KnotRun {
+  int k_begin, k_end, cls, rowbase;
+  int fast, pad0, pad1, pad2;
 };
 struct ProblemDesc {
   int n, m, N, B, Bp;
   int nclass, ngroups, total_rows;
+  int nruns, nslots;  // nslots: per-instance parameter slots (ipool rows)
+  float hstep;        // uniform step (trajectory.hpp:122-130); the terminal knot's step is unused
+  int npool;          // elements in the shared parameter pool
+  KnotRun runs[kMaxRuns];
   KnotClass cls[kMaxClasses];
   CostGroupDesc grp[kMaxCostGroups];
 };

@@ -29,6 +29,8 @@ struct DevArrays {
   T *AB, *lxx, *lxu, *luu, *lx, *lu, *costs;
   // gains, cost-to-go (P, p recorded per knot only on request)
   T *K, *d, *P, *p;
+  // line-search candidates, instance-major [b][k][trial][x|u] (Zbar_ of every speculative trial)
+  T* trial;
   // constraint rows: duals, penalties, stored constraint values (c_)
   T *lam, *pen, *cval;
   // parameters
@@ -49,9 +51,43 @@ struct DevArrays {
 
 template <class T>
 ALTRO_DEV void sincos_(T x, T* s, T* c);
+// fp64 sin/cos for the model dynamics.  ocml's sincos carries a double-double argument reduction
+// (~250 instructions); the rollout evaluates 3 of them per knot on the serial critical path, so this
+// is a short Cody-Waite reduction (exact for |x| < 1e5 thanks to FMA) + the fdlibm minimax kernels
+// on [-pi/4, pi/4]: <= 1.5 ulp from the correctly rounded value, which is also what glibc (the CPU
+// oracle) delivers, so results agree to ~1e-16.  Larger arguments take the ocml path.
 template <>
 ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
-  sincos(x, s, c);
+  if (!(fabs(x) < 1.0e5)) {
+    sincos(x, s, c);
+    return;
+  }
+  const double kq = rint(x * 6.36619772367581382433e-01);  // x * 2/pi
+  // pi/2 split: hi has 53 bits, lo the next 53
+  double r = fma(-kq, 1.57079632679489655800e+00, x);
+  r = fma(-kq, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  // __kernel_sin
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  // __kernel_cos
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)kq & 3;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -s0 : s0;
+  *c = ((q + 1) & 2) ? -c0 : c0;
 }
 template <>
 ALTRO_DEV void sincos_<float>(float x, float* s, float* c) {
@@ -85,6 +121,25 @@ ALTRO_DEV T max_(T a, T b) {
 // -------------------------------------------------------------------------------------------------
 struct UnicycleM {  // examples/unicycle.cpp:12-33
   static constexpr int n = 3, m = 2;
+  static constexpr bool kHasFusedRk4 = true;
+  // RK4 step with the duplicated work of the generic formula removed.  theta' = omega is constant
+  // over the step, so the stage angles are theta, theta + (omega*0.5)*h (stages 2 AND 3: the two
+  // expressions are the same floating-point computation) and theta + omega*h: 3 sincos instead of
+  // 4.  Every other operation is performed exactly as rk4_step_generic does, in the same order.
+  template <class T>
+  static ALTRO_DEV void rk4_fused(const T* x, const T* u, T hh, T* xn) {
+    const T v = u[0], w = u[1];
+    T s1, c1, s2, c2, s4, c4;
+    sincos_(x[2], &s1, &c1);
+    const T k1x = v * c1, k1y = v * s1;
+    sincos_(x[2] + w * T(0.5) * hh, &s2, &c2);
+    const T k2x = v * c2, k2y = v * s2;  // k3 == k2: same stage angle
+    sincos_(x[2] + w * hh, &s4, &c4);
+    const T k4x = v * c4, k4y = v * s4;
+    xn[0] = x[0] + hh * (k1x + 2 * k2x + 2 * k2x + k4x) / 6;
+    xn[1] = x[1] + hh * (k1y + 2 * k2y + 2 * k2y + k4y) / 6;
+    xn[2] = x[2] + hh * (w + 2 * w + 2 * w + w) / 6;
+  }
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
     T s, c;
@@ -110,6 +165,7 @@ struct UnicycleM {  // examples/unicycle.cpp:12-33
 template <int DOF>
 struct TripleIntegratorM {  // examples/triple_integrator.cpp:9-33
   static constexpr int n = 3 * DOF, m = DOF;
+  static constexpr bool kHasFusedRk4 = false;
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
 #pragma unroll
@@ -136,6 +192,7 @@ struct TripleIntegratorM {  // examples/triple_integrator.cpp:9-33
 // x = (p, phi, v, w), u = (a, tau);  p' = v, phi' = w, v' = ((g+a) phi_y, -(g+a) phi_x, a), w' = tau.
 struct Quadrotor12M {
   static constexpr int n = 12, m = 4;
+  static constexpr bool kHasFusedRk4 = false;
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
     const T g = T(9.81);
@@ -173,8 +230,9 @@ struct Quadrotor12M {
 // -------------------------------------------------------------------------------------------------
 // RK4 (altro/problem/integration.hpp:123-169); h is a 32-bit float promoted to T (quirk Q1)
 // -------------------------------------------------------------------------------------------------
+// Generic RK4 step.  Models may provide `rk4_fused` (same arithmetic, shared sub-expressions).
 template <class T, class M>
-ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn) {
+ALTRO_DEV void rk4_step_generic(const T* x, const T* u, T hh, T* xn) {
   constexpr int n = M::n;
   T k1[n], k2[n], k3[n], k4[n], xt[n];
   M::f(x, u, k1);
@@ -189,6 +247,15 @@ ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn) {
   M::f(xt, u, k4);
 #pragma unroll
   for (int i = 0; i < n; ++i) xn[i] = x[i] + hh * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+}
+
+template <class T, class M>
+ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn) {
+  if constexpr (M::kHasFusedRk4) {
+    M::rk4_fused(x, u, hh, xn);
+  } else {
+    rk4_step_generic<T, M>(x, u, hh, xn);
+  }
 }
 
 template <class T, class M>
@@ -277,15 +344,42 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J) {
 // -------------------------------------------------------------------------------------------------
 // Per-knot problem access
 // -------------------------------------------------------------------------------------------------
+// Per-knot data access.  Two interchangeable contexts:
+//   CtxG  reads duals / penalties / parameters from the global SoA arrays (parallel kernels),
+//   CtxL  reads them from the copy the forward pass staged in LDS (serial rollout loop: no VMEM
+//         load may sit behind the candidate stores, and every pointer is an LDS pointer so that
+//         the compiler emits ds_read, never flat_load).
 template <class T>
-struct KnotCtx {
+struct CtxG {
   const DevArrays<T>& A;
-  const ProblemDesc* pd;
-  int b;
+  unsigned b;
+  ALTRO_DEV CtxG(const DevArrays<T>& A_, int b_) : A(A_), b((unsigned)b_) {}
   ALTRO_DEV T par(int per_instance, int off, int i) const {
-    return per_instance ? A.ipool[(size_t)(off + i) * A.Bp + b] : A.pool[off + i];
+    return per_instance ? A.ipool[(unsigned)(off + i) * (unsigned)A.Bp + b] : A.pool[off + i];
   }
-  ALTRO_DEV T& row(T* arr, int r) const { return arr[(size_t)r * A.Bp + b]; }
+  ALTRO_DEV T shared(int off) const { return A.pool[off]; }
+  ALTRO_DEV T lam(int r) const { return A.lam[(unsigned)r * (unsigned)A.Bp + b]; }
+  ALTRO_DEV T pen(int r) const { return A.pen[(unsigned)r * (unsigned)A.Bp + b]; }
+  ALTRO_DEV void store_c(int r, T c) const { A.cval[(unsigned)r * (unsigned)A.Bp + b] = c; }
+};
+template <class T>
+struct CtxL {
+  const DevArrays<T>& A;
+  unsigned b;
+  const T* sPool;  // shared parameters (LDS, one copy per wave)
+  const T* sIp;    // per-instance parameter slots (LDS)
+  const T* sLam;   // duals (LDS)
+  const T* sPen;   // penalties (LDS)
+  ALTRO_DEV CtxL(const DevArrays<T>& A_, int b_, const T* pool_, const T* ip_, const T* lam_, const T* pen_)
+      : A(A_), b((unsigned)b_), sPool(pool_), sIp(ip_), sLam(lam_), sPen(pen_) {}
+  ALTRO_DEV T par(int per_instance, int off, int i) const {
+    const T* base = per_instance ? sIp : sPool;  // both LDS
+    return base[off + i];
+  }
+  ALTRO_DEV T shared(int off) const { return sPool[off]; }
+  ALTRO_DEV T lam(int r) const { return sLam[r]; }
+  ALTRO_DEV T pen(int r) const { return sPen[r]; }
+  ALTRO_DEV void store_c(int r, T c) const { A.cval[(unsigned)r * (unsigned)A.Bp + b] = c; }
 };
 
 // Dual-cone projection and its (diagonal) Jacobian (altro/constraints/constraint.hpp:70-78 for
@@ -304,23 +398,32 @@ ALTRO_DEV T violation(int type, T c) {
   return type == 0 ? abs_(c) : abs_(c - min_(T(0), c));
 }
 
-// QuadraticCost::Evaluate (examples/quadratic_cost.cpp:8-11); H == 0 for LQRCost.
-template <class T, int n, int m>
-ALTRO_DEV T quad_cost(const KnotCtx<T>& C, const CostGroupDesc& g, const T* x, const T* u) {
+// QuadraticCost::Evaluate (examples/quadratic_cost.cpp:8-11); H == 0 for LQRCost.  When Q / R are
+// diagonal the exact-zero off-diagonal products are skipped (they contribute +0.0 to every sum).
+template <class T, int n, int m, class Ctx>
+ALTRO_DEV T quad_cost(const Ctx& C, const CostGroupDesc& g, const T* x, const T* u) {
   T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     T s = T(0);
+    if (g.q_diag) {
+      s = C.shared(g.Q_off + i + i * n) * x[i];
+    } else {
 #pragma unroll
-    for (int j = 0; j < n; ++j) s += C.A.pool[g.Q_off + i + j * n] * x[j];
+      for (int j = 0; j < n; ++j) s += C.shared(g.Q_off + i + j * n) * x[j];
+    }
     xQx += x[i] * s;
     qx += C.par(g.q_pi, g.q_off, i) * x[i];
   }
 #pragma unroll
   for (int i = 0; i < m; ++i) {
     T s = T(0);
+    if (g.r_diag) {
+      s = C.shared(g.R_off + i + i * m) * u[i];
+    } else {
 #pragma unroll
-    for (int j = 0; j < m; ++j) s += C.A.pool[g.R_off + i + j * m] * u[j];
+      for (int j = 0; j < m; ++j) s += C.shared(g.R_off + i + j * m) * u[j];
+    }
     uRu += u[i] * s;
     ru += C.par(g.r_pi, g.r_off, i) * u[i];
   }
@@ -331,27 +434,26 @@ ALTRO_DEV T quad_cost(const KnotCtx<T>& C, const CostGroupDesc& g, const T* x, c
 // (constraint_values.hpp:111-119, quirk Q2: scalar rho = penalty_(0)).
 // STORE: also store c_ (the side effect every Evaluate has in the reference, quirk Q6) and return
 // the knot's max violation through *viol.
-template <class T, int n, int m, bool STORE>
-ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* viol) {
-  const KnotClass& kc = C.pd->cls[C.A.knot_class[k]];
-  T J = quad_cost<T, n, m>(C, C.pd->grp[kc.cost_group], x, u);
-  const int rb = C.A.knot_rowbase[k];
+template <class T, int n, int m, bool STORE, class Ctx>
+ALTRO_DEV T knot_cost(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, int rb, const T* x, const T* u,
+                      T* viol) {
+  T J = quad_cost<T, n, m>(C, pd->grp[kc.cost_group], x, u);
   T vmax = T(0);
   for (int ci = 0; ci < kc.ncon; ++ci) {
     const ConDesc& cd = kc.con[ci];
     const int r0 = rb + cd.row_off;
-    const T rho = C.row(C.A.pen, r0);
+    const T rho = C.pen(r0);
     T a = T(0), bsum = T(0);
     if (cd.kind == ALTRO_CON_GOAL) {
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         T c = x[i] - C.par(cd.per_instance, cd.param_off, i);
-        T lam = C.row(C.A.lam, r0 + i);
+        T lam = C.lam(r0 + i);
         T lp = dual_proj(cd.type, lam - rho * c);
         a += lp * lp;
         bsum += lam * lam;
         if (STORE) {
-          C.row(C.A.cval, r0 + i) = c;
+          C.store_c(r0 + i, c);
           vmax = max_(vmax, violation(cd.type, c));
         }
       }
@@ -360,13 +462,13 @@ ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* vio
 #pragma unroll
       for (int j = 0; j < m; ++j)
         if ((cd.lo_mask >> j) & 1u) {
-          T c = C.A.pool[pi] - u[j];
-          T lam = C.row(C.A.lam, r);
+          T c = C.shared(pi) - u[j];
+          T lam = C.lam(r);
           T lp = dual_proj(1, lam - rho * c);
           a += lp * lp;
           bsum += lam * lam;
           if (STORE) {
-            C.row(C.A.cval, r) = c;
+            C.store_c(r, c);
             vmax = max_(vmax, violation(1, c));
           }
           ++r;
@@ -375,13 +477,13 @@ ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* vio
 #pragma unroll
       for (int j = 0; j < m; ++j)
         if ((cd.hi_mask >> j) & 1u) {
-          T c = u[j] - C.A.pool[pi];
-          T lam = C.row(C.A.lam, r);
+          T c = u[j] - C.shared(pi);
+          T lam = C.lam(r);
           T lp = dual_proj(1, lam - rho * c);
           a += lp * lp;
           bsum += lam * lam;
           if (STORE) {
-            C.row(C.A.cval, r) = c;
+            C.store_c(r, c);
             vmax = max_(vmax, violation(1, c));
           }
           ++r;
@@ -393,12 +495,12 @@ ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* vio
         T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
         T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
         T c = -(dx * dx + dy * dy - rr * rr);
-        T lam = C.row(C.A.lam, r0 + i);
+        T lam = C.lam(r0 + i);
         T lp = dual_proj(1, lam - rho * c);
         a += lp * lp;
         bsum += lam * lam;
         if (STORE) {
-          C.row(C.A.cval, r0 + i) = c;
+          C.store_c(r0 + i, c);
           vmax = max_(vmax, violation(1, c));
         }
       }
@@ -410,21 +512,144 @@ ALTRO_DEV T knot_cost(const KnotCtx<T>& C, int k, const T* x, const T* u, T* vio
   return J;
 }
 
+// Constants of one run of knots, hoisted into VGPRs before the serial rollout loop: diagonal cost
+// weights, linear terms, and the finite bounds of the run's first CONTROL_BOUND constraint.
+template <class T, int n, int m>
+struct RunConsts {
+  bool diag;
+  T Qd[n], Rd[m], q[n], r[m], c;
+  int bnd_ci;  // index of the hoisted bound constraint, -1 if none
+  T bnd[2 * m];
+};
+template <class T, int n, int m, class Ctx>
+ALTRO_DEV void load_run_consts(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, RunConsts<T, n, m>& R) {
+  const CostGroupDesc& g = pd->grp[kc.cost_group];
+  R.diag = g.q_diag && g.r_diag;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    R.Qd[i] = C.shared(g.Q_off + i + i * n);
+    R.q[i] = C.par(g.q_pi, g.q_off, i);
+  }
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    R.Rd[i] = C.shared(g.R_off + i + i * m);
+    R.r[i] = C.par(g.r_pi, g.r_off, i);
+  }
+  R.c = C.par(g.c_pi, g.c_off, 0);
+  R.bnd_ci = -1;
+#pragma unroll
+  for (int j = 0; j < 2 * m; ++j) R.bnd[j] = T(0);
+#pragma unroll
+  for (int ci = 0; ci < kMaxConPerKnot; ++ci) {
+    if (ci < kc.ncon && R.bnd_ci < 0 && kc.con[ci].kind == ALTRO_CON_CONTROL_BOUND) {
+      R.bnd_ci = ci;
+      const ConDesc& cd = kc.con[ci];
+      int pi = cd.param_off;
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.lo_mask >> j) & 1u) R.bnd[j] = C.shared(pi++);
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+        if ((cd.hi_mask >> j) & 1u) R.bnd[m + j] = C.shared(pi++);
+    }
+  }
+}
+// Same value as knot_cost<.., STORE=false> (identical operation order), with the run constants in
+// registers and the constraint list unrolled so that class metadata stays in scalar registers.
+template <class T, int n, int m, class Ctx>
+ALTRO_DEV T knot_cost_fast(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, const RunConsts<T, n, m>& R,
+                           int rb, const T* x, const T* u) {
+  T J;
+  if (R.diag) {
+    T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      xQx += x[i] * (R.Qd[i] * x[i]);
+      qx += R.q[i] * x[i];
+    }
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      uRu += u[i] * (R.Rd[i] * u[i]);
+      ru += R.r[i] * u[i];
+    }
+    J = T(0.5) * xQx + T(0.5) * uRu + qx + ru + R.c;
+  } else {
+    J = quad_cost<T, n, m>(C, pd->grp[kc.cost_group], x, u);
+  }
+#pragma unroll
+  for (int ci = 0; ci < kMaxConPerKnot; ++ci) {
+    if (ci < kc.ncon) {
+      const ConDesc& cd = kc.con[ci];
+      const int r0 = rb + cd.row_off;
+      const T rho = C.pen(r0);
+      T a = T(0), bsum = T(0);
+      if (cd.kind == ALTRO_CON_GOAL) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          T c = x[i] - C.par(cd.per_instance, cd.param_off, i);
+          T lam = C.lam(r0 + i);
+          T lp = dual_proj(cd.type, lam - rho * c);
+          a += lp * lp;
+          bsum += lam * lam;
+        }
+      } else if (cd.kind == ALTRO_CON_CONTROL_BOUND) {
+        const bool hoisted = (ci == R.bnd_ci);
+        int r = r0, pi = cd.param_off;
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+          if ((cd.lo_mask >> j) & 1u) {
+            T c = (hoisted ? R.bnd[j] : C.shared(pi)) - u[j];
+            T lam = C.lam(r);
+            T lp = dual_proj(1, lam - rho * c);
+            a += lp * lp;
+            bsum += lam * lam;
+            ++r;
+            ++pi;
+          }
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+          if ((cd.hi_mask >> j) & 1u) {
+            T c = u[j] - (hoisted ? R.bnd[m + j] : C.shared(pi));
+            T lam = C.lam(r);
+            T lp = dual_proj(1, lam - rho * c);
+            a += lp * lp;
+            bsum += lam * lam;
+            ++r;
+            ++pi;
+          }
+      } else {
+        for (int i = 0; i < cd.p; ++i) {
+          T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
+          T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
+          T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
+          T c = -(dx * dx + dy * dy - rr * rr);
+          T lam = C.lam(r0 + i);
+          T lp = dual_proj(1, lam - rho * c);
+          a += lp * lp;
+          bsum += lam * lam;
+        }
+      }
+      T Jc = a - bsum;
+      J += Jc / (2 * rho);
+    }
+  }
+  return J;
+}
+
 // Cost expansion of one knot: QuadraticCost::Gradient/Hessian + ConstraintValues::AugLagGradient /
 // AugLagHessian for every constraint (al_cost.hpp:276-308, quadratic_cost.cpp:13-28,
 // constraint_values.hpp:131-177).  Also returns the AL cost (ilqr.hpp:675) and stores c_.
-template <class T, int n, int m>
-ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T* u, T* gx, T* gu,
-                                T* hxx, T* hxu, T* huu) {
-  const KnotClass& kc = C.pd->cls[C.A.knot_class[k]];
-  const CostGroupDesc& g = C.pd->grp[kc.cost_group];
+template <class T, int n, int m, class Ctx>
+ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, int rb, const T* x,
+                                const T* u, T* gx, T* gu, T* hxx, T* hxu, T* huu) {
+  const CostGroupDesc& g = pd->grp[kc.cost_group];
   T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     T s = T(0);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-      T q = C.A.pool[g.Q_off + i + j * n];
+      T q = C.shared(g.Q_off + i + j * n);
       hxx[i + j * n] = q;
       s += q * x[j];
     }
@@ -438,7 +663,7 @@ ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T*
     T s = T(0);
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-      T r = C.A.pool[g.R_off + i + j * m];
+      T r = C.shared(g.R_off + i + j * m);
       huu[i + j * m] = r;
       s += r * u[j];
     }
@@ -451,24 +676,23 @@ ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T*
   for (int e = 0; e < n * m; ++e) hxu[e] = T(0);
   T J = T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
 
-  const int rb = C.A.knot_rowbase[k];
   for (int ci = 0; ci < kc.ncon; ++ci) {
     const ConDesc& cd = kc.con[ci];
     const int r0 = rb + cd.row_off;
-    const T rho = C.row(C.A.pen, r0);
+    const T rho = C.pen(r0);
     T a = T(0), bsum = T(0);
     if (cd.kind == ALTRO_CON_GOAL) {
       // C_x = I, C_u = 0: gradient -(P C)^T lambda_bar, Gauss-Newton Hessian rho (PC)^T(PC)
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         T c = x[i] - C.par(cd.per_instance, cd.param_off, i);
-        T lam = C.row(C.A.lam, r0 + i);
+        T lam = C.lam(r0 + i);
         T v = lam - rho * c;
         T lp = dual_proj(cd.type, v);
         T pj = dual_proj_jac(cd.type, v);
         a += lp * lp;
         bsum += lam * lam;
-        C.row(C.A.cval, r0 + i) = c;
+        C.store_c(r0 + i, c);
         gx[i] += -(pj * lp);
         hxx[i + i * n] += (rho * pj) * pj;
       }
@@ -481,14 +705,14 @@ ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T*
 #pragma unroll
       for (int j = 0; j < m; ++j)
         if ((cd.lo_mask >> j) & 1u) {
-          T c = C.A.pool[pi] - u[j];
-          T lam = C.row(C.A.lam, r);
+          T c = C.shared(pi) - u[j];
+          T lam = C.lam(r);
           T v = lam - rho * c;
           T lp = dual_proj(1, v);
           T jp = dual_proj_jac(1, v) * T(-1);
           a += lp * lp;
           bsum += lam * lam;
-          C.row(C.A.cval, r) = c;
+          C.store_c(r, c);
           sg[j] += jp * lp;
           sh[j] += (rho * jp) * jp;
           ++r;
@@ -497,14 +721,14 @@ ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T*
 #pragma unroll
       for (int j = 0; j < m; ++j)
         if ((cd.hi_mask >> j) & 1u) {
-          T c = u[j] - C.A.pool[pi];
-          T lam = C.row(C.A.lam, r);
+          T c = u[j] - C.shared(pi);
+          T lam = C.lam(r);
           T v = lam - rho * c;
           T lp = dual_proj(1, v);
           T jp = dual_proj_jac(1, v);
           a += lp * lp;
           bsum += lam * lam;
-          C.row(C.A.cval, r) = c;
+          C.store_c(r, c);
           sg[j] += jp * lp;
           sh[j] += (rho * jp) * jp;
           ++r;
@@ -523,13 +747,13 @@ ALTRO_DEV T knot_cost_expansion(const KnotCtx<T>& C, int k, const T* x, const T*
         T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
         T dx = x[0] - cx, dy = x[1] - cy;
         T c = -(dx * dx + dy * dy - rr * rr);
-        T lam = C.row(C.A.lam, r0 + i);
+        T lam = C.lam(r0 + i);
         T v = lam - rho * c;
         T lp = dual_proj(1, v);
         T pj = dual_proj_jac(1, v);
         a += lp * lp;
         bsum += lam * lam;
-        C.row(C.A.cval, r0 + i) = c;
+        C.store_c(r0 + i, c);
         T j0 = pj * (2 * (cx - x[0]));
         T j1 = pj * (2 * (cy - x[1]));
         g0 += j0 * lp;
@@ -626,7 +850,7 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
     Qu[i] = lu[i] + s;
   }
   // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure
-  T L[m * m];
+  T L[m * m], Linv[m];
 #pragma unroll
   for (int e = 0; e < m * m; ++e) L[e] = Quu[e];
 #pragma unroll
@@ -640,12 +864,15 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
     if (xjj <= T(0)) ok = false;
     T ljj = sqrt_(xjj);
     L[j + j * m] = ljj;
+    // one reciprocal per pivot; the triangular solves below multiply by it instead of dividing
+    // (an fp64 division costs ~35 instructions on gfx950 and there would be (n+1)*2m of them)
+    Linv[j] = T(1) / ljj;
 #pragma unroll
     for (int i = j + 1; i < m; ++i) {
       T s = L[i + j * m];
 #pragma unroll
       for (int l = 0; l < j; ++l) s -= L[i + l * m] * L[j + l * m];
-      L[i + j * m] = s / ljj;
+      L[i + j * m] = s * Linv[j];
     }
   }
   if (!ok) return false;
@@ -660,14 +887,14 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
       T s = col[i];
 #pragma unroll
       for (int l = 0; l < i; ++l) s -= L[i + l * m] * col[l];
-      col[i] = s / L[i + i * m];
+      col[i] = s * Linv[i];
     }
 #pragma unroll
     for (int i = m - 1; i >= 0; --i) {
       T s = col[i];
 #pragma unroll
       for (int l = i + 1; l < m; ++l) s -= L[l + i * m] * col[l];
-      col[i] = s / L[i + i * m];
+      col[i] = s * Linv[i];
     }
 #pragma unroll
     for (int i = 0; i < m; ++i) {

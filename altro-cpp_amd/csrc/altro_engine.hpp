@@ -157,8 +157,7 @@ class Engine final : public EngineBase {
   }
   altro_status ForwardPass(const altro_options& o) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL((k_forward<T, M>), GridF(), dim3(kBlock), 0, stream_, A_, d_pd_, ToDevOpts(o),
-                       (int)kFwdStepOnly, 1, (int*)nullptr);
+    LaunchForward(ToDevOpts(o), (int)kFwdStepOnly, 1, nullptr);
     return Sync();
   }
   altro_status UpdateConvergenceStatistics(const altro_options& o) override {
@@ -339,9 +338,17 @@ class Engine final : public EngineBase {
   // ---- helpers ----------------------------------------------------------------------------------
   dim3 GridB() const { return dim3((B_ + kBlock - 1) / kBlock); }
   dim3 GridBK() const { return dim3((B_ + kBlock - 1) / kBlock, N_ + 1); }
-  dim3 GridF() const {
-    constexpr int per = kBlock / kLineSearchLanes;
-    return dim3((B_ + per - 1) / per);
+  // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
+  // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
+  void LaunchForward(const DevOpts& d, int mode, int all, int* counter) {
+    const dim3 grid((B_ + fwd_per_wave_ - 1) / fwd_per_wave_);
+    if (fwd_lds_bytes_ > 0) {
+      hipLaunchKernelGGL((k_forward<T, M, true>), grid, dim3(kBlock), fwd_lds_bytes_, stream_, A_, d_pd_, pd_, d,
+                         mode, all, fwd_per_wave_, counter);
+    } else {
+      hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A_, d_pd_, pd_, d, mode, all,
+                         fwd_per_wave_, counter);
+    }
   }
   altro_status Sync() {
     ALTRO_HIP_CHECK(hipGetLastError());
@@ -473,6 +480,13 @@ class Engine final : public EngineBase {
       for (int e = 0; e < m * m; ++e) pool.push_back(T(c.R[e]));
       const T* Q = &pool[g.Q_off];
       const T* R = &pool[g.R_off];
+      g.q_diag = g.r_diag = 1;
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i)
+          if (i != j && Q[i + j * n] != T(0)) g.q_diag = 0;
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i)
+          if (i != j && R[i + j * m] != T(0)) g.r_diag = 0;
       const bool xpi = (c.per_instance & 1) != 0, upi = (c.per_instance & 2) != 0;
       g.q_pi = xpi;
       g.r_pi = upi;
@@ -633,6 +647,52 @@ class Engine final : public EngineBase {
       rows += pd_.cls[cls].nrows;
     }
     pd_.total_rows = rows;
+    pd_.nslots = (int)ip.size();
+    pd_.npool = (int)pool.size();
+    pd_.hstep = s.hstep;
+    // runs of consecutive knots sharing a class (scalar-register friendly serial loops)
+    pd_.nruns = 0;
+    for (int k = 0; k <= N_; ++k) {
+      if (pd_.nruns > 0 && pd_.runs[pd_.nruns - 1].cls == knot_class_[k]) {
+        pd_.runs[pd_.nruns - 1].k_end = k + 1;
+        continue;
+      }
+      if (pd_.nruns >= kMaxRuns) {
+        err_ = "too many runs of distinct knot-point classes";
+        return ALTRO_UNSUPPORTED;
+      }
+      KnotRun run{};
+      run.k_begin = k;
+      run.k_end = k + 1;
+      run.cls = knot_class_[k];
+      run.rowbase = knot_rowbase_[k];
+      {
+        const KnotClass& kc = pd_.cls[run.cls];
+        const unsigned full = (1u << m) - 1u;
+        auto is_full_bound = [&](const ConDesc& c) {
+          return c.kind == ALTRO_CON_CONTROL_BOUND && c.lo_mask == full && c.hi_mask == full;
+        };
+        auto is_circle = [&](const ConDesc& c) { return c.kind == ALTRO_CON_CIRCLE; };
+        run.fast = kFastGeneric;
+        if (pd_.grp[kc.cost_group].q_diag && pd_.grp[kc.cost_group].r_diag) {
+          if (kc.ncon == 0) run.fast = kFastNone;
+          else if (kc.ncon == 1 && is_full_bound(kc.con[0])) run.fast = kFastB;
+          else if (kc.ncon == 1 && is_circle(kc.con[0])) run.fast = kFastC;
+          else if (kc.ncon == 2 && is_circle(kc.con[0]) && is_full_bound(kc.con[1])) run.fast = kFastCB;
+          else if (kc.ncon == 2 && is_full_bound(kc.con[0]) && is_circle(kc.con[1])) run.fast = kFastBC;
+        }
+      }
+      pd_.runs[pd_.nruns++] = run;
+    }
+    {
+      const double lim = 2147483647.0;
+      const double biggest = std::max({(double)N_ * n * nm * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
+                                       (double)std::max(rows, 1) * Bp_});
+      if (biggest > lim) {
+        err_ = "problem too large for 32-bit device indexing (split the batch over several handles)";
+        return ALTRO_UNSUPPORTED;
+      }
+    }
 
     // --- device allocations --------------------------------------------------------------------------
     std::memset(&A_, 0, sizeof(A_));
@@ -659,6 +719,8 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.d, (size_t)N_ * m * bp);
     ALTRO_ALLOC(A_.P, (size_t)(N_ + 1) * n * n * bp);
     ALTRO_ALLOC(A_.p, (size_t)(N_ + 1) * n * bp);
+    ALTRO_HIP_CHECK(hipMalloc((void**)&A_.trial, (size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T)));
+    allocs_.push_back((void*)A_.trial);
     ALTRO_ALLOC(A_.lam, (size_t)rows * bp);
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
@@ -715,6 +777,25 @@ class Engine final : public EngineBase {
       ALTRO_HIP_CHECK(hipMemcpy(A_.status, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
       ALTRO_HIP_CHECK(hipMemcpy(A_.status_al, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
     }
+    {
+      // LDS plan of the forward pass: up to 3 instances per wavefront, at most 80 KiB per workgroup
+      // (two workgroups per CU); if even one instance does not fit in 160 KiB, read from HBM instead.
+      const size_t per_inst = ((size_t)(N_ + 1) * n + (size_t)N_ * m + (size_t)N_ * m * n + (size_t)N_ * m +
+                               2 * (size_t)rows + ip.size()) * sizeof(T);
+      const int lanes_max = kBlock / kLineSearchLanes;
+      fwd_per_wave_ = lanes_max;
+      while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
+      const size_t pool_bytes = pool.size() * sizeof(T);
+      while (fwd_per_wave_ > 1 && pool_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
+      fwd_lds_bytes_ = pool_bytes + fwd_per_wave_ * per_inst;
+      if (fwd_lds_bytes_ > 160 * 1024) {
+        fwd_lds_bytes_ = 0;
+        fwd_per_wave_ = lanes_max;
+      } else if (fwd_lds_bytes_ > 64 * 1024) {
+        ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward<T, M, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+      }
+    }
     uploaded_ = true;
     // penalties start at one (constraint_values.hpp:44); an earlier SetPenalty overrides
     hipLaunchKernelGGL(k_set_rows<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 0, 1,
@@ -765,8 +846,7 @@ class Engine final : public EngineBase {
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
       hipLaunchKernelGGL((k_backward<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d, 0);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-      hipLaunchKernelGGL((k_forward<T, M>), GridF(), dim3(kBlock), 0, stream_, A_, d_pd_, d, mode, 0,
-                         d_counter_ + slot);
+      LaunchForward(d, mode, 0, d_counter_ + slot);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
       ALTRO_HIP_CHECK(hipMemcpyAsync(h_counter_ + slot, d_counter_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
       ALTRO_HIP_CHECK(hipEventRecord(ring_ev_[slot], stream_));
@@ -828,6 +908,8 @@ class Engine final : public EngineBase {
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};
   T* d_tmp_ = nullptr;
+  int fwd_per_wave_ = kBlock / kLineSearchLanes;
+  size_t fwd_lds_bytes_ = 0;
   T *X_init_ = nullptr, *U_init_ = nullptr;
   T* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;

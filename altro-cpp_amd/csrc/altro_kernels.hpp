@@ -21,11 +21,23 @@
 // Instances are independent; a finished instance (phase == 0) simply masks its lanes.
 #pragma once
 
+#include <type_traits>
+
 #include "altro_device.hpp"
 
 namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
+
+// Batch-minor SoA element: arr[(row)*Bp + b] with 32-bit index arithmetic (every array of the
+// BASELINE configurations has < 2^31 elements; Upload() rejects larger problems).
+#define SOA(arr, row) (arr)[(unsigned)(row) * (unsigned)Bp + (unsigned)b]
+
+template <class T>
+ALTRO_DEV const KnotClass& class_of_knot(const DevArrays<T>& A, const ProblemDesc* pd, int k, int* rowbase) {
+  *rowbase = A.knot_rowbase[k];
+  return pd->cls[A.knot_class[k]];
+}
 
 enum ForwardMode { kFwdStepOnly = 0, kFwdILQR = 1, kFwdAL = 2 };
 
@@ -62,9 +74,11 @@ __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const Pro
   for (int i = 0; i < n; ++i) x[i] = A.X[((size_t)k * n + i) * Bp + b];
 #pragma unroll
   for (int i = 0; i < m; ++i) u[i] = (k < N) ? A.U[((size_t)k * m + i) * Bp + b] : T(0);
-  KnotCtx<T> C{A, pd, b};
+  CtxG<T> C(A, b);
   T gx[n], gu[m], hxx[n * n], hxu[n * m], huu[m * m];
-  T J = knot_cost_expansion<T, n, m>(C, k, x, u, gx, gu, hxx, hxu, huu);
+  int rb;
+  const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+  T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, x, u, gx, gu, hxx, hxu, huu);
   A.costs[(size_t)k * Bp + b] = J;
 #pragma unroll
   for (int e = 0; e < n * n; ++e) A.lxx[((size_t)k * n * n + e) * Bp + b] = hxx[e];
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const Pro
 #pragma unroll
     for (int e = 0; e < m; ++e) A.lu[((size_t)k * m + e) * Bp + b] = gu[e];
     T Jc[n * nm];
-    rk4_jacobian<T, M>(x, u, T(A.hstep[k]), Jc);
+    rk4_jacobian<T, M>(x, u, T(pd->hstep), Jc);
 #pragma unroll
     for (int e = 0; e < n * nm; ++e) A.AB[((size_t)k * n * nm + e) * Bp + b] = Jc[e];
   }
@@ -239,9 +253,11 @@ __global__ __launch_bounds__(kBlock) void k_knot_costs(DevArrays<T> A, const Pro
   for (int i = 0; i < n; ++i) x[i] = A.X[((size_t)k * n + i) * Bp + b];
 #pragma unroll
   for (int i = 0; i < m; ++i) u[i] = (k < A.N) ? A.U[((size_t)k * m + i) * Bp + b] : T(0);
-  KnotCtx<T> C{A, pd, b};
+  CtxG<T> C(A, b);
   T v;
-  A.costs[(size_t)k * Bp + b] = knot_cost<T, n, m, true>(C, k, x, u, &v);
+  int rb;
+  const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+  A.costs[(size_t)k * Bp + b] = knot_cost<T, n, m, true>(C, pd, kc, rb, x, u, &v);
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_sum_costs(DevArrays<T> A, T* out) {
@@ -427,12 +443,12 @@ ALTRO_DEV bool conv_stats_and_done(const DevArrays<T>& A, const DevOpts& o, int 
   return done;
 }
 
-// AL outer-loop step after an inner solve finished: UpdateDuals, UpdateConvergenceStatistics,
-// IsDone, UpdatePenalties (al_solver.hpp:313-401).  Returns true if the instance keeps iterating.
+// AL outer-loop decision after an inner solve finished and the duals were updated:
+// UpdateConvergenceStatistics + IsDone (al_solver.hpp:357-401).  viol / pen are the max violation
+// of the stored c_ and the max penalty.  Returns true if the instance keeps iterating (the caller
+// then applies UpdatePenalties and starts the next inner solve).
 template <class T>
-ALTRO_DEV bool al_outer_step(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int b) {
-  T viol, pen;
-  rows_update_duals(A, pd, b, &viol, &pen);
+ALTRO_DEV bool al_outer_decide(const DevArrays<T>& A, const DevOpts& o, int b, T viol, T pen) {
   const int outer = A.it_outer[b] + 1;
   A.it_outer[b] = outer;
   A.viol[b] = viol;
@@ -453,8 +469,6 @@ ALTRO_DEV bool al_outer_step(const DevArrays<T>& A, const ProblemDesc* pd, const
     A.status_al[b] = sal;
     return false;
   }
-  rows_update_penalties(A, pd, b);
-  begin_inner_solve(A, o, b);
   return true;
 }
 
@@ -483,34 +497,273 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
 
 // -------------------------------------------------------------------------------------------------
 // iLQR::ForwardPass (ilqr.hpp:512-558) with speculative parallel line search, + state machine
+//
+// Lane layout: lane = grp*20 + t, grp = instance slot in the wave (up to 3 per wave), t = trial.
+// Phase 0 (LDS variant): the 20 lanes of an instance stage everything the serial rollout reads --
+//   X, U (Z_), K, d (gains), lambda, rho -- from HBM into LDS once, so the N dependent rollout
+//   steps contain no global load at all (the only VMEM traffic in the loop is the candidate stores,
+//   which nothing waits on).  Reads are wave-broadcasts: all 20 trials read the same LDS address.
+// Phase 1 (all lanes): closed-loop rollout + cost with alpha_t; every trial stores its candidate
+//   trajectory (Zbar_) to the `trial` scratch so the winner never has to be re-integrated.
+// Phase 2 (all lanes of the instance, knots strided over the 20 lanes): copy the winning candidate
+//   into Z_ and evaluate the constraint values it leaves behind (c_, quirk Q6).
+// Phase 3 (one lane per instance): statistics, IsDone, AL outer-loop transition.
 // -------------------------------------------------------------------------------------------------
-template <class T, class M>
-__global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
-                                                    DevOpts o, int mode, int all, int* active_counter) {
-  constexpr int n = M::n, m = M::m;
+// One run of knots of the closed-loop rollout + cost of ONE line-search trial (one lane):
+// iLQR::RolloutClosedLoop + ALCost::Evaluate per knot (ilqr.hpp:468-499, al_cost.hpp:264-274).
+// FK picks a compile-time constraint layout (FastKind); kFastGeneric is the table-driven fallback.
+// Values and operation order are identical across the variants.
+template <class T, class M, class Ctx, bool LDS, int FK>
+ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run, int kend,
+                           const T* sX, const T* sU, const T* sK, const T* sd, T alpha, T hh, bool valid,
+                           unsigned tb, unsigned Bp, int b, bool check_bounds, T state_max2, T control_max2,
+                           T* xb, T& J, T& gs, bool& ok, int& st) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
-  constexpr int kPerWave = kBlock / LS;  // instances per wavefront (3)
+  const KnotClass& kc = pd->cls[run.cls];
+  RunConsts<T, n, m> RC;
+  load_run_consts<T, n, m>(C, pd, kc, RC);
+  // layout of the specialised variants: circle rows / bound rows inside the knot
+  constexpr bool kHasB = (FK == kFastB || FK == kFastCB || FK == kFastBC);
+  constexpr bool kHasC = (FK == kFastC || FK == kFastCB || FK == kFastBC);
+  constexpr int kCi = (FK == kFastBC) ? 1 : 0;  // constraint index of the circle
+  constexpr int kBi = (FK == kFastCB) ? 1 : 0;  // constraint index of the bound
+  int c_p = 0, c_pi = 0, c_off = 0, c_row = 0, b_row = 0;
+  if (kHasC) {
+    c_p = kc.con[kCi].p;
+    c_pi = kc.con[kCi].per_instance;
+    c_off = kc.con[kCi].param_off;
+    c_row = kc.con[kCi].row_off;
+  }
+  if (kHasB) b_row = kc.con[kBi].row_off;
+  const int nrows = kc.nrows;
+  for (int k = run.k_begin; k < kend; ++k) {
+    T xk[n], uk[m], K[m * n], d[m], ub[m], xn[n];
+    if (LDS) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) xk[i] = sX[k * n + i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) uk[i] = sU[k * m + i];
+#pragma unroll
+      for (int e = 0; e < m * n; ++e) K[e] = sK[k * m * n + e];
+#pragma unroll
+      for (int i = 0; i < m; ++i) d[i] = sd[k * m + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < n; ++i) xk[i] = SOA(A.X, k * n + i);
+#pragma unroll
+      for (int i = 0; i < m; ++i) uk[i] = SOA(A.U, k * m + i);
+#pragma unroll
+      for (int e = 0; e < m * n; ++e) K[e] = SOA(A.K, k * m * n + e);
+#pragma unroll
+      for (int i = 0; i < m; ++i) d[i] = SOA(A.d, k * m + i);
+    }
+    const int rb = run.rowbase + (k - run.k_begin) * nrows;
+    // duals / penalty of the bound rows: loaded up front so that one wait covers the whole knot
+    T blam[2 * m], brho = T(1);
+    if (kHasB) {
+      brho = C.pen(rb + b_row);
+#pragma unroll
+      for (int j = 0; j < 2 * m; ++j) blam[j] = C.lam(rb + b_row + j);
+    }
+    if (ok) {
+      // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
+      T gnum = T(0), gden = T(1);
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int l = 0; l < n; ++l) s += K[i + l * m] * (xb[l] - xk[l]);
+        ub[i] = uk[i] + s + d[i] * alpha;
+        const T num = abs_(d[i]), den = abs_(ub[i]) + T(1);
+        if (num * gden > gnum * den) {
+          gnum = num;
+          gden = den;
+        }
+      }
+      gs += gnum / gden;
+      if (FK == kFastGeneric) {
+        J += knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
+      } else {
+        // quadratic cost (diagonal Q, R guaranteed by the host for the fast kinds)
+        T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          xQx += xb[i] * (RC.Qd[i] * xb[i]);
+          qx += RC.q[i] * xb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          uRu += ub[i] * (RC.Rd[i] * ub[i]);
+          ru += RC.r[i] * ub[i];
+        }
+        T Jk = T(0.5) * xQx + T(0.5) * uRu + qx + ru + RC.c;
+        auto circle_term = [&]() {
+          const T rho = C.pen(rb + c_row);
+          T a = T(0), bsum = T(0);
+          for (int i = 0; i < c_p; ++i) {
+            T dx = xb[0] - C.par(c_pi, c_off, 3 * i);
+            T dy = xb[1] - C.par(c_pi, c_off, 3 * i + 1);
+            T rr = C.par(c_pi, c_off, 3 * i + 2);
+            T c = -(dx * dx + dy * dy - rr * rr);
+            T lam = C.lam(rb + c_row + i);
+            T lp = dual_proj(1, lam - rho * c);
+            a += lp * lp;
+            bsum += lam * lam;
+          }
+          T Jc = a - bsum;
+          Jk += Jc / (2 * rho);
+        };
+        auto bound_term = [&]() {
+          T a = T(0), bsum = T(0);
+#pragma unroll
+          for (int j = 0; j < m; ++j) {
+            T c = RC.bnd[j] - ub[j];
+            T lp = dual_proj(1, blam[j] - brho * c);
+            a += lp * lp;
+            bsum += blam[j] * blam[j];
+          }
+#pragma unroll
+          for (int j = 0; j < m; ++j) {
+            T c = ub[j] - RC.bnd[m + j];
+            T lp = dual_proj(1, blam[m + j] - brho * c);
+            a += lp * lp;
+            bsum += blam[m + j] * blam[m + j];
+          }
+          T Jc = a - bsum;
+          Jk += Jc / (2 * brho);
+        };
+        if (FK == kFastB) bound_term();
+        if (FK == kFastC) circle_term();
+        if (FK == kFastCB) {
+          circle_term();
+          bound_term();
+        }
+        if (FK == kFastBC) {
+          bound_term();
+          circle_term();
+        }
+        J += Jk;
+      }
+      if (valid) {  // idle lanes must not touch instance 0's candidates
+        T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
+#pragma unroll
+        for (int i = 0; i < n; ++i) cand[i] = xb[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
+      }
+      rk4_step<T, M>(xb, ub, hh, xn);
+      if (check_bounds) {
+        // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2 (ilqr.hpp:484-495), no sqrt needed
+        T sx = T(0), su = T(0);
+#pragma unroll
+        for (int i = 0; i < n; ++i) sx += xn[i] * xn[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) su += ub[i] * ub[i];
+        if (sx > state_max2) {
+          ok = false;
+          st = ALTRO_STATE_LIMIT;
+        } else if (su > control_max2) {
+          ok = false;
+          st = ALTRO_CONTROL_LIMIT;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) xb[i] = xn[i];
+    }
+  }
+}
+
+template <class T>
+struct FwdLds {  // element counts of one instance's staged block (after the wave-shared pool copy)
+  int nX, nU, nK, nd, nR, nS;
+  ALTRO_DEV int total() const { return nX + nU + nK + nd + 2 * nR + nS; }
+};
+
+template <class T, class M, bool LDS>
+__global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const ProblemDesc* __restrict__ pd_global,
+                                                    const ProblemDesc pd_arg, DevOpts o, int mode, int all,
+                                                    int per_wave, int* active_counter) {
+  // LDS variant: the problem description comes from the kernel arguments (scalar loads that the
+  // compiler can keep in SGPRs across the serial loop)
+  const ProblemDesc* pd = LDS ? &pd_arg : pd_global;
+  using Ctx = typename std::conditional<LDS, CtxL<T>, CtxG<T>>::type;
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  constexpr int LS = kLineSearchLanes;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int grp = lane / LS;
   const int t = lane - grp * LS;
-  const int b = blockIdx.x * kPerWave + grp;
-  const size_t Bp = A.Bp;
+  const int b0 = blockIdx.x * per_wave + grp;
+  const unsigned Bp = A.Bp;
   const int N = A.N;
-  const bool valid = (grp < kPerWave) && (b < A.B) && (all || A.phase[b] == 1);
-  const int bb = valid ? b : 0;  // idle lanes shadow instance 0's loads but never store
-  KnotCtx<T> C{A, pd, bb};
+  const bool valid = (grp < per_wave) && (b0 < A.B) && (all || A.phase[b0] == 1);
+  if (__ballot(valid) == 0ull) return;  // nothing to do for this wave (finished instances)
+  const int b = valid ? b0 : 0;         // idle lanes shadow instance 0's loads but never store
 
-  const T J0 = A.J0[bb];
-  const T dV0 = A.dV0[bb], dV1 = A.dV1[bb];
+  // ---- phase 0: stage the shared pool and the instance's read-only inputs in LDS ----------------
+  const FwdLds<T> L{(N + 1) * n, N * m, N * m * n, N * m, pd->total_rows, pd->nslots};
+  T* sPool = reinterpret_cast<T*>(smem_raw);
+  T* sm = sPool + pd->npool + (grp < per_wave ? grp : 0) * L.total();
+  T* sX = sm;
+  T* sU = sX + L.nX;
+  T* sK = sU + L.nU;
+  T* sd = sK + L.nK;
+  T* sLam = sd + L.nd;
+  T* sPen = sLam + L.nR;
+  T* sIp = sPen + L.nR;
+  if (LDS) {
+    for (int i = lane; i < pd->npool; i += kBlock) sPool[i] = A.pool[i];
+    if (valid) {
+      // 16 loads in flight per lane before the first LDS write: the copy costs a handful of memory
+      // round trips instead of one per element
+      auto stage = [&](T* dst, const T* src, int cnt) {
+        constexpr int kDepth = 16;
+        for (int i0 = t; i0 < cnt; i0 += LS * kDepth) {
+          T v[kDepth];
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int i = i0 + j * LS;
+            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)b] : T(0);
+          }
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int i = i0 + j * LS;
+            if (i < cnt) dst[i] = v[j];
+          }
+        }
+      };
+      stage(sX, A.X, L.nX);
+      stage(sU, A.U, L.nU);
+      stage(sK, A.K, L.nK);
+      stage(sd, A.d, L.nd);
+      stage(sLam, A.lam, L.nR);
+      stage(sPen, A.pen, L.nR);
+      stage(sIp, A.ipool, L.nS);
+    }
+    __syncthreads();
+  }
+  Ctx C = [&]() {
+    if constexpr (LDS) {
+      return CtxL<T>(A, b, sPool, sIp, sLam, sPen);
+    } else {
+      return CtxG<T>(A, b);
+    }
+  }();
+  const T hh = T(pd->hstep);
+
+  const T J0 = A.J0[b];
+  const T dV0 = A.dV0[b], dV1 = A.dV1[b];
   T x0[n];
 #pragma unroll
-  for (int i = 0; i < n; ++i) x0[i] = A.x0[(size_t)i * Bp + bb];
+  for (int i = 0; i < n; ++i) x0[i] = SOA(A.x0, i);
+  const T state_max2 = T(o.state_max) * T(o.state_max);
+  const T control_max2 = T(o.control_max) * T(o.control_max);
 
   const int ls_max = o.line_search_max_iterations;
   bool accepted = false;
-  T alpha_sel = T(0), J_sel = J0, z_sel = T(-1), g_sel = T(0), g_old = T(0);
-  T alpha_replay = T(0);
-  bool have_replay = false;
+  T alpha_sel = T(0), J_sel = J0, z_sel = T(-1), g_sel = T(0);
+  int t_replay = -1;  // trial whose candidate defines c_ (and Z_ when accepted)
   int last_status = ALTRO_UNSOLVED;
 
   T alpha_base = T(1);
@@ -519,61 +772,44 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
     T alpha = alpha_base;
     for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
     const bool live = valid && (base + t < ls_max);
-    // ---- pass 1: closed-loop rollout + cost for this lane's alpha (ilqr.hpp:468-499, 527) -------
+    // ---- phase 1: closed-loop rollout + cost for this lane's alpha (ilqr.hpp:468-499, 527) -------
     bool ok = true;
     int st = ALTRO_UNSOLVED;
-    T J = T(0), gs = T(0), go = T(0);
+    T J = T(0), gs = T(0);
     T xb[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      T xk[n], uk[m], K[m * n], d[m], ub[m], xn[n];
-#pragma unroll
-      for (int i = 0; i < n; ++i) xk[i] = A.X[((size_t)k * n + i) * Bp + bb];
-#pragma unroll
-      for (int i = 0; i < m; ++i) uk[i] = A.U[((size_t)k * m + i) * Bp + bb];
-#pragma unroll
-      for (int e = 0; e < m * n; ++e) K[e] = A.K[((size_t)k * m * n + e) * Bp + bb];
-#pragma unroll
-      for (int i = 0; i < m; ++i) d[i] = A.d[((size_t)k * m + i) * Bp + bb];
-      if (ok) {
-        T gm = T(0), gmo = T(0);
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-          T s = T(0);
-#pragma unroll
-          for (int l = 0; l < n; ++l) s += K[i + l * m] * (xb[l] - xk[l]);
-          ub[i] = uk[i] + s + d[i] * alpha;
-          gm = max_(gm, abs_(d[i]) / (abs_(ub[i]) + T(1)));
-          gmo = max_(gmo, abs_(d[i]) / (abs_(uk[i]) + T(1)));
-        }
-        gs += gm;
-        go += gmo;
-        J += knot_cost<T, n, m, false>(C, k, xb, ub, nullptr);
-        rk4_step<T, M>(xb, ub, T(A.hstep[k]), xn);
-        if (o.check_forwardpass_bounds) {
-          T sx = T(0), su = T(0);
-#pragma unroll
-          for (int i = 0; i < n; ++i) sx += xn[i] * xn[i];
-#pragma unroll
-          for (int i = 0; i < m; ++i) su += ub[i] * ub[i];
-          if (sqrt_(sx) > T(o.state_max)) {
-            ok = false;
-            st = ALTRO_STATE_LIMIT;
-          } else if (sqrt_(su) > T(o.control_max)) {
-            ok = false;
-            st = ALTRO_CONTROL_LIMIT;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < n; ++i) xb[i] = xn[i];
+    // candidate scratch, instance-major [b][k][trial][x|u]: the 20 trials of an instance write one
+    // contiguous 20*(n+m)-element block per knot
+    const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
+    for (int r = 0; r < pd->nruns; ++r) {
+      const KnotRun run = pd->runs[r];
+      const int kend = run.k_end < N ? run.k_end : N;
+#define ALTRO_RUN(FK)                                                                                     \
+  rollout_run<T, M, Ctx, LDS, FK>(C, pd, A, run, kend, sX, sU, sK, sd, alpha, hh, valid, tb, Bp, b,       \
+                                  o.check_forwardpass_bounds != 0, state_max2, control_max2, xb, J, gs, ok, st)
+      switch (run.fast) {
+        case kFastNone: ALTRO_RUN(kFastNone); break;
+        case kFastB: ALTRO_RUN(kFastB); break;
+        case kFastCB: ALTRO_RUN(kFastCB); break;
+        case kFastBC: ALTRO_RUN(kFastBC); break;
+        case kFastC: ALTRO_RUN(kFastC); break;
+        default: ALTRO_RUN(kFastGeneric); break;
       }
+#undef ALTRO_RUN
     }
     if (ok) {
       T uz[m];
 #pragma unroll
       for (int i = 0; i < m; ++i) uz[i] = T(0);
-      J += knot_cost<T, n, m, false>(C, N, xb, uz, nullptr);
+      const KnotRun runN = pd->runs[pd->nruns - 1];  // the terminal knot closes the last run
+      const KnotClass& kcN = pd->cls[runN.cls];
+      J += knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xb, uz, nullptr);
+      if (valid) {
+        T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
+#pragma unroll
+        for (int i = 0; i < n; ++i) cand[i] = xb[i];
+      }
     }
     // ---- acceptance test (ilqr.hpp:528-542) --------------------------------------------------
     const T expected = -alpha * (dV0 + alpha * dV1);
@@ -597,116 +833,156 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
       g_sel = __shfl(gs, src);
       accepted = true;
       last_status = ALTRO_UNSOLVED;  // the accepted rollout was the last one run (ilqr.hpp:497)
-      alpha_replay = alpha_sel;
-      have_replay = true;
+      t_replay = tsel;
     } else {
       // no acceptance in this round: the serial loop ran all `nlive` trials; c_ now holds the
       // constraint values of the last trial whose rollout succeeded (quirk Q6), and status_ is the
       // outcome of the very last rollout.
-      const int src_last = grp * LS + (nlive - 1);
-      last_status = __shfl(st, src_last);
-      if (ok_g) {
-        const int tl = 31 - __clz(ok_g);
-        alpha_replay = __shfl(alpha, grp * LS + tl);
-        have_replay = true;
-      }
+      last_status = __shfl(st, grp * LS + (nlive - 1));
+      if (ok_g) t_replay = 31 - __clz(ok_g);
     }
-    g_old = __shfl(go, grp * LS);  // trial 0 always runs the whole horizon unless it blew up
-    if (!(ok_g & 1u)) g_old = T(-1);
     alpha_base = __shfl(alpha, grp * LS + (LS - 1)) / T(o.line_search_decrease_factor);
+    if (!accepted && base + LS < ls_max && t_replay >= 0) {
+      // (only reachable with line_search_max_iterations > 20) the next round overwrites the
+      // candidates: c_ then falls back to the values of the expansion step.
+      t_replay = -1;
+    }
   }
+  if (!valid) return;
+  __threadfence_block();  // candidates written by the other lanes of this wave are read below
 
-  if (!valid || t != 0) return;
-
-  // ---- pass 2 (one lane per instance): replay the selected step.  Accepted: write the new
-  //      trajectory in place ((*Z_) = (*Zbar_), ilqr.hpp:548) and the c_ it leaves behind.
-  //      Rejected: only reproduce the stale c_ of the last evaluated candidate (quirk Q6). --------
+  // ---- phase 2: all 20 lanes of the instance, knots strided over lanes -----------------------
+  //      accepted: (*Z_) = (*Zbar_) (ilqr.hpp:548); always: c_ of the last evaluated candidate.
   T viol = T(0);
-  if (have_replay) {
-    T xb[n];
+  if (t_replay >= 0) {
+    const unsigned rbo = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t_replay) * (unsigned)nm;
+    for (int k = t; k <= N; k += LS) {
+      T xs[n], us[m];
+      const T* cand = A.trial + (rbo + (unsigned)k * (unsigned)(LS * nm));
 #pragma unroll
-    for (int i = 0; i < n; ++i) xb[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      T xk[n], uk[m], K[m * n], d[m], ub[m], xn[n];
+      for (int i = 0; i < n; ++i) xs[i] = cand[i];
 #pragma unroll
-      for (int i = 0; i < n; ++i) xk[i] = A.X[((size_t)k * n + i) * Bp + b];
-#pragma unroll
-      for (int i = 0; i < m; ++i) uk[i] = A.U[((size_t)k * m + i) * Bp + b];
-#pragma unroll
-      for (int e = 0; e < m * n; ++e) K[e] = A.K[((size_t)k * m * n + e) * Bp + b];
-#pragma unroll
-      for (int i = 0; i < m; ++i) d[i] = A.d[((size_t)k * m + i) * Bp + b];
-#pragma unroll
-      for (int i = 0; i < m; ++i) {
-        T s = T(0);
-#pragma unroll
-        for (int l = 0; l < n; ++l) s += K[i + l * m] * (xb[l] - xk[l]);
-        ub[i] = uk[i] + s + d[i] * alpha_replay;
-      }
+      for (int i = 0; i < m; ++i) us[i] = (k < N) ? cand[n + i] : T(0);
+      int rb;
+      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
       T v;
-      knot_cost<T, n, m, true>(C, k, xb, ub, &v);
+      knot_cost<T, n, m, true>(C, pd, kc, rb, xs, us, &v);
       viol = max_(viol, v);
       if (accepted) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) A.X[((size_t)k * n + i) * Bp + b] = xb[i];
+        for (int i = 0; i < n; ++i) SOA(A.X, k * n + i) = xs[i];
+        if (k < N) {
 #pragma unroll
-        for (int i = 0; i < m; ++i) A.U[((size_t)k * m + i) * Bp + b] = ub[i];
+          for (int i = 0; i < m; ++i) SOA(A.U, k * m + i) = us[i];
+        }
       }
-      rk4_step<T, M>(xb, ub, T(A.hstep[k]), xn);
-#pragma unroll
-      for (int i = 0; i < n; ++i) xb[i] = xn[i];
     }
-    T uz[m], v;
-#pragma unroll
-    for (int i = 0; i < m; ++i) uz[i] = T(0);
-    knot_cost<T, n, m, true>(C, N, xb, uz, &v);
-    viol = max_(viol, v);
+  }
+  // max over the instance's lanes
+  {
+    T vm = viol;
+    for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
+    viol = vm;
+  }
+  if (t_replay < 0) {
+    // c_ untouched since the expansion step: recompute the max violation of the stored values
+    T vpart = T(0);
+    for (int k = t; k <= N; k += LS) {
+      int rb;
+      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+      for (int ci = 0; ci < kc.ncon; ++ci)
+        for (int i = 0; i < kc.con[ci].p; ++i)
+          vpart = max_(vpart, violation(kc.con[ci].type, SOA(A.cval, rb + kc.con[ci].row_off + i)));
+    }
+    T vm = vpart;
+    for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(vpart, grp * LS + j));
+    viol = vm;
+  }
+
+  // ---- phase 3: per-instance state machine.  Lane 0 of the instance takes the decisions; the
+  //      row sweeps of the AL transition (dual and penalty updates) are spread over its 20 lanes.
+  int inner_done = 0;
+  if (t == 0) {
     if (accepted) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) A.X[((size_t)N * n + i) * Bp + b] = xb[i];
+      A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
+      A.alpha[b] = alpha_sel;
+      A.z[b] = z_sel;
+    } else {
+      T rho = A.rho_reg[b], drho = A.drho[b];
+      increase_reg(o, &rho, &drho);  // ilqr.hpp:550
+      A.rho_reg[b] = rho;
+      A.drho[b] = drho;
     }
-  } else {
-    T pmax;
-    rows_viol_pen(A, pd, b, &viol, &pmax);  // c_ untouched since the expansion step
-  }
-
-  if (accepted) {
-    A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
-    A.alpha[b] = alpha_sel;
-    A.z[b] = z_sel;
-  } else {
-    T rho = A.rho_reg[b], drho = A.drho[b];
-    increase_reg(o, &rho, &drho);  // ilqr.hpp:550
-    A.rho_reg[b] = rho;
-    A.drho[b] = drho;
-  }
-  A.status[b] = last_status;
-  if (mode == kFwdStepOnly) {
-    A.viol[b] = viol;
-    return;
-  }
-
-  T gsum = accepted ? g_sel : g_old;
-  if (!accepted && g_old < T(0)) {  // trial 0 aborted early: recompute with the unchanged controls
-    gsum = T(0);
-    for (int k = 0; k < N; ++k) {
-      T mx = T(0);
+    A.status[b] = last_status;
+    if (mode == kFwdStepOnly) {
+      A.viol[b] = viol;
+    } else {
+      T gsum = g_sel;
+      if (!accepted) {  // rejected step: the controls are unchanged (quirk Q12 uses the current Z_)
+        gsum = T(0);
+        for (int k = 0; k < N; ++k) {
+          T mx = T(0);
 #pragma unroll
-      for (int i = 0; i < m; ++i) {
-        const size_t idx = ((size_t)k * m + i) * Bp + b;
-        mx = max_(mx, abs_(A.d[idx]) / (abs_(A.U[idx]) + T(1)));
+          for (int i = 0; i < m; ++i) {
+            const T dv = LDS ? sd[k * m + i] : SOA(A.d, k * m + i);
+            const T uv = LDS ? sU[k * m + i] : SOA(A.U, k * m + i);
+            mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
+          }
+          gsum += mx;
+        }
       }
-      gsum += mx;
+      inner_done = conv_stats_and_done(A, o, b, gsum, viol) ? 1 : 0;
     }
   }
+  if (mode == kFwdStepOnly) return;
+  inner_done = __shfl(inner_done, grp * LS);
   bool active = true;
-  if (conv_stats_and_done(A, o, b, gsum, viol)) {
+  if (inner_done) {
     if (mode == kFwdAL) {
-      active = al_outer_step(A, pd, o, b);
+      // AugmentedLagrangianiLQR: UpdateDuals, UpdateConvergenceStatistics, IsDone, UpdatePenalties
+      // (al_solver.hpp:313-401); each lane sweeps the rows of knots t, t+20, ...
+      T vpart = T(0), ppart = T(0);
+      for (int k = t; k <= N; k += LS) {
+        int rb;
+        const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+        for (int ci = 0; ci < kc.ncon; ++ci) {
+          const ConDesc& cd = kc.con[ci];
+          for (int i = 0; i < cd.p; ++i) {
+            const unsigned idx = (unsigned)(rb + cd.row_off + i) * Bp + (unsigned)b;
+            const T c = A.cval[idx], rho = A.pen[idx];
+            A.lam[idx] = dual_proj(cd.type, A.lam[idx] - rho * c);  // constraint_values.hpp:192-194
+            vpart = max_(vpart, violation(cd.type, c));
+            ppart = max_(ppart, rho);
+          }
+        }
+      }
+      T vm = vpart, pm = ppart;
+      for (int j = 0; j < LS; ++j) {
+        vm = max_(vm, __shfl(vpart, grp * LS + j));
+        pm = max_(pm, __shfl(ppart, grp * LS + j));
+      }
+      int cont = 0;
+      if (t == 0) cont = al_outer_decide(A, o, b, vm, pm) ? 1 : 0;
+      cont = __shfl(cont, grp * LS);
+      if (cont) {
+        for (int k = t; k <= N; k += LS) {  // constraint_values.hpp:202-207
+          const int cls = A.knot_class[k];
+          const KnotClass& kc = pd->cls[cls];
+          const int rb = A.knot_rowbase[k];
+          for (int ci = 0; ci < kc.ncon; ++ci) {
+            const T phi = T(A.phi[cls * kMaxConPerKnot + ci]);
+            for (int i = 0; i < kc.con[ci].p; ++i)
+              A.pen[(unsigned)(rb + kc.con[ci].row_off + i) * Bp + (unsigned)b] *= phi;
+          }
+        }
+        if (t == 0) begin_inner_solve(A, o, b);
+      }
+      active = cont != 0;
     } else {
       active = false;
     }
   }
+  if (t != 0) return;
   if (!active) {
     A.phase[b] = 0;
   } else if (active_counter) {

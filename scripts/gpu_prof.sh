@@ -1,16 +1,14 @@
-# One GPU visit: parity tests, smoke, bench, rocprof kernel trace of the bench.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -m pytest tests -q -m gpu 2>&1 | grep -v "^E  " | tail -12 | tee gpurun_out/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
-python bench.py --steps 3 --warmup 1 2>&1 | tail -1 | tee gpurun_out/bench.log
 rm -rf gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof_run.log 2>&1
+ls -R gpurun_out/prof | head
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/prof/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
+print(rows[0].keys())
 per = collections.defaultdict(list)
 for r in rows:
     name = r['Kernel_Name']
@@ -19,6 +17,6 @@ for r in rows:
 for k,v in per.items():
     v.sort()
     d=[x[1] for x in v]
-    n=len(d)//2
-    print(k, 'launches', len(d), 'first solve durations us:', [round(x) for x in d[:n][:20]], '...', [round(x) for x in d[:n][-6:]])
+    n=len(d)//2  # bench runs 2 solves (timed + profiled)
+    print(k, 'launches', len(d), 'first solve durations us:', [round(x) for x in d[:n][:24]], '...', [round(x) for x in d[:n][-6:]])
 PY
