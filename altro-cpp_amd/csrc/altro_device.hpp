@@ -1,10 +1,9 @@
 // altro_device.hpp — per-knot-point device math of the batched AL-iLQR solver (gfx950).
 //
-// Data layout in HBM is struct-of-arrays with the BATCH index innermost ("batch-minor"): element e
-// of knot k of instance b lives at arr[(k*E + e)*Bp + b], so the 64 lanes of a wavefront, which
-// always hold 64 consecutive instances (or a few instances x line-search trials), issue fully
-// coalesced 512-byte loads and stores.  All per-knot matrices are tiny (n<=12, m<=4) and live in
-// VGPRs as fully unrolled arrays; nothing here touches scratch memory.
+// Data layout in HBM: per-knot RECORDS, batch-minor at record granularity -- element e of knot k of
+// instance b lives at arr[(k*Bp + b)*EP + e] (see struct Rec).  Constraint rows and per-instance
+// scalars are plain struct-of-arrays [row][b].  All per-knot matrices are tiny (n<=12, m<=4) and
+// live in VGPRs as fully unrolled arrays; nothing here touches scratch memory.
 //
 // Every function cites the reference code it replaces (paths relative to the reference root).
 #pragma once
@@ -20,25 +19,84 @@ namespace altro_hip {
 // -------------------------------------------------------------------------------------------------
 // Device array bundle (passed to kernels by value)
 // -------------------------------------------------------------------------------------------------
+// Record layout.  Per-knot data of one instance is a contiguous, 16-byte aligned RECORD; records of
+// the 64 instances a wavefront owns are adjacent: arr[(k*Bp + b)*EP + e].  A lane therefore reads
+// its record with a few 16-byte vector loads whose only varying address part is a scalar (k) --
+// no per-element address arithmetic on the serial critical path -- and a wave touches one
+// contiguous 64*EP*sizeof(T) block (fully coalesced).
+template <class T, int n, int m>
+struct Rec {
+  static constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte vector
+  static constexpr int pad(int e) { return (e + V - 1) / V * V; }
+  static constexpr int nP = pad(n), mP = pad(m);  // X / U records
+  // expansion record: [A|B] | lxx | lxu | luu | lx | lu
+  static constexpr int oAB = 0, oLxx = n * (n + m), oLxu = oLxx + n * n, oLuu = oLxu + n * m,
+                       oLx = oLuu + m * m, oLu = oLx + n, eE = oLu + m, EP = pad(eE);
+  // gain record: K (m x n, column-major) | d
+  static constexpr int oK = 0, oD = m * n, KP = pad(m * n + m);
+  // cost-to-go record: P | p
+  static constexpr int oP = 0, op = n * n, CP = pad(n * n + n);
+};
+template <class T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  using type = double2;
+};
+template <>
+struct VecOf<float> {
+  using type = float4;
+};
+// 16-byte vector copies between a record (global / LDS) and registers; EP is a padded length.
+template <class T, int EP>
+__device__ __forceinline__ void load_rec(const T* p, T* out) {
+  using V = typename VecOf<T>::type;
+  constexpr int VN = 16 / (int)sizeof(T);
+  const V* pv = reinterpret_cast<const V*>(p);
+#pragma unroll
+  for (int i = 0; i < EP / VN; ++i) {
+    const V v = pv[i];
+    const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) out[i * VN + j] = e[j];
+  }
+}
+template <class T, int EP>
+__device__ __forceinline__ void store_rec(T* p, const T* in) {
+  using V = typename VecOf<T>::type;
+  constexpr int VN = 16 / (int)sizeof(T);
+  V* pv = reinterpret_cast<V*>(p);
+#pragma unroll
+  for (int i = 0; i < EP / VN; ++i) {
+    V v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) e[j] = in[i * VN + j];
+    pv[i] = v;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Device array bundle (passed to kernels by value)
+// -------------------------------------------------------------------------------------------------
 template <class T>
 struct DevArrays {
   int B, Bp, N;
-  // trajectory (Z_), initial state
+  // trajectory (Z_) records X[k][b][nP], U[k][b][mP]; initial state x0[b][nP]
   T *x0, *X, *U;
-  // expansions: dynamics Jacobian [A|B], cost expansion, per-knot cost
-  T *AB, *lxx, *lxu, *luu, *lx, *lu, *costs;
-  // gains, cost-to-go (P, p recorded per knot only on request)
-  T *K, *d, *P, *p;
+  // expansion records EXP[k][b][EP] (dynamics Jacobian + cost expansion), per-knot cost costs[k][b]
+  T *EXP, *costs;
+  // gain records KD[k][b][KP]; cost-to-go records CTG[k][b][CP] (written only on request)
+  T *KD, *CTG;
   // line-search candidates, instance-major [b][k][trial][x|u] (Zbar_ of every speculative trial)
   T* trial;
-  // constraint rows: duals, penalties, stored constraint values (c_)
+  // constraint rows [row][b]: duals, penalties, stored constraint values (c_)
   T *lam, *pen, *cval;
   // parameters
   const T *pool, *ipool;
   const int *knot_class, *knot_rowbase;
-  const float* hstep;
   const double* phi;  // penalty scaling per (class, constraint): phi[cls*kMaxConPerKnot + c]
-  // per-instance solver state
+  // per-instance solver state [field][b]
   T *rho_reg, *drho, *dV0, *dV1, *J0, *initial_cost, *cost_cur, *cost_prev, *dJ, *grad, *viol,
       *penmax, *alpha, *z, *reg_log;
   int *status, *status_al, *it_inner, *it_outer, *it_total, *phase, *need_init_cost;
@@ -784,9 +842,15 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
 // Cholesky factorisation of Quu + rho I hits a non-positive pivot (Eigen::NumericalIssue).
 // Gains come from the REGULARISED Q, cost-to-go from the UN-regularised Q (quirk Q3).
 // -------------------------------------------------------------------------------------------------
+// Part 1: action-value expansion (knot_point_function_type.hpp:149-164).  Consumes [A|B] and the
+// cost expansion; after it returns the caller may overwrite those registers with the next knot's.
 template <class T, int n, int m>
-ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* luu, const T* lx,
-                            const T* lu, T rho, T* P, T* p, T* K, T* d, T* dV0, T* dV1) {
+struct QExp {
+  T Qxx[n * n], Qxu[n * m], Quu[m * m], Qx[n], Qu[m];
+};
+template <class T, int n, int m>
+ALTRO_DEV void riccati_q(const T* AB, const T* lxx, const T* lxu, const T* luu, const T* lx, const T* lu,
+                         const T* P, const T* p, QExp<T, n, m>& Q) {
   const T* A = AB;
   const T* Bm = AB + n * n;
   T AtP[n * n], BtP[m * n];
@@ -807,7 +871,6 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
       BtP[i + j * m] = s;
     }
   }
-  T Qxx[n * n], Qxu[n * m], Quu[m * m], Qx[n], Qu[m];
 #pragma unroll
   for (int j = 0; j < n; ++j)
 #pragma unroll
@@ -815,7 +878,7 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
       T s = T(0);
 #pragma unroll
       for (int l = 0; l < n; ++l) s += AtP[i + l * n] * A[l + j * n];
-      Qxx[i + j * n] = lxx[i + j * n] + s;
+      Q.Qxx[i + j * n] = lxx[i + j * n] + s;
     }
 #pragma unroll
   for (int j = 0; j < m; ++j)
@@ -824,7 +887,7 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
       T s = T(0);
 #pragma unroll
       for (int l = 0; l < n; ++l) s += AtP[i + l * n] * Bm[l + j * n];
-      Qxu[i + j * n] = lxu[i + j * n] + s;
+      Q.Qxu[i + j * n] = lxu[i + j * n] + s;
     }
 #pragma unroll
   for (int j = 0; j < m; ++j)
@@ -833,22 +896,36 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
       T s = T(0);
 #pragma unroll
       for (int l = 0; l < n; ++l) s += BtP[i + l * m] * Bm[l + j * n];
-      Quu[i + j * m] = luu[i + j * m] + s;
+      Q.Quu[i + j * m] = luu[i + j * m] + s;
     }
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     T s = T(0);
 #pragma unroll
     for (int l = 0; l < n; ++l) s += A[l + i * n] * p[l];
-    Qx[i] = lx[i] + s;
+    Q.Qx[i] = lx[i] + s;
   }
 #pragma unroll
   for (int i = 0; i < m; ++i) {
     T s = T(0);
 #pragma unroll
     for (int l = 0; l < n; ++l) s += Bm[l + i * n] * p[l];
-    Qu[i] = lu[i] + s;
+    Q.Qu[i] = lu[i] + s;
   }
+}
+
+// Part 2: RegularizeActionValue, CalcGains, CalcCostToGo, AddCostToGo
+// (knot_point_function_type.hpp:175-235).  Out (only on success): K, d, P/p of this knot
+// (overwriting the next knot's), dV += (d^T Qu, 0.5 d^T Quu d).  Returns false when the Cholesky
+// factorisation of Quu + rho I hits a non-positive pivot (Eigen::NumericalIssue).
+// Gains come from the REGULARISED Q, cost-to-go from the UN-regularised Q (quirk Q3).
+template <class T, int n, int m>
+ALTRO_DEV bool riccati_gains(const QExp<T, n, m>& Q, T rho, T* P, T* p, T* K, T* d, T* dV0, T* dV1) {
+  const T* Qxx = Q.Qxx;
+  const T* Qxu = Q.Qxu;
+  const T* Quu = Q.Quu;
+  const T* Qx = Q.Qx;
+  const T* Qu = Q.Qu;
   // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure
   T L[m * m], Linv[m];
 #pragma unroll
@@ -952,6 +1029,7 @@ ALTRO_DEV bool riccati_knot(const T* AB, const T* lxx, const T* lxu, const T* lu
   *dV1 += T(0.5) * v1;
   return true;
 }
+
 
 // iLQR::IncreaseRegularization / DecreaseRegularization (altro/ilqr/ilqr.hpp:770-786)
 template <class T>

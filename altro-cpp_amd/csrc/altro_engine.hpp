@@ -63,6 +63,7 @@ inline DevOpts ToDevOpts(const altro_options& o) {
 template <class T, class M>
 class Engine final : public EngineBase {
   static constexpr int n = M::n, m = M::m, nm = n + m;
+  using R = Rec<T, n, m>;
   static constexpr int kRing = 4;
 
  public:
@@ -98,8 +99,8 @@ class Engine final : public EngineBase {
 
   altro_status ResetTrajectory() override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * n * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.U, U_init_, (size_t)N_ * m * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    ALTRO_HIP_CHECK(hipMemcpyAsync(A_.U, U_init_, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     return ALTRO_OK;
   }
   altro_status SetPenalty(double rho) override {
@@ -133,7 +134,7 @@ class Engine final : public EngineBase {
   }
   altro_status Rollout(const altro_options&) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, 1);
+    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     return Sync();
   }
   altro_status Cost(const altro_options&, double* J) override {
@@ -193,18 +194,18 @@ class Engine final : public EngineBase {
   // ---- results ----------------------------------------------------------------------------------
   altro_status GetTrajectory(double* X, double* U) override {
     if (X) {
-      altro_status st = DownloadKnots(A_.X, N_ + 1, n, X);
+      altro_status st = DownloadRec(A_.X, N_ + 1, R::nP, 0, n, X);
       if (st != ALTRO_OK) return st;
     }
-    if (U) return DownloadKnots(A_.U, N_, m, U);
+    if (U) return DownloadRec(A_.U, N_, R::mP, 0, m, U);
     return ALTRO_OK;
   }
   altro_status GetGains(double* K, double* d) override {
     if (K) {
-      altro_status st = DownloadKnots(A_.K, N_, m * n, K);
+      altro_status st = DownloadRec(A_.KD, N_, R::KP, R::oK, m * n, K);
       if (st != ALTRO_OK) return st;
     }
-    if (d) return DownloadKnots(A_.d, N_, m, d);
+    if (d) return DownloadRec(A_.KD, N_, R::KP, R::oD, m, d);
     return ALTRO_OK;
   }
   altro_status SetRecordCtg(int enable) override {
@@ -217,25 +218,32 @@ class Engine final : public EngineBase {
       return ALTRO_NOT_READY;
     }
     if (P) {
-      altro_status st = DownloadKnots(A_.P, N_ + 1, n * n, P);
+      altro_status st = DownloadRec(A_.CTG, N_ + 1, R::CP, R::oP, n * n, P);
       if (st != ALTRO_OK) return st;
     }
-    if (p) return DownloadKnots(A_.p, N_ + 1, n, p);
+    if (p) return DownloadRec(A_.CTG, N_ + 1, R::CP, R::op, n, p);
     return ALTRO_OK;
   }
   altro_status GetExpansion(int k, double* AB, double* lxx, double* lxu, double* luu, double* lx,
                             double* lu) override {
     if (k < 0 || k > N_) return ALTRO_INVALID_ARG;
-    altro_status st = ALTRO_OK;
-    if (AB && k < N_) st = DownloadOneKnot(A_.AB, k, n * nm, AB);
-    if (st == ALTRO_OK && lxx) st = DownloadOneKnot(A_.lxx, k, n * n, lxx);
-    if (st == ALTRO_OK && lxu && k < N_) st = DownloadOneKnot(A_.lxu, k, n * m, lxu);
-    if (st == ALTRO_OK && luu && k < N_) st = DownloadOneKnot(A_.luu, k, m * m, luu);
-    if (st == ALTRO_OK && lx) st = DownloadOneKnot(A_.lx, k, n, lx);
-    if (st == ALTRO_OK && lu && k < N_) st = DownloadOneKnot(A_.lu, k, m, lu);
-    return st;
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    std::vector<T> h((size_t)R::EP * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), A_.EXP + (size_t)k * Bp_ * R::EP, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    auto take = [&](double* out, int off, int E, bool stage_only) {
+      if (!out || (stage_only && k >= N_)) return;
+      for (int b = 0; b < B_; ++b)
+        for (int e = 0; e < E; ++e) out[(size_t)b * E + e] = (double)h[(size_t)b * R::EP + off + e];
+    };
+    take(AB, R::oAB, n * nm, true);
+    take(lxx, R::oLxx, n * n, false);
+    take(lxu, R::oLxu, n * m, true);
+    take(luu, R::oLuu, m * m, true);
+    take(lx, R::oLx, n, false);
+    take(lu, R::oLu, m, true);
+    return ALTRO_OK;
   }
-  altro_status GetKnotCosts(double* costs) override { return DownloadKnots(A_.costs, N_ + 1, 1, costs); }
+  altro_status GetKnotCosts(double* costs) override { return DownloadRec(A_.costs, N_ + 1, 1, 0, 1, costs); }
   int NumRows() override { return pd_.total_rows; }
   int NumRowsAt(int k) override {
     if (k < 0 || k > N_) return -1;
@@ -381,33 +389,29 @@ class Engine final : public EngineBase {
     for (int b = 0; b < B_; ++b) out[b] = (double)h[b];
     return ALTRO_OK;
   }
-  // device [knots][E][Bp] -> host [B][knots][E]
-  altro_status DownloadKnots(const T* dev, int knots, int E, double* out) {
+  // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]
+  altro_status DownloadRec(const T* dev, int knots, int EP, int off, int E, double* out) {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    std::vector<T> h((size_t)knots * E * Bp_);
+    std::vector<T> h((size_t)knots * EP * Bp_);
     ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, h.size() * sizeof(T), hipMemcpyDeviceToHost));
-    const size_t KE = (size_t)knots * E;
-    for (size_t ke = 0; ke < KE; ++ke) {
-      const T* src = &h[ke * Bp_];
-      for (int b = 0; b < B_; ++b) out[(size_t)b * KE + ke] = (double)src[b];
-    }
+    for (int k = 0; k < knots; ++k)
+      for (int b = 0; b < B_; ++b) {
+        const T* src = &h[((size_t)k * Bp_ + b) * EP + off];
+        double* dst = out + ((size_t)b * knots + k) * E;
+        for (int e = 0; e < E; ++e) dst[e] = (double)src[e];
+      }
     return ALTRO_OK;
   }
-  altro_status DownloadOneKnot(const T* dev, int k, int E, double* out) {
-    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    std::vector<T> h((size_t)E * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev + (size_t)k * E * Bp_, h.size() * sizeof(T), hipMemcpyDeviceToHost));
-    for (int e = 0; e < E; ++e)
-      for (int b = 0; b < B_; ++b) out[(size_t)b * E + e] = (double)h[(size_t)e * Bp_ + b];
-    return ALTRO_OK;
-  }
-  // host [B][knots][E] (or shared [knots][E]) -> device [knots][E][Bp]
-  altro_status UploadKnots(T* dev, int knots, int E, const double* src, bool per_instance) {
-    const size_t KE = (size_t)knots * E;
-    std::vector<T> h(KE * Bp_, T(0));
+  // host [B][knots][E] (or shared [knots][E]) -> device records [knots][Bp][EP] (padding zeroed)
+  altro_status UploadRec(T* dev, int knots, int EP, int E, const double* src, bool per_instance) {
+    std::vector<T> h((size_t)knots * EP * Bp_, T(0));
     if (src)
-      for (size_t ke = 0; ke < KE; ++ke)
-        for (int b = 0; b < B_; ++b) h[ke * Bp_ + b] = T(src[(per_instance ? (size_t)b * KE : 0) + ke]);
+      for (int k = 0; k < knots; ++k)
+        for (int b = 0; b < B_; ++b) {
+          const double* s0 = src + ((per_instance ? (size_t)b * knots : 0) + k) * E;
+          T* dst = &h[((size_t)k * Bp_ + b) * EP];
+          for (int e = 0; e < E; ++e) dst[e] = T(s0[e]);
+        }
     ALTRO_HIP_CHECK(hipMemcpy(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
@@ -415,18 +419,19 @@ class Engine final : public EngineBase {
   altro_status SetInitialStateImpl(const ProblemSpec& s) {
     if (!uploaded_) return ALTRO_OK;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    if (s.x0.empty()) return UploadKnots(A_.x0, 1, n, nullptr, false);
-    return UploadKnots(A_.x0, 1, n, s.x0.data(), s.x0_per_instance != 0);
+    // x0 records [b][nP]: one "knot" with Bp instances
+    if (s.x0.empty()) return UploadRec(A_.x0, 1, R::nP, n, nullptr, false);
+    return UploadRec(A_.x0, 1, R::nP, n, s.x0.data(), s.x0_per_instance != 0);
   }
   altro_status SetTrajectoryImpl(const ProblemSpec& s) {
     if (!uploaded_) return ALTRO_OK;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    altro_status st = UploadKnots(A_.X, N_ + 1, n, s.has_X ? s.X.data() : nullptr, s.traj_per_instance != 0);
+    altro_status st = UploadRec(A_.X, N_ + 1, R::nP, n, s.has_X ? s.X.data() : nullptr, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
-    st = UploadKnots(A_.U, N_, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
+    st = UploadRec(A_.U, N_, R::mP, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
-    ALTRO_HIP_CHECK(hipMemcpy(X_init_, A_.X, (size_t)(N_ + 1) * n * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
-    ALTRO_HIP_CHECK(hipMemcpy(U_init_, A_.U, (size_t)N_ * m * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    ALTRO_HIP_CHECK(hipMemcpy(X_init_, A_.X, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    ALTRO_HIP_CHECK(hipMemcpy(U_init_, A_.U, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
     return ALTRO_OK;
   }
 
@@ -686,7 +691,7 @@ class Engine final : public EngineBase {
     }
     {
       const double lim = 2147483647.0;
-      const double biggest = std::max({(double)N_ * n * nm * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
+      const double biggest = std::max({(double)(N_ + 1) * R::EP * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
                                        (double)std::max(rows, 1) * Bp_});
       if (biggest > lim) {
         err_ = "problem too large for 32-bit device indexing (split the batch over several handles)";
@@ -705,28 +710,21 @@ class Engine final : public EngineBase {
     altro_status st_ = Alloc(&(ptr), (count));      \
     if (st_ != ALTRO_OK) return st_;                \
   } while (0)
-    ALTRO_ALLOC(A_.x0, n * bp);
-    ALTRO_ALLOC(A_.X, (size_t)(N_ + 1) * n * bp);
-    ALTRO_ALLOC(A_.U, (size_t)N_ * m * bp);
-    ALTRO_ALLOC(A_.AB, (size_t)N_ * n * nm * bp);
-    ALTRO_ALLOC(A_.lxx, (size_t)(N_ + 1) * n * n * bp);
-    ALTRO_ALLOC(A_.lxu, (size_t)N_ * n * m * bp);
-    ALTRO_ALLOC(A_.luu, (size_t)N_ * m * m * bp);
-    ALTRO_ALLOC(A_.lx, (size_t)(N_ + 1) * n * bp);
-    ALTRO_ALLOC(A_.lu, (size_t)N_ * m * bp);
+    ALTRO_ALLOC(A_.x0, (size_t)R::nP * bp);
+    ALTRO_ALLOC(A_.X, (size_t)(N_ + 1) * R::nP * bp);
+    ALTRO_ALLOC(A_.U, (size_t)N_ * R::mP * bp);
+    ALTRO_ALLOC(A_.EXP, (size_t)(N_ + 1) * R::EP * bp);
     ALTRO_ALLOC(A_.costs, (size_t)(N_ + 1) * bp);
-    ALTRO_ALLOC(A_.K, (size_t)N_ * m * n * bp);
-    ALTRO_ALLOC(A_.d, (size_t)N_ * m * bp);
-    ALTRO_ALLOC(A_.P, (size_t)(N_ + 1) * n * n * bp);
-    ALTRO_ALLOC(A_.p, (size_t)(N_ + 1) * n * bp);
+    ALTRO_ALLOC(A_.KD, (size_t)N_ * R::KP * bp);
+    ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
     ALTRO_HIP_CHECK(hipMalloc((void**)&A_.trial, (size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T)));
     allocs_.push_back((void*)A_.trial);
     ALTRO_ALLOC(A_.lam, (size_t)rows * bp);
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
     ALTRO_ALLOC(d_tmp_, bp);
-    ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * n * bp);
-    ALTRO_ALLOC(U_init_, (size_t)N_ * m * bp);
+    ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * R::nP * bp);
+    ALTRO_ALLOC(U_init_, (size_t)N_ * R::mP * bp);
     T* dpool = nullptr;
     T* dipool = nullptr;
     ALTRO_ALLOC(dpool, pool.size());
@@ -742,18 +740,12 @@ class Engine final : public EngineBase {
     A_.pool = dpool;
     A_.ipool = dipool;
     int *dkc = nullptr, *dkr = nullptr;
-    float* dh = nullptr;
     ALTRO_ALLOC(dkc, N_ + 1);
     ALTRO_ALLOC(dkr, N_ + 1);
-    ALTRO_ALLOC(dh, N_ + 1);
-    std::vector<float> hs(N_ + 1, s.hstep);
-    hs[N_] = 0.0f;  // trajectory.hpp:128
     ALTRO_HIP_CHECK(hipMemcpy(dkc, knot_class_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
     ALTRO_HIP_CHECK(hipMemcpy(dkr, knot_rowbase_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
-    ALTRO_HIP_CHECK(hipMemcpy(dh, hs.data(), (N_ + 1) * sizeof(float), hipMemcpyHostToDevice));
     A_.knot_class = dkc;
     A_.knot_rowbase = dkr;
-    A_.hstep = dh;
     ALTRO_ALLOC(d_phi_, kMaxClasses * kMaxConPerKnot);
     {
       std::vector<double> v(kMaxClasses * kMaxConPerKnot, s.phi >= 1.0 ? s.phi : 10.0);  // constraint_values.hpp:30
@@ -780,8 +772,9 @@ class Engine final : public EngineBase {
     {
       // LDS plan of the forward pass: up to 3 instances per wavefront, at most 80 KiB per workgroup
       // (two workgroups per CU); if even one instance does not fit in 160 KiB, read from HBM instead.
-      const size_t per_inst = ((size_t)(N_ + 1) * n + (size_t)N_ * m + (size_t)N_ * m * n + (size_t)N_ * m +
-                               2 * (size_t)rows + ip.size()) * sizeof(T);
+      auto padv = [](size_t e) { return (e + R::V - 1) / R::V * R::V; };
+      const size_t per_inst = ((size_t)(N_ + 1) * R::nP + (size_t)N_ * R::mP + (size_t)N_ * R::KP +
+                               2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T);
       const int lanes_max = kBlock / kLineSearchLanes;
       fwd_per_wave_ = lanes_max;
       while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
@@ -829,7 +822,7 @@ class Engine final : public EngineBase {
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
     hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, d, 1);
-    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, 1);
+    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     timing_.launches += (mode == kFwdAL) ? 3 : 2;
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     ALTRO_HIP_CHECK(hipGetLastError());

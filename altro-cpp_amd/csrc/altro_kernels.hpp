@@ -29,9 +29,10 @@ namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
 
-// Batch-minor SoA element: arr[(row)*Bp + b] with 32-bit index arithmetic (every array of the
-// BASELINE configurations has < 2^31 elements; Upload() rejects larger problems).
+// constraint rows and per-instance scalars: arr[row*Bp + b]
 #define SOA(arr, row) (arr)[(unsigned)(row) * (unsigned)Bp + (unsigned)b]
+// record base of knot k for this lane's instance: arr + (k*Bp + b)*EP
+#define RECP(arr, k, EP) ((arr) + ((size_t)(unsigned)(k) * (unsigned)Bp + (unsigned)b) * (unsigned)(EP))
 
 template <class T>
 ALTRO_DEV const KnotClass& class_of_knot(const DevArrays<T>& A, const ProblemDesc* pd, int k, int* rowbase) {
@@ -63,144 +64,124 @@ template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
                                                        int all) {
   constexpr int n = M::n, m = M::m, nm = n + m;
+  using R = Rec<T, n, m>;
   const int b = blockIdx.x * kBlock + threadIdx.x;
   const int k = blockIdx.y;
   if (b >= A.B) return;
   if (!all && A.phase[b] != 1) return;
   const int N = A.N;
-  const size_t Bp = A.Bp;
-  T x[n], u[m];
+  const unsigned Bp = A.Bp;
+  T xr[R::nP], ur[R::mP];
+  load_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
 #pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = A.X[((size_t)k * n + i) * Bp + b];
-#pragma unroll
-  for (int i = 0; i < m; ++i) u[i] = (k < N) ? A.U[((size_t)k * m + i) * Bp + b] : T(0);
+  for (int i = 0; i < R::mP; ++i) ur[i] = T(0);
+  if (k < N) load_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
   CtxG<T> C(A, b);
-  T gx[n], gu[m], hxx[n * n], hxu[n * m], huu[m * m];
+  T E[R::EP];
+#pragma unroll
+  for (int e = 0; e < R::EP; ++e) E[e] = T(0);
   int rb;
   const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-  T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, x, u, gx, gu, hxx, hxu, huu);
-  A.costs[(size_t)k * Bp + b] = J;
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) A.lxx[((size_t)k * n * n + e) * Bp + b] = hxx[e];
-#pragma unroll
-  for (int e = 0; e < n; ++e) A.lx[((size_t)k * n + e) * Bp + b] = gx[e];
-  if (k < N) {
-#pragma unroll
-    for (int e = 0; e < n * m; ++e) A.lxu[((size_t)k * n * m + e) * Bp + b] = hxu[e];
-#pragma unroll
-    for (int e = 0; e < m * m; ++e) A.luu[((size_t)k * m * m + e) * Bp + b] = huu[e];
-#pragma unroll
-    for (int e = 0; e < m; ++e) A.lu[((size_t)k * m + e) * Bp + b] = gu[e];
-    T Jc[n * nm];
-    rk4_jacobian<T, M>(x, u, T(pd->hstep), Jc);
-#pragma unroll
-    for (int e = 0; e < n * nm; ++e) A.AB[((size_t)k * n * nm + e) * Bp + b] = Jc[e];
-  }
+  T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
+                                     E + R::oLuu);
+  A.costs[(unsigned)k * Bp + (unsigned)b] = J;
+  if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
+  store_rec<T, R::EP>(RECP(A.EXP, k, R::EP), E);
 }
 
 // -------------------------------------------------------------------------------------------------
-// iLQR::BackwardPass (ilqr.hpp:385-445), one lane per instance
+// iLQR::BackwardPass (ilqr.hpp:385-445), one lane per instance, k uniform across the wavefront.
+//
+// The reference restarts the whole sweep when a Cholesky factorisation fails (after raising the
+// regularisation).  Here a lane whose factorisation failed simply sits out the rest of the current
+// sweep and the wave runs another sweep for the lanes that need one: per instance the sequence of
+// operations (and of dV accumulations, quirk Q4) is exactly the reference's, and because k is a
+// scalar every record address is `scalar base + lane offset + immediate`.
 // -------------------------------------------------------------------------------------------------
-template <class T, int n, int m>
-struct KnotExp {
-  T AB[n * (n + m)], lxx[n * n], lxu[n * m], luu[m * m], lx[n], lu[m];
-};
-template <class T, int n, int m>
-ALTRO_DEV void load_knot_exp(const DevArrays<T>& A, int k, int b, KnotExp<T, n, m>& E) {
-  const size_t Bp = A.Bp;
-#pragma unroll
-  for (int e = 0; e < n * (n + m); ++e) E.AB[e] = A.AB[((size_t)k * n * (n + m) + e) * Bp + b];
-#pragma unroll
-  for (int e = 0; e < n * n; ++e) E.lxx[e] = A.lxx[((size_t)k * n * n + e) * Bp + b];
-#pragma unroll
-  for (int e = 0; e < n * m; ++e) E.lxu[e] = A.lxu[((size_t)k * n * m + e) * Bp + b];
-#pragma unroll
-  for (int e = 0; e < m * m; ++e) E.luu[e] = A.luu[((size_t)k * m * m + e) * Bp + b];
-#pragma unroll
-  for (int e = 0; e < n; ++e) E.lx[e] = A.lx[((size_t)k * n + e) * Bp + b];
-#pragma unroll
-  for (int e = 0; e < m; ++e) E.lu[e] = A.lu[((size_t)k * m + e) * Bp + b];
-}
-
 template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, int all) {
   constexpr int n = M::n, m = M::m;
-  constexpr bool kPrefetch = (n * (n + m) + n * n + n * m + m * m + n + m) <= 64;
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= A.B) return;
-  if (!all && A.phase[b] != 1) return;
+  using R = Rec<T, n, m>;
+  const int b0 = blockIdx.x * kBlock + threadIdx.x;
+  const bool lane_on = (b0 < A.B) && (all || A.phase[b0] == 1);
+  if (__ballot(lane_on) == 0ull) return;
+  const int b = lane_on ? b0 : 0;
   const int N = A.N;
-  const size_t Bp = A.Bp;
+  const unsigned Bp = A.Bp;
   // J0 = costs_.sum() of the expansion step (ilqr.hpp:516); it is also the inner solve's
   // initial_cost on its first iteration (ilqr.hpp:298: same trajectory, same duals/penalties).
   T J0 = T(0);
-  for (int k = 0; k <= N; ++k) J0 += A.costs[(size_t)k * Bp + b];
-  A.J0[b] = J0;
-  if (A.need_init_cost[b]) {
-    A.initial_cost[b] = J0;
-    A.need_init_cost[b] = 0;
-  }
-  // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138)
-  T P[n * n], p[n];
-  auto load_terminal = [&]() {
-#pragma unroll
-    for (int e = 0; e < n * n; ++e) P[e] = A.lxx[((size_t)N * n * n + e) * Bp + b];
-#pragma unroll
-    for (int e = 0; e < n; ++e) p[e] = A.lx[((size_t)N * n + e) * Bp + b];
-  };
-  load_terminal();
-  if (A.record_ctg) {
-#pragma unroll
-    for (int e = 0; e < n * n; ++e) A.P[((size_t)N * n * n + e) * Bp + b] = P[e];
-#pragma unroll
-    for (int e = 0; e < n; ++e) A.p[((size_t)N * n + e) * Bp + b] = p[e];
-  }
+#pragma unroll 8
+  for (int k = 0; k <= N; ++k) J0 += A.costs[(unsigned)k * Bp + (unsigned)b];
   T rho = A.rho_reg[b], drho = A.drho[b];
   T dV0 = T(0), dV1 = T(0);  // zeroed once, NOT per retry (quirk Q4)
   int max_reg_count = 0;
   int status = A.status[b];
-  int k = N - 1;
-  bool done = (N <= 0);
-  KnotExp<T, n, m> E, En;
-  if (!done) load_knot_exp<T, n, m>(A, k, b, E);
-  while (!done) {
-    const int kn = k > 0 ? k - 1 : 0;
-    if (kPrefetch) load_knot_exp<T, n, m>(A, kn, b, En);
-    T K[m * n], d[m];
-    const bool ok = riccati_knot<T, n, m>(E.AB, E.lxx, E.lxu, E.luu, E.lx, E.lu, rho, P, p, K, d, &dV0, &dV1);
-    if (!ok) {
-      // ilqr.hpp:409-427: raise the regularisation, reset the cost-to-go, restart the sweep
-      increase_reg(o, &rho, &drho);
-      load_terminal();
-      if (rho >= T(o.bp_reg_max)) max_reg_count++;
-      if (max_reg_count >= o.bp_reg_fail_threshold) {
-        status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
-        done = true;
-      } else {
-        k = N - 1;
-        load_knot_exp<T, n, m>(A, k, b, E);
-      }
-    } else {
+  bool need = lane_on && N > 0;  // this lane still has to complete a sweep
+  T P[n * n], p[n];
+  T E[R::EP];
+  while (__ballot(need) != 0ull) {
+    // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138)
+    load_rec<T, R::EP>(RECP(A.EXP, N, R::EP), E);
 #pragma unroll
-      for (int e = 0; e < m * n; ++e) A.K[((size_t)k * m * n + e) * Bp + b] = K[e];
+    for (int e = 0; e < n * n; ++e) P[e] = E[R::oLxx + e];
 #pragma unroll
-      for (int e = 0; e < m; ++e) A.d[((size_t)k * m + e) * Bp + b] = d[e];
-      if (A.record_ctg) {
+    for (int e = 0; e < n; ++e) p[e] = E[R::oLx + e];
+    if (A.record_ctg && need) {
+      T c[R::CP];
 #pragma unroll
-        for (int e = 0; e < n * n; ++e) A.P[((size_t)k * n * n + e) * Bp + b] = P[e];
+      for (int e = 0; e < R::CP; ++e) c[e] = T(0);
 #pragma unroll
-        for (int e = 0; e < n; ++e) A.p[((size_t)k * n + e) * Bp + b] = p[e];
-      }
-      if (k == 0) {
-        done = true;
-      } else {
-        k = kn;
-        if (kPrefetch)
-          E = En;
-        else
-          load_knot_exp<T, n, m>(A, k, b, E);
+      for (int e = 0; e < n * n; ++e) c[R::oP + e] = P[e];
+#pragma unroll
+      for (int e = 0; e < n; ++e) c[R::op + e] = p[e];
+      store_rec<T, R::CP>(RECP(A.CTG, N, R::CP), c);
+    }
+    bool running = need;
+    load_rec<T, R::EP>(RECP(A.EXP, N - 1, R::EP), E);
+    for (int k = N - 1; k >= 0; --k) {
+      // Q-function assembly consumes the expansion registers ...
+      QExp<T, n, m> Q;
+      riccati_q<T, n, m>(E + R::oAB, E + R::oLxx, E + R::oLxu, E + R::oLuu, E + R::oLx, E + R::oLu, P, p, Q);
+      // ... which are immediately refilled with the next knot's record: the loads fly while the
+      // Cholesky / gains / cost-to-go half of this knot executes (no second register buffer)
+      if (k > 0) load_rec<T, R::EP>(RECP(A.EXP, k - 1, R::EP), E);
+      if (running) {
+        T KD[R::KP];
+#pragma unroll
+        for (int e = 0; e < R::KP; ++e) KD[e] = T(0);
+        const bool ok = riccati_gains<T, n, m>(Q, rho, P, p, KD + R::oK, KD + R::oD, &dV0, &dV1);
+        if (!ok) {
+          // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
+          increase_reg(o, &rho, &drho);
+          if (rho >= T(o.bp_reg_max)) max_reg_count++;
+          if (max_reg_count >= o.bp_reg_fail_threshold) {
+            status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
+            need = false;
+          }
+          running = false;
+        } else {
+          store_rec<T, R::KP>(RECP(A.KD, k, R::KP), KD);
+          if (A.record_ctg) {
+            T c[R::CP];
+#pragma unroll
+            for (int e = 0; e < R::CP; ++e) c[e] = T(0);
+#pragma unroll
+            for (int e = 0; e < n * n; ++e) c[R::oP + e] = P[e];
+#pragma unroll
+            for (int e = 0; e < n; ++e) c[R::op + e] = p[e];
+            store_rec<T, R::CP>(RECP(A.CTG, k, R::CP), c);
+          }
+          if (k == 0) need = false;  // sweep completed
+        }
       }
     }
+  }
+  if (!lane_on) return;
+  A.J0[b] = J0;
+  if (A.need_init_cost[b]) {
+    A.initial_cost[b] = J0;
+    A.need_init_cost[b] = 0;
   }
   A.reg_log[b] = rho;  // stats_.Log("reg", rho_)
   decrease_reg(o, &rho, &drho);
@@ -215,26 +196,24 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
 // iLQR::Rollout (ilqr.hpp:453-459), one lane per instance
 // -------------------------------------------------------------------------------------------------
 template <class T, class M>
-__global__ __launch_bounds__(kBlock) void k_rollout(DevArrays<T> A, int all) {
+__global__ __launch_bounds__(kBlock) void k_rollout(DevArrays<T> A, const ProblemDesc* __restrict__ pd, int all) {
   constexpr int n = M::n, m = M::m;
+  using R = Rec<T, n, m>;
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
   if (!all && A.phase[b] != 1) return;
-  const size_t Bp = A.Bp;
-  T x[n], u[m], xn[n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = A.x0[(size_t)i * Bp + b];
+  const unsigned Bp = A.Bp;
+  const T hh = T(pd->hstep);
+  T x[R::nP], u[R::mP], xn[n];
+  load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x);
   for (int k = 0; k < A.N; ++k) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) A.X[((size_t)k * n + i) * Bp + b] = x[i];
-#pragma unroll
-    for (int i = 0; i < m; ++i) u[i] = A.U[((size_t)k * m + i) * Bp + b];
-    rk4_step<T, M>(x, u, T(A.hstep[k]), xn);
+    store_rec<T, R::nP>(RECP(A.X, k, R::nP), x);
+    load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
+    rk4_step<T, M>(x, u, hh, xn);
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = xn[i];
   }
-#pragma unroll
-  for (int i = 0; i < n; ++i) A.X[((size_t)A.N * n + i) * Bp + b] = x[i];
+  store_rec<T, R::nP>(RECP(A.X, A.N, R::nP), x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -244,27 +223,28 @@ __global__ __launch_bounds__(kBlock) void k_rollout(DevArrays<T> A, int all) {
 template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_knot_costs(DevArrays<T> A, const ProblemDesc* __restrict__ pd) {
   constexpr int n = M::n, m = M::m;
+  using R = Rec<T, n, m>;
   const int b = blockIdx.x * kBlock + threadIdx.x;
   const int k = blockIdx.y;
   if (b >= A.B) return;
-  const size_t Bp = A.Bp;
-  T x[n], u[m];
+  const unsigned Bp = A.Bp;
+  T x[R::nP], u[R::mP];
+  load_rec<T, R::nP>(RECP(A.X, k, R::nP), x);
 #pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = A.X[((size_t)k * n + i) * Bp + b];
-#pragma unroll
-  for (int i = 0; i < m; ++i) u[i] = (k < A.N) ? A.U[((size_t)k * m + i) * Bp + b] : T(0);
+  for (int i = 0; i < R::mP; ++i) u[i] = T(0);
+  if (k < A.N) load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
   CtxG<T> C(A, b);
   T v;
   int rb;
   const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-  A.costs[(size_t)k * Bp + b] = knot_cost<T, n, m, true>(C, pd, kc, rb, x, u, &v);
+  A.costs[(unsigned)k * Bp + (unsigned)b] = knot_cost<T, n, m, true>(C, pd, kc, rb, x, u, &v);
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_sum_costs(DevArrays<T> A, T* out) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
   T J = T(0);
-  for (int k = 0; k <= A.N; ++k) J += A.costs[(size_t)k * A.Bp + b];
+  for (int k = 0; k <= A.N; ++k) J += A.costs[(unsigned)k * (unsigned)A.Bp + (unsigned)b];
   out[b] = J;
 }
 
@@ -475,17 +455,19 @@ ALTRO_DEV bool al_outer_decide(const DevArrays<T>& A, const DevOpts& o, int b, T
 // step-level iLQR::UpdateConvergenceStatistics
 template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const ProblemDesc* __restrict__ pd, DevOpts o) {
-  constexpr int m = M::m;
+  constexpr int n = M::n, m = M::m;
+  using R = Rec<T, n, m>;
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
+  const unsigned Bp = A.Bp;
   T gsum = T(0);
   for (int k = 0; k < A.N; ++k) {
+    T u[R::mP], kd[R::KP];
+    load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
+    load_rec<T, R::KP>(RECP(A.KD, k, R::KP), kd);
     T mx = T(0);
 #pragma unroll
-    for (int i = 0; i < m; ++i) {
-      const size_t idx = ((size_t)k * m + i) * A.Bp + b;
-      mx = max_(mx, abs_(A.d[idx]) / (abs_(A.U[idx]) + T(1)));
-    }
+    for (int i = 0; i < m; ++i) mx = max_(mx, abs_(kd[R::oD + i]) / (abs_(u[i]) + T(1)));
     gsum += mx;
   }
   T v, p;
@@ -495,27 +477,13 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
   A.status[b] = st;  // the status change belongs to IsDone, which the step-level API does not call
 }
 
-// -------------------------------------------------------------------------------------------------
-// iLQR::ForwardPass (ilqr.hpp:512-558) with speculative parallel line search, + state machine
-//
-// Lane layout: lane = grp*20 + t, grp = instance slot in the wave (up to 3 per wave), t = trial.
-// Phase 0 (LDS variant): the 20 lanes of an instance stage everything the serial rollout reads --
-//   X, U (Z_), K, d (gains), lambda, rho -- from HBM into LDS once, so the N dependent rollout
-//   steps contain no global load at all (the only VMEM traffic in the loop is the candidate stores,
-//   which nothing waits on).  Reads are wave-broadcasts: all 20 trials read the same LDS address.
-// Phase 1 (all lanes): closed-loop rollout + cost with alpha_t; every trial stores its candidate
-//   trajectory (Zbar_) to the `trial` scratch so the winner never has to be re-integrated.
-// Phase 2 (all lanes of the instance, knots strided over the 20 lanes): copy the winning candidate
-//   into Z_ and evaluate the constraint values it leaves behind (c_, quirk Q6).
-// Phase 3 (one lane per instance): statistics, IsDone, AL outer-loop transition.
-// -------------------------------------------------------------------------------------------------
 // One run of knots of the closed-loop rollout + cost of ONE line-search trial (one lane):
 // iLQR::RolloutClosedLoop + ALCost::Evaluate per knot (ilqr.hpp:468-499, al_cost.hpp:264-274).
 // FK picks a compile-time constraint layout (FastKind); kFastGeneric is the table-driven fallback.
 // Values and operation order are identical across the variants.
 template <class T, class M, class Ctx, bool LDS, int FK>
 ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run, int kend,
-                           const T* sX, const T* sU, const T* sK, const T* sd, T alpha, T hh, bool valid,
+                           const T* sX, const T* sU, const T* sKD, T alpha, T hh, bool valid,
                            unsigned tb, unsigned Bp, int b, bool check_bounds, T state_max2, T control_max2,
                            T* xb, T& J, T& gs, bool& ok, int& st) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -538,26 +506,19 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
   if (kHasB) b_row = kc.con[kBi].row_off;
   const int nrows = kc.nrows;
   for (int k = run.k_begin; k < kend; ++k) {
-    T xk[n], uk[m], K[m * n], d[m], ub[m], xn[n];
+    using R = Rec<T, n, m>;
+    T xk[R::nP], uk[R::mP], kd[R::KP], ub[m], xn[n];
     if (LDS) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) xk[i] = sX[k * n + i];
-#pragma unroll
-      for (int i = 0; i < m; ++i) uk[i] = sU[k * m + i];
-#pragma unroll
-      for (int e = 0; e < m * n; ++e) K[e] = sK[k * m * n + e];
-#pragma unroll
-      for (int i = 0; i < m; ++i) d[i] = sd[k * m + i];
+      load_rec<T, R::nP>(sX + k * R::nP, xk);
+      load_rec<T, R::mP>(sU + k * R::mP, uk);
+      load_rec<T, R::KP>(sKD + k * R::KP, kd);
     } else {
-#pragma unroll
-      for (int i = 0; i < n; ++i) xk[i] = SOA(A.X, k * n + i);
-#pragma unroll
-      for (int i = 0; i < m; ++i) uk[i] = SOA(A.U, k * m + i);
-#pragma unroll
-      for (int e = 0; e < m * n; ++e) K[e] = SOA(A.K, k * m * n + e);
-#pragma unroll
-      for (int i = 0; i < m; ++i) d[i] = SOA(A.d, k * m + i);
+      load_rec<T, R::nP>(RECP(A.X, k, R::nP), xk);
+      load_rec<T, R::mP>(RECP(A.U, k, R::mP), uk);
+      load_rec<T, R::KP>(RECP(A.KD, k, R::KP), kd);
     }
+    const T* K = kd + R::oK;
+    const T* d = kd + R::oD;
     const int rb = run.rowbase + (k - run.k_begin) * nrows;
     // duals / penalty of the bound rows: loaded up front so that one wait covers the whole knot
     T blam[2 * m], brho = T(1);
@@ -675,9 +636,11 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
 }
 
 template <class T>
-struct FwdLds {  // element counts of one instance's staged block (after the wave-shared pool copy)
-  int nX, nU, nK, nd, nR, nS;
-  ALTRO_DEV int total() const { return nX + nU + nK + nd + 2 * nR + nS; }
+struct FwdLds {  // element counts of one instance's staged block (16-byte aligned sub-blocks)
+  int nX, nU, nKD, nR, nS, V;
+  ALTRO_DEV int padv(int e) const { return (e + V - 1) / V * V; }
+  ALTRO_DEV int rowsP() const { return padv(nR); }
+  ALTRO_DEV int total() const { return nX + nU + nKD + 2 * padv(nR) + padv(nS); }
 };
 
 template <class T, class M, bool LDS>
@@ -702,22 +665,44 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   const int b = valid ? b0 : 0;         // idle lanes shadow instance 0's loads but never store
 
   // ---- phase 0: stage the shared pool and the instance's read-only inputs in LDS ----------------
-  const FwdLds<T> L{(N + 1) * n, N * m, N * m * n, N * m, pd->total_rows, pd->nslots};
-  T* sPool = reinterpret_cast<T*>(smem_raw);
-  T* sm = sPool + pd->npool + (grp < per_wave ? grp : 0) * L.total();
+  using R = Rec<T, n, m>;
+  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, Rec<T, n, m>::V};
+  T* sm = reinterpret_cast<T*>(smem_raw) + (grp < per_wave ? grp : 0) * L.total();
   T* sX = sm;
   T* sU = sX + L.nX;
-  T* sK = sU + L.nU;
-  T* sd = sK + L.nK;
-  T* sLam = sd + L.nd;
-  T* sPen = sLam + L.nR;
-  T* sIp = sPen + L.nR;
+  T* sKD = sU + L.nU;
+  T* sLam = sKD + L.nKD;
+  T* sPen = sLam + L.rowsP();
+  T* sIp = sPen + L.rowsP();
+  T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   if (LDS) {
     for (int i = lane; i < pd->npool; i += kBlock) sPool[i] = A.pool[i];
     if (valid) {
-      // 16 loads in flight per lane before the first LDS write: the copy costs a handful of memory
-      // round trips instead of one per element
-      auto stage = [&](T* dst, const T* src, int cnt) {
+      using V = typename VecOf<T>::type;
+      constexpr int VN = R::V;
+      // records: 16-byte vector copies, 8 in flight per lane before the first LDS write
+      auto stage_rec = [&](T* dst, const T* src, int knots, int EP) {
+        const int per = EP / VN;
+        const int total = knots * per;
+        constexpr int kDepth = 8;
+        for (int i0 = t; i0 < total; i0 += LS * kDepth) {
+          V v[kDepth];
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            int vi = i0 + j * LS;
+            vi = vi < total ? vi : total - 1;  // clamp: the load is unconditional, the store is not
+            const int k = vi / per, w = vi - k * per;
+            v[j] = *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
+          }
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int vi = i0 + j * LS;
+            if (vi < total) *reinterpret_cast<V*>(dst + vi * VN) = v[j];
+          }
+        }
+      };
+      // rows / parameter slots: [row][b] scalars, 16 in flight per lane
+      auto stage_soa = [&](T* dst, const T* src, int cnt) {
         constexpr int kDepth = 16;
         for (int i0 = t; i0 < cnt; i0 += LS * kDepth) {
           T v[kDepth];
@@ -733,13 +718,12 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
           }
         }
       };
-      stage(sX, A.X, L.nX);
-      stage(sU, A.U, L.nU);
-      stage(sK, A.K, L.nK);
-      stage(sd, A.d, L.nd);
-      stage(sLam, A.lam, L.nR);
-      stage(sPen, A.pen, L.nR);
-      stage(sIp, A.ipool, L.nS);
+      stage_rec(sX, A.X, N + 1, R::nP);
+      stage_rec(sU, A.U, N, R::mP);
+      stage_rec(sKD, A.KD, N, R::KP);
+      stage_soa(sLam, A.lam, L.nR);
+      stage_soa(sPen, A.pen, L.nR);
+      stage_soa(sIp, A.ipool, L.nS);
     }
     __syncthreads();
   }
@@ -754,9 +738,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 
   const T J0 = A.J0[b];
   const T dV0 = A.dV0[b], dV1 = A.dV1[b];
-  T x0[n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x0[i] = SOA(A.x0, i);
+  T x0[R::nP];
+  load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
   const T state_max2 = T(o.state_max) * T(o.state_max);
   const T control_max2 = T(o.control_max) * T(o.control_max);
 
@@ -786,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
       const KnotRun run = pd->runs[r];
       const int kend = run.k_end < N ? run.k_end : N;
 #define ALTRO_RUN(FK)                                                                                     \
-  rollout_run<T, M, Ctx, LDS, FK>(C, pd, A, run, kend, sX, sU, sK, sd, alpha, hh, valid, tb, Bp, b,       \
+  rollout_run<T, M, Ctx, LDS, FK>(C, pd, A, run, kend, sX, sU, sKD, alpha, hh, valid, tb, Bp, b,          \
                                   o.check_forwardpass_bounds != 0, state_max2, control_max2, xb, J, gs, ok, st)
       switch (run.fast) {
         case kFastNone: ALTRO_RUN(kFastNone); break;
@@ -869,12 +852,13 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
       knot_cost<T, n, m, true>(C, pd, kc, rb, xs, us, &v);
       viol = max_(viol, v);
       if (accepted) {
+        T xr[R::nP], ur[R::mP];
 #pragma unroll
-        for (int i = 0; i < n; ++i) SOA(A.X, k * n + i) = xs[i];
-        if (k < N) {
+        for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[i < n ? i : 0] : T(0);
 #pragma unroll
-          for (int i = 0; i < m; ++i) SOA(A.U, k * m + i) = us[i];
-        }
+        for (int i = 0; i < R::mP; ++i) ur[i] = i < m ? us[i < m ? i : 0] : T(0);
+        store_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
+        if (k < N) store_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
       }
     }
   }
@@ -924,8 +908,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
           T mx = T(0);
 #pragma unroll
           for (int i = 0; i < m; ++i) {
-            const T dv = LDS ? sd[k * m + i] : SOA(A.d, k * m + i);
-            const T uv = LDS ? sU[k * m + i] : SOA(A.U, k * m + i);
+            const T dv = LDS ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
+            const T uv = LDS ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
             mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
           }
           gsum += mx;
