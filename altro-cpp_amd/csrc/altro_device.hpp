@@ -96,12 +96,14 @@ struct DevArrays {
   const T *pool, *ipool;
   const int *knot_class, *knot_rowbase;
   const double* phi;  // penalty scaling per (class, constraint): phi[cls*kMaxConPerKnot + c]
-  // per-instance solver state [field][b]
-  T *rho_reg, *drho, *dV0, *dV1, *J0, *initial_cost, *cost_cur, *cost_prev, *dJ, *grad, *viol,
+  // per-instance solver state [field][b].  ALWAYS fp64, also when T = float: costs, expected
+  // decrease, regularisation and the convergence statistics are differences of nearly equal
+  // numbers (dJ < 1e-4 on J ~ 1e2; z = (J0 - J) / expected) that fp32 cannot resolve.
+  double *rho_reg, *drho, *dV0, *dV1, *J0, *initial_cost, *cost_cur, *cost_prev, *dJ, *grad, *viol,
       *penmax, *alpha, *z, *reg_log;
   int *status, *status_al, *it_inner, *it_outer, *it_total, *phase, *need_init_cost;
   // optional per-iteration history [field][cap][Bp]
-  T* hist;
+  double* hist;
   int* hist_len;
   int hist_cap;
   int record_ctg;
@@ -920,7 +922,7 @@ ALTRO_DEV void riccati_q(const T* AB, const T* lxx, const T* lxu, const T* luu, 
 // factorisation of Quu + rho I hits a non-positive pivot (Eigen::NumericalIssue).
 // Gains come from the REGULARISED Q, cost-to-go from the UN-regularised Q (quirk Q3).
 template <class T, int n, int m>
-ALTRO_DEV bool riccati_gains(const QExp<T, n, m>& Q, T rho, T* P, T* p, T* K, T* d, T* dV0, T* dV1) {
+ALTRO_DEV bool riccati_gains(const QExp<T, n, m>& Q, T rho, T* P, T* p, T* K, T* d, double* dV0, double* dV1) {
   const T* Qxx = Q.Qxx;
   const T* Qxu = Q.Qxu;
   const T* Quu = Q.Quu;
@@ -1025,24 +1027,22 @@ ALTRO_DEV bool riccati_gains(const QExp<T, n, m>& Q, T rho, T* P, T* p, T* K, T*
     for (int l = 0; l < m; ++l) s += Quu[i + l * m] * d[l];
     v1 += d[i] * s;
   }
-  *dV0 += v0;
-  *dV1 += T(0.5) * v1;
+  *dV0 += (double)v0;
+  *dV1 += (double)(T(0.5) * v1);
   return true;
 }
 
 
 // iLQR::IncreaseRegularization / DecreaseRegularization (altro/ilqr/ilqr.hpp:770-786)
-template <class T>
-ALTRO_DEV void increase_reg(const DevOpts& o, T* rho, T* drho) {
-  *drho = max_(*drho * T(o.bp_reg_increase_factor), T(o.bp_reg_increase_factor));
-  *rho = max_(*rho * *drho, T(o.bp_reg_min));
-  *rho = min_(*rho, T(o.bp_reg_max));
+ALTRO_DEV void increase_reg(const DevOpts& o, double* rho, double* drho) {
+  *drho = max_(*drho * o.bp_reg_increase_factor, o.bp_reg_increase_factor);
+  *rho = max_(*rho * *drho, o.bp_reg_min);
+  *rho = min_(*rho, o.bp_reg_max);
 }
-template <class T>
-ALTRO_DEV void decrease_reg(const DevOpts& o, T* rho, T* drho) {
-  *drho = min_(*drho / T(o.bp_reg_increase_factor), T(1) / T(o.bp_reg_increase_factor));
-  *rho = max_(*rho * *drho, T(o.bp_reg_min));
-  *rho = min_(*rho, T(o.bp_reg_max));
+ALTRO_DEV void decrease_reg(const DevOpts& o, double* rho, double* drho) {
+  *drho = min_(*drho / o.bp_reg_increase_factor, 1.0 / o.bp_reg_increase_factor);
+  *rho = max_(*rho * *drho, o.bp_reg_min);
+  *rho = min_(*rho, o.bp_reg_max);
 }
 
 }  // namespace altro_hip

@@ -178,14 +178,14 @@ class Engine final : public EngineBase {
   }
   altro_status GetMaxViolation(double* out) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d_tmp_, (T*)nullptr);
+    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d_tmp_, (double*)nullptr);
     altro_status st = Sync();
     if (st != ALTRO_OK) return st;
     return DownloadVec(d_tmp_, out);
   }
   altro_status GetMaxPenalty(double* out) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, (T*)nullptr, d_tmp_);
+    hipLaunchKernelGGL(k_max_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, (double*)nullptr, d_tmp_);
     altro_status st = Sync();
     if (st != ALTRO_OK) return st;
     return DownloadVec(d_tmp_, out);
@@ -272,11 +272,11 @@ class Engine final : public EngineBase {
   }
   altro_status GetStats(altro_stats* st, bool ilqr_mode) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    std::vector<T> f((size_t)kNumScalarT * Bp_);
+    std::vector<double> f((size_t)kNumScalarT * Bp_);
     std::vector<int> iv((size_t)kNumScalarI * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(f.data(), d_scalarT_, f.size() * sizeof(T), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(hipMemcpy(f.data(), d_scalarT_, f.size() * sizeof(double), hipMemcpyDeviceToHost));
     ALTRO_HIP_CHECK(hipMemcpy(iv.data(), d_scalarI_, iv.size() * sizeof(int), hipMemcpyDeviceToHost));
-    auto F = [&](T* p, int b) { return (double)f[(size_t)(p - d_scalarT_) + b]; };
+    auto F = [&](double* p, int b) { return f[(size_t)(p - d_scalarT_) + b]; };
     auto I = [&](int* p, int b) { return iv[(size_t)(p - d_scalarI_) + b]; };
     for (int b = 0; b < B_; ++b) {
       altro_stats& s = st[b];
@@ -312,7 +312,7 @@ class Engine final : public EngineBase {
     }
     A_.hist_cap = 0;
     if (capacity > 0) {
-      ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist, (size_t)kHistFields * capacity * Bp_ * sizeof(T)));
+      ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist, (size_t)kHistFields * capacity * Bp_ * sizeof(double)));
       ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist_len, (size_t)Bp_ * sizeof(int)));
       ALTRO_HIP_CHECK(hipMemset(A_.hist_len, 0, (size_t)Bp_ * sizeof(int)));
       A_.hist_cap = capacity;
@@ -327,12 +327,12 @@ class Engine final : public EngineBase {
     // the reference's vectors also hold the row opened by the last NewIteration: a copy of the last
     int stored = std::min(len, A_.hist_cap);
     int cnt = 0;
-    T v = T(0);
+    double v = 0.0;
     for (int i = 0; i < stored && cnt < cap; ++i) {
-      if (hipMemcpy(&v, A_.hist + ((size_t)field * A_.hist_cap + i) * Bp_ + instance, sizeof(T),
+      if (hipMemcpy(&v, A_.hist + ((size_t)field * A_.hist_cap + i) * Bp_ + instance, sizeof(double),
                     hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
-      out[cnt++] = (double)v;
+      out[cnt++] = v;
     }
     return cnt;
   }
@@ -383,10 +383,8 @@ class Engine final : public EngineBase {
     for (auto& e : prof_ev_) hipEventDestroy(e);
     if (stream_) hipStreamDestroy(stream_);
   }
-  altro_status DownloadVec(const T* dev, double* out) {
-    std::vector<T> h(Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, (size_t)Bp_ * sizeof(T), hipMemcpyDeviceToHost));
-    for (int b = 0; b < B_; ++b) out[b] = (double)h[b];
+  altro_status DownloadVec(const double* dev, double* out) {
+    ALTRO_HIP_CHECK(hipMemcpy(out, dev, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   }
   // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]
@@ -757,7 +755,7 @@ class Engine final : public EngineBase {
     // per-instance scalar state, one slab each so GetStats is two copies
     ALTRO_ALLOC(d_scalarT_, (size_t)kNumScalarT * bp);
     ALTRO_ALLOC(d_scalarI_, (size_t)kNumScalarI * bp);
-    T** tp[kNumScalarT] = {&A_.rho_reg, &A_.drho,     &A_.dV0,  &A_.dV1,  &A_.J0,
+    double** tp[kNumScalarT] = {&A_.rho_reg, &A_.drho,     &A_.dV0,  &A_.dV1,  &A_.J0,
                            &A_.initial_cost, &A_.cost_cur, &A_.cost_prev, &A_.dJ, &A_.grad,
                            &A_.viol,    &A_.penmax,   &A_.alpha, &A_.z,   &A_.reg_log};
     for (int i = 0; i < kNumScalarT; ++i) *tp[i] = d_scalarT_ + (size_t)i * bp;
@@ -900,11 +898,11 @@ class Engine final : public EngineBase {
   ProblemDesc pd_{};
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};
-  T* d_tmp_ = nullptr;
+  double* d_tmp_ = nullptr;
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0;
   T *X_init_ = nullptr, *U_init_ = nullptr;
-  T* d_scalarT_ = nullptr;
+  double* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;
   double* d_phi_ = nullptr;
   std::vector<int> knot_class_, knot_rowbase_;

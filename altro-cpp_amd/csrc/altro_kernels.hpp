@@ -48,8 +48,8 @@ ALTRO_DEV void hist_push(const DevArrays<T>& A, int b) {
   if (!A.hist) return;
   int len = A.hist_len[b];
   if (len < A.hist_cap) {
-    const T vals[kHistFields] = {A.cost_cur[b], A.alpha[b], A.z[b],    A.grad[b],
-                                 A.dJ[b],       A.reg_log[b], A.viol[b], A.penmax[b]};
+    const double vals[kHistFields] = {A.cost_cur[b], A.alpha[b], A.z[b],    A.grad[b],
+                                      A.dJ[b],       A.reg_log[b], A.viol[b], A.penmax[b]};
 #pragma unroll
     for (int f = 0; f < kHistFields; ++f)
       A.hist[((size_t)f * A.hist_cap + len) * A.Bp + b] = vals[f];
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
   const unsigned Bp = A.Bp;
   // J0 = costs_.sum() of the expansion step (ilqr.hpp:516); it is also the inner solve's
   // initial_cost on its first iteration (ilqr.hpp:298: same trajectory, same duals/penalties).
-  T J0 = T(0);
+  double J0 = 0.0;
 #pragma unroll 8
-  for (int k = 0; k <= N; ++k) J0 += A.costs[(unsigned)k * Bp + (unsigned)b];
-  T rho = A.rho_reg[b], drho = A.drho[b];
-  T dV0 = T(0), dV1 = T(0);  // zeroed once, NOT per retry (quirk Q4)
+  for (int k = 0; k <= N; ++k) J0 += (double)A.costs[(unsigned)k * Bp + (unsigned)b];
+  double rho = A.rho_reg[b], drho = A.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
   int max_reg_count = 0;
   int status = A.status[b];
   bool need = lane_on && N > 0;  // this lane still has to complete a sweep
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
         T KD[R::KP];
 #pragma unroll
         for (int e = 0; e < R::KP; ++e) KD[e] = T(0);
-        const bool ok = riccati_gains<T, n, m>(Q, rho, P, p, KD + R::oK, KD + R::oD, &dV0, &dV1);
+        const bool ok = riccati_gains<T, n, m>(Q, T(rho), P, p, KD + R::oK, KD + R::oD, &dV0, &dV1);
         if (!ok) {
           // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
           increase_reg(o, &rho, &drho);
-          if (rho >= T(o.bp_reg_max)) max_reg_count++;
+          if (rho >= o.bp_reg_max) max_reg_count++;
           if (max_reg_count >= o.bp_reg_fail_threshold) {
             status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
             need = false;
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(kBlock) void k_knot_costs(DevArrays<T> A, const Pro
   A.costs[(unsigned)k * Bp + (unsigned)b] = knot_cost<T, n, m, true>(C, pd, kc, rb, x, u, &v);
 }
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_sum_costs(DevArrays<T> A, T* out) {
+__global__ __launch_bounds__(kBlock) void k_sum_costs(DevArrays<T> A, double* out) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
-  T J = T(0);
-  for (int k = 0; k <= A.N; ++k) J += A.costs[(unsigned)k * (unsigned)A.Bp + (unsigned)b];
+  double J = 0.0;
+  for (int k = 0; k <= A.N; ++k) J += (double)A.costs[(unsigned)k * (unsigned)A.Bp + (unsigned)b];
   out[b] = J;
 }
 
@@ -319,10 +319,10 @@ template <class T>
 ALTRO_DEV void begin_inner_solve(const DevArrays<T>& A, const DevOpts& o, int b) {
   A.it_inner[b] = 0;
   A.status[b] = ALTRO_UNSOLVED;
-  A.rho_reg[b] = T(o.bp_reg_initial);
-  A.drho[b] = T(0);
-  A.dV0[b] = T(0);
-  A.dV1[b] = T(0);
+  A.rho_reg[b] = o.bp_reg_initial;
+  A.drho[b] = 0.0;
+  A.dV0[b] = 0.0;
+  A.dV1[b] = 0.0;
   A.need_init_cost[b] = 1;  // stats_.initial_cost = Cost() is taken from the next expansion step
 }
 
@@ -334,10 +334,18 @@ __global__ __launch_bounds__(kBlock) void k_al_init(DevArrays<T> A, const Proble
   if (b >= A.B) return;
   rows_set(A, pd, b, o.reset_duals != 0, o.initial_penalty > 0, T(o.initial_penalty));  // quirk Q8
   // stats.Reset()
-  A.initial_cost[b] = T(0);
+  A.initial_cost[b] = 0.0;
   A.it_inner[b] = A.it_outer[b] = A.it_total[b] = 0;
-  A.cost_cur[b] = A.cost_prev[b] = A.dJ[b] = A.grad[b] = A.viol[b] = A.penmax[b] = T(0);
-  A.alpha[b] = A.z[b] = A.reg_log[b] = T(0);
+  A.cost_cur[b] = A.cost_prev[b] = A.dJ[b] = A.grad[b] = A.viol[b] = 0.0;
+  A.alpha[b] = A.z[b] = A.reg_log[b] = 0.0;
+  // stats.Log("pen", GetMaxPenalty()) of Init (al_solver.hpp:301)
+  if (o.initial_penalty > 0) {
+    A.penmax[b] = o.initial_penalty;
+  } else {
+    T v, pm;
+    rows_viol_pen(A, pd, b, &v, &pm);
+    A.penmax[b] = (double)pm;
+  }
   if (A.hist) A.hist_len[b] = 0;
   A.status_al[b] = ALTRO_UNSOLVED;
 }
@@ -348,8 +356,8 @@ __global__ __launch_bounds__(kBlock) void k_log_viol_pen(DevArrays<T> A, const P
   if (b >= A.B) return;
   T v, p;
   rows_viol_pen(A, pd, b, &v, &p);
-  A.viol[b] = v;
-  A.penmax[b] = p;
+  A.viol[b] = (double)v;
+  A.penmax[b] = (double)p;
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_solve_setup(DevArrays<T> A, DevOpts o, int activate) {
@@ -380,23 +388,23 @@ __global__ __launch_bounds__(kBlock) void k_update_penalties(DevArrays<T> A, con
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_max_viol_pen(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
-                                                         T* viol, T* pen) {
+                                                         double* viol, double* pen) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
   T v, p;
   rows_viol_pen(A, pd, b, &v, &p);
-  if (viol) viol[b] = v;
-  if (pen) pen[b] = p;
+  if (viol) viol[b] = (double)v;
+  if (pen) pen[b] = (double)p;
 }
 
 // iLQR::UpdateConvergenceStatistics + IsDone (ilqr.hpp:568-619) for one instance.
 // gsum = sum_k max_i |d_k,i| / (|u_k,i| + 1) with the POST-forward-pass controls (quirk Q12).
 // Returns true when the inner solve is finished.
 template <class T>
-ALTRO_DEV bool conv_stats_and_done(const DevArrays<T>& A, const DevOpts& o, int b, T gsum, T viol) {
-  const T grad = A.N > 0 ? gsum / T(A.N) : T(0);
+ALTRO_DEV bool conv_stats_and_done(const DevArrays<T>& A, const DevOpts& o, int b, double gsum, double viol) {
+  const double grad = A.N > 0 ? gsum / (double)A.N : 0.0;
   const int it = A.it_inner[b];
-  const T dJ = (it == 0) ? A.initial_cost[b] - A.cost_cur[b] : A.cost_prev[b] - A.cost_cur[b];
+  const double dJ = (it == 0) ? A.initial_cost[b] - A.cost_cur[b] : A.cost_prev[b] - A.cost_cur[b];
   A.it_inner[b] = it + 1;
   const int itot = A.it_total[b] + 1;
   A.it_total[b] = itot;
@@ -407,7 +415,7 @@ ALTRO_DEV bool conv_stats_and_done(const DevArrays<T>& A, const DevOpts& o, int 
   A.cost_prev[b] = A.cost_cur[b];  // NewIteration copies the row (solver_stats.cpp:54-66)
   int status = A.status[b];
   bool done = false;
-  if (dJ < T(o.cost_tolerance) && grad < T(o.gradient_tolerance)) {
+  if (dJ < o.cost_tolerance && grad < o.gradient_tolerance) {
     status = ALTRO_SOLVED;
     done = true;
   } else if (it + 1 >= o.max_iterations_inner) {
@@ -428,7 +436,7 @@ ALTRO_DEV bool conv_stats_and_done(const DevArrays<T>& A, const DevOpts& o, int 
 // of the stored c_ and the max penalty.  Returns true if the instance keeps iterating (the caller
 // then applies UpdatePenalties and starts the next inner solve).
 template <class T>
-ALTRO_DEV bool al_outer_decide(const DevArrays<T>& A, const DevOpts& o, int b, T viol, T pen) {
+ALTRO_DEV bool al_outer_decide(const DevArrays<T>& A, const DevOpts& o, int b, double viol, double pen) {
   const int outer = A.it_outer[b] + 1;
   A.it_outer[b] = outer;
   A.viol[b] = viol;
@@ -437,9 +445,9 @@ ALTRO_DEV bool al_outer_decide(const DevArrays<T>& A, const DevOpts& o, int b, T
   int sal = -1;
   if (st != ALTRO_SOLVED)
     sal = st;
-  else if (viol < T(o.constraint_tolerance))
+  else if (viol < o.constraint_tolerance)
     sal = ALTRO_SOLVED;
-  else if (pen > T(o.maximum_penalty))
+  else if (pen > o.maximum_penalty)
     sal = ALTRO_MAX_PENALTY;
   else if (outer >= o.max_iterations_outer)
     sal = ALTRO_MAX_OUTER_ITERATIONS;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
   const unsigned Bp = A.Bp;
-  T gsum = T(0);
+  double gsum = 0.0;
   for (int k = 0; k < A.N; ++k) {
     T u[R::mP], kd[R::KP];
     load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
@@ -468,12 +476,12 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
     T mx = T(0);
 #pragma unroll
     for (int i = 0; i < m; ++i) mx = max_(mx, abs_(kd[R::oD + i]) / (abs_(u[i]) + T(1)));
-    gsum += mx;
+    gsum += (double)mx;
   }
   T v, p;
   rows_viol_pen(A, pd, b, &v, &p);
   const int st = A.status[b];
-  conv_stats_and_done(A, o, b, gsum, v);
+  conv_stats_and_done(A, o, b, gsum, (double)v);
   A.status[b] = st;  // the status change belongs to IsDone, which the step-level API does not call
 }
 
@@ -485,7 +493,7 @@ template <class T, class M, class Ctx, bool LDS, int FK>
 ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run, int kend,
                            const T* sX, const T* sU, const T* sKD, T alpha, T hh, bool valid,
                            unsigned tb, unsigned Bp, int b, bool check_bounds, T state_max2, T control_max2,
-                           T* xb, T& J, T& gs, bool& ok, int& st) {
+                           T* xb, double& J, double& gs, bool& ok, int& st) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   const KnotClass& kc = pd->cls[run.cls];
@@ -542,9 +550,9 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
           gden = den;
         }
       }
-      gs += gnum / gden;
+      gs += (double)(gnum / gden);
       if (FK == kFastGeneric) {
-        J += knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
+        J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
       } else {
         // quadratic cost (diagonal Q, R guaranteed by the host for the fast kinds)
         T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
@@ -604,7 +612,7 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
           bound_term();
           circle_term();
         }
-        J += Jk;
+        J += (double)Jk;
       }
       if (valid) {  // idle lanes must not touch instance 0's candidates
         T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
@@ -736,8 +744,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   }();
   const T hh = T(pd->hstep);
 
-  const T J0 = A.J0[b];
-  const T dV0 = A.dV0[b], dV1 = A.dV1[b];
+  const double J0 = A.J0[b];
+  const double dV0 = A.dV0[b], dV1 = A.dV1[b];
   T x0[R::nP];
   load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
   const T state_max2 = T(o.state_max) * T(o.state_max);
@@ -745,7 +753,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 
   const int ls_max = o.line_search_max_iterations;
   bool accepted = false;
-  T alpha_sel = T(0), J_sel = J0, z_sel = T(-1), g_sel = T(0);
+  T alpha_sel = T(0);
+  double J_sel = J0, z_sel = -1.0, g_sel = 0.0;
   int t_replay = -1;  // trial whose candidate defines c_ (and Z_ when accepted)
   int last_status = ALTRO_UNSOLVED;
 
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
     // ---- phase 1: closed-loop rollout + cost for this lane's alpha (ilqr.hpp:468-499, 527) -------
     bool ok = true;
     int st = ALTRO_UNSOLVED;
-    T J = T(0), gs = T(0);
+    double J = 0.0, gs = 0.0;
     T xb[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = x0[i];
@@ -787,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
       for (int i = 0; i < m; ++i) uz[i] = T(0);
       const KnotRun runN = pd->runs[pd->nruns - 1];  // the terminal knot closes the last run
       const KnotClass& kcN = pd->cls[runN.cls];
-      J += knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xb, uz, nullptr);
+      J += (double)knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xb, uz, nullptr);
       if (valid) {
         T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
 #pragma unroll
@@ -795,10 +804,9 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
       }
     }
     // ---- acceptance test (ilqr.hpp:528-542) --------------------------------------------------
-    const T expected = -alpha * (dV0 + alpha * dV1);
-    const T z = (expected > T(0)) ? (J0 - J) / expected : T(-1);
-    const bool acc = live && ok && T(o.line_search_lower_bound) <= z &&
-                     z <= T(o.line_search_upper_bound) && J < J0;
+    const double expected = -(double)alpha * (dV0 + (double)alpha * dV1);
+    const double z = (expected > 0.0) ? (J0 - J) / expected : -1.0;
+    const bool acc = live && ok && o.line_search_lower_bound <= z && z <= o.line_search_upper_bound && J < J0;
     // ---- pick the first accepted trial of this instance, exactly as the serial loop would ------
     const unsigned long long accm = __ballot(acc);
     const unsigned long long okm = __ballot(live && ok);
@@ -889,21 +897,21 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   if (t == 0) {
     if (accepted) {
       A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
-      A.alpha[b] = alpha_sel;
+      A.alpha[b] = (double)alpha_sel;
       A.z[b] = z_sel;
     } else {
-      T rho = A.rho_reg[b], drho = A.drho[b];
+      double rho = A.rho_reg[b], drho = A.drho[b];
       increase_reg(o, &rho, &drho);  // ilqr.hpp:550
       A.rho_reg[b] = rho;
       A.drho[b] = drho;
     }
     A.status[b] = last_status;
     if (mode == kFwdStepOnly) {
-      A.viol[b] = viol;
+      A.viol[b] = (double)viol;
     } else {
-      T gsum = g_sel;
+      double gsum = g_sel;
       if (!accepted) {  // rejected step: the controls are unchanged (quirk Q12 uses the current Z_)
-        gsum = T(0);
+        gsum = 0.0;
         for (int k = 0; k < N; ++k) {
           T mx = T(0);
 #pragma unroll
@@ -912,10 +920,10 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
             const T uv = LDS ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
             mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
           }
-          gsum += mx;
+          gsum += (double)mx;
         }
       }
-      inner_done = conv_stats_and_done(A, o, b, gsum, viol) ? 1 : 0;
+      inner_done = conv_stats_and_done(A, o, b, gsum, (double)viol) ? 1 : 0;
     }
   }
   if (mode == kFwdStepOnly) return;
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
         pm = max_(pm, __shfl(ppart, grp * LS + j));
       }
       int cont = 0;
-      if (t == 0) cont = al_outer_decide(A, o, b, vm, pm) ? 1 : 0;
+      if (t == 0) cont = al_outer_decide(A, o, b, (double)vm, (double)pm) ? 1 : 0;
       cont = __shfl(cont, grp * LS);
       if (cont) {
         for (int k = t; k <= N; k += LS) {  // constraint_values.hpp:202-207

@@ -151,15 +151,20 @@ def quadrotor12(make, batch=1, N=200, dtype=F32, xf_pos=None, **kw):
 # ---------------------------------------------------------------------------------------------------
 # Seeded synthetic batches; instance 0 = the exact reference problem
 # ---------------------------------------------------------------------------------------------------
-def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3):
-    """BASELINE config 3: kTurn90 with per-instance goal xf = (1.5+dx, 1.5+dy, pi/2+dth)."""
+def batch_turn90_goals(batch, seed=SEED_BASE + 3):
+    """Per-instance goals of BASELINE config 3: xf = (1.5+dx, 1.5+dy, pi/2+dth), instance 0 exact."""
     rng = np.random.default_rng(seed)
     xf = np.tile(np.array([1.5, 1.5, np.pi / 2]), (batch, 1))
     if batch > 1:
         xf[1:, 0] += rng.uniform(-0.5, 0.5, batch - 1)
         xf[1:, 1] += rng.uniform(-0.5, 0.5, batch - 1)
         xf[1:, 2] += rng.uniform(-0.3, 0.3, batch - 1)
-    return unicycle_turn90(make, batch=batch, N=N, dtype=dtype, xf=xf)
+    return xf
+
+
+def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3):
+    """BASELINE config 3: kTurn90 with per-instance goal xf = (1.5+dx, 1.5+dy, pi/2+dth)."""
+    return unicycle_turn90(make, batch=batch, N=N, dtype=dtype, xf=batch_turn90_goals(batch, seed))
 
 
 def batch_three_obstacles(make, batch, N=100, dtype=F32, seed=SEED_BASE + 4):

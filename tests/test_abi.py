@@ -1,0 +1,97 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/altro_hip.h
+declares, records problem definitions, validates arguments like the reference's ALTRO_ASSERTs, and
+FAILS LOUDLY (ALTRO_HIP_ERROR, no CPU fallback) when a compute entry point is called without a
+usable HIP device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "altro_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(altro_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("altro_create", "altro_destroy", "altro_solve_al", "altro_solve_ilqr", "altro_set_lqr_cost",
+                 "altro_add_constraint", "altro_get_trajectory", "altro_get_gains", "altro_get_stats",
+                 "altro_update_expansions", "altro_backward_pass", "altro_forward_pass", "altro_pack_results_device"):
+        assert must in names
+    assert len(names) >= 45
+
+
+def test_library_exports_every_declared_symbol(A):
+    lib = A.load_library()
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_oracle_mirrors_the_abi(oracle_lib):
+    """The oracle exposes the same entry points with the prefix oracle_ (tests drive both alike)."""
+    skip = {"altro_pack_results_device", "altro_device_info", "altro_get_timing"}
+    missing = [n for n in declared_functions() if n not in skip and not hasattr(oracle_lib, "oracle_" + n[len("altro_"):])]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_the_header(A):
+    # field order / sizes of the ctypes mirrors (a mismatch would corrupt every call)
+    assert ctypes.sizeof(A.Desc) == 24
+    assert ctypes.sizeof(A.Stats) == 24 + 9 * 8
+    assert [f for f, _ in A.Options._fields_][:5] == ["max_iterations_total", "max_iterations_outer",
+                                                      "max_iterations_inner", "cost_tolerance", "gradient_tolerance"]
+    assert ctypes.sizeof(A.Options) % 8 == 0
+
+
+def test_default_options_are_the_reference_defaults(A):
+    # altro/common/solver_options.hpp:23-56
+    s = A.BatchSolver(3, 2, 10, 1)
+    o = s.default_options()
+    assert (o.max_iterations_total, o.max_iterations_outer, o.max_iterations_inner) == (300, 30, 100)
+    assert (o.cost_tolerance, o.gradient_tolerance) == (1e-4, 1e-2)
+    assert (o.bp_reg_increase_factor, o.bp_reg_initial, o.bp_reg_max, o.bp_reg_min) == (1.6, 0.0, 1e8, 1e-8)
+    assert o.bp_reg_fail_threshold == 100 and o.check_forwardpass_bounds == 1
+    assert (o.state_max, o.control_max) == (1e8, 1e8)
+    assert (o.line_search_max_iterations, o.line_search_lower_bound, o.line_search_upper_bound,
+            o.line_search_decrease_factor) == (20, 1e-8, 10.0, 2.0)
+    assert (o.constraint_tolerance, o.maximum_penalty, o.initial_penalty, o.reset_duals) == (1e-4, 1e8, 1.0, 1)
+    s.set_options(constraint_tolerance=1e-6)
+    assert s.get_options().constraint_tolerance == 1e-6
+
+
+def test_argument_validation(A):
+    with pytest.raises(A.AltroError):
+        A.BatchSolver(0, 2, 10, 1)  # invalid dimensions
+    s = A.BatchSolver(3, 2, 10, 4)
+    with pytest.raises(A.AltroError):  # knot range out of bounds (Problem::SetCostFunction asserts)
+        s.set_lqr_cost(0, 12, np.eye(3), np.eye(2), np.zeros(3), np.zeros(2))
+    with pytest.raises(A.AltroError):  # "Lower bound isn't less than the upper bound." (basic_constraints.hpp:131-136)
+        s.add_control_bound(0, 10, [1.0, 1.0], [0.0, 2.0])
+    with pytest.raises(A.AltroError):  # ALTRO_ASSERT(rho >= 0), constraint_values.hpp:80
+        s.set_penalty(-1.0)
+    with pytest.raises(A.AltroError):  # ALTRO_ASSERT(phi >= 1), constraint_values.hpp:85
+        s.set_penalty_scaling(0.5)
+
+
+def test_no_cpu_fallback(A, P):
+    """Without a GPU every compute entry point must fail with a HIP error -- never silently run on CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device error path cannot be exercised")
+    s = P.unicycle_turn90(lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d), batch=2)
+    for call in (s.solve, s.solve_ilqr, s.rollout, s.update_expansions, s.get_trajectory):
+        with pytest.raises(A.AltroError) as e:
+            call()
+        assert "(2)" in str(e.value) or "hip" in str(e.value).lower()
+
+
+def test_missing_library_fails_loudly(A, tmp_path):
+    with pytest.raises(A.AltroError):
+        A.load_library(str(tmp_path / "libaltro_hip.so"))
