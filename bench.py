@@ -142,10 +142,25 @@ def main():
         achieved = ab[dom] * units / max(launches, 1) / (avg_launch_ms * 1e-3) / 1e9  # GB/s
         sweep_ms = sum(kern_ms.values())
         achieved_all = ab["total"] * units / (sweep_ms * 1e-3) / 1e9
+        # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
+        # same command (FETCH_SIZE / WRITE_SIZE in separate --pmc runs, gfx950 correction applied --
+        # see profiles/rNN_traffic.json); bench.py itself cannot run the profiler.
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            try:
+                tj = json.load(open(f))
+                key = "k_" + dom.replace("_pass", "")
+                if key in tj:
+                    traffic = round(tj[key]["traffic_bytes_per_launch"])
+                    traffic_src = os.path.relpath(f, ROOT)
+                    break
+            except Exception:
+                pass
         roofline = {
             "bound": "hbm", "kernel": "k_" + dom.replace("_pass", ""), "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(1e3 * avg_launch_ms, 2), "launches": launches,
             "algorithmic_bytes_per_launch": round(ab[dom] * units / max(launches, 1)),
             "all_kernels_achieved": round(achieved_all, 2),
