@@ -102,6 +102,14 @@ struct DevArrays {
   double *rho_reg, *drho, *dV0, *dV1, *J0, *initial_cost, *cost_cur, *cost_prev, *dJ, *grad, *viol,
       *penmax, *alpha, *z, *reg_log;
   int *status, *status_al, *it_inner, *it_outer, *it_total, *phase, *need_init_cost;
+  // active-instance compaction: this launch handles instances act_list[0 .. *act_count) (nullptr:
+  // identity list of act_count_const entries); instances that keep iterating are appended to
+  // next_list / next_count by the forward kernel's state machine
+  const int* act_list;
+  const int* act_count;
+  int act_count_const;
+  int* next_list;
+  int* next_count;
   // optional per-iteration history [field][cap][Bp]
   double* hist;
   int* hist_len;

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -153,12 +154,12 @@ class Engine final : public EngineBase {
   }
   altro_status BackwardPass(const altro_options& o) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL((k_backward<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, ToDevOpts(o), 1);
+    LaunchBackward(A_, ToDevOpts(o), 1, B_);
     return Sync();
   }
   altro_status ForwardPass(const altro_options& o) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    LaunchForward(ToDevOpts(o), (int)kFwdStepOnly, 1, nullptr);
+    LaunchForward(A_, ToDevOpts(o), (int)kFwdStepOnly, 1, B_);
     return Sync();
   }
   altro_status UpdateConvergenceStatistics(const altro_options& o) override {
@@ -346,16 +347,28 @@ class Engine final : public EngineBase {
   // ---- helpers ----------------------------------------------------------------------------------
   dim3 GridB() const { return dim3((B_ + kBlock - 1) / kBlock); }
   dim3 GridBK() const { return dim3((B_ + kBlock - 1) / kBlock, N_ + 1); }
+  // Backward pass launch: fp64 unicycle-sized problems run on the matrix cores (4 instances per
+  // wavefront), everything else on the one-lane-per-instance VALU kernel.
+  static constexpr bool kMfmaBackward = std::is_same<T, double>::value && n == 3 && m == 2;
+  void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
+    if constexpr (kMfmaBackward) {
+      if (!force_valu_backward_) {
+        hipLaunchKernelGGL((k_backward_mfma<M>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((k_backward<T, M>), dim3((ninst + kBlock - 1) / kBlock), dim3(kBlock), 0, stream_, A, d, all);
+  }
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
-  void LaunchForward(const DevOpts& d, int mode, int all, int* counter) {
-    const dim3 grid((B_ + fwd_per_wave_ - 1) / fwd_per_wave_);
+  void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
+    const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     if (fwd_lds_bytes_ > 0) {
-      hipLaunchKernelGGL((k_forward<T, M, true>), grid, dim3(kBlock), fwd_lds_bytes_, stream_, A_, d_pd_, pd_, d,
-                         mode, all, fwd_per_wave_, counter);
+      hipLaunchKernelGGL((k_forward<T, M, true>), grid, dim3(kBlock), fwd_lds_bytes_, stream_, A, d_pd_, pd_, d,
+                         mode, all, fwd_per_wave_);
     } else {
-      hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A_, d_pd_, pd_, d, mode, all,
-                         fwd_per_wave_, counter);
+      hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A, d_pd_, pd_, d, mode, all,
+                         fwd_per_wave_);
     }
   }
   altro_status Sync() {
@@ -721,6 +734,8 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
     ALTRO_ALLOC(d_tmp_, bp);
+    ALTRO_ALLOC(d_list_[0], bp);
+    ALTRO_ALLOC(d_list_[1], bp);
     ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * R::nP * bp);
     ALTRO_ALLOC(U_init_, (size_t)N_ * R::mP * bp);
     T* dpool = nullptr;
@@ -830,14 +845,32 @@ class Engine final : public EngineBase {
                                                 o.max_iterations_inner * std::max(1, (mode == kFwdAL) ? o.max_iterations_outer : 1))) + 2;
     int sweeps = 0;
     bool finished = false;
+    // Sweep i works on the instances that sweep i-1 left active: a dense list built by the forward
+    // kernel (two list buffers, a ring of counters that the host reads back one sweep late).  The
+    // grid is sized with the newest count the host knows -- counts only shrink, so it is an upper
+    // bound -- and tail sweeps launch a handful of workgroups instead of B/3.
+    int known_count = B_;
     auto enqueue_sweep = [&](int i) -> altro_status {
       const int slot = i % kRing;
       ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_ + slot, 0, sizeof(int), stream_));
-      hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 0);
+      DevArrays<T> A = A_;
+      if (i == 0) {
+        A.act_list = nullptr;
+        A.act_count = nullptr;
+        A.act_count_const = B_;
+      } else {
+        A.act_list = d_list_[i % 2];
+        A.act_count = d_counter_ + ((i - 1) % kRing);
+      }
+      A.next_list = d_list_[(i + 1) % 2];
+      A.next_count = d_counter_ + slot;
+      const int ninst = std::max(1, known_count);
+      const dim3 gridB((ninst + kBlock - 1) / kBlock);
+      hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-      hipLaunchKernelGGL((k_backward<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d, 0);
+      LaunchBackward(A, d, 0, ninst);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-      LaunchForward(d, mode, 0, d_counter_ + slot);
+      LaunchForward(A, d, mode, 0, ninst);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
       ALTRO_HIP_CHECK(hipMemcpyAsync(h_counter_ + slot, d_counter_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
       ALTRO_HIP_CHECK(hipEventRecord(ring_ev_[slot], stream_));
@@ -856,7 +889,8 @@ class Engine final : public EngineBase {
       }
       const int check = sweeps - 2 >= 0 ? sweeps - 2 : 0;
       ALTRO_HIP_CHECK(hipEventSynchronize(ring_ev_[check % kRing]));
-      if (h_counter_[check % kRing] == 0) finished = true;
+      known_count = h_counter_[check % kRing];
+      if (known_count == 0) finished = true;
       if (!finished && sweeps >= max_sweeps) {
         ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
         finished = true;
@@ -899,6 +933,8 @@ class Engine final : public EngineBase {
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};
   double* d_tmp_ = nullptr;
+  int* d_list_[2] = {nullptr, nullptr};
+  bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr;
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0;
   T *X_init_ = nullptr, *U_init_ = nullptr;

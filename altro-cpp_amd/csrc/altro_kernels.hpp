@@ -34,6 +34,15 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: instances never shar
 // record base of knot k for this lane's instance: arr + (k*Bp + b)*EP
 #define RECP(arr, k, EP) ((arr) + ((size_t)(unsigned)(k) * (unsigned)Bp + (unsigned)b) * (unsigned)(EP))
 
+// Instance handled by slot `idx` of this launch (-1: none).  `all` launches cover every instance.
+template <class T>
+ALTRO_DEV int instance_of_slot(const DevArrays<T>& A, int idx, int all) {
+  if (all) return idx < A.B ? idx : -1;
+  const int cnt = A.act_count ? *A.act_count : A.act_count_const;
+  if (idx >= cnt) return -1;
+  return A.act_list ? A.act_list[idx] : idx;
+}
+
 template <class T>
 ALTRO_DEV const KnotClass& class_of_knot(const DevArrays<T>& A, const ProblemDesc* pd, int k, int* rowbase) {
   *rowbase = A.knot_rowbase[k];
@@ -65,10 +74,9 @@ __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const Pro
                                                        int all) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using R = Rec<T, n, m>;
-  const int b = blockIdx.x * kBlock + threadIdx.x;
+  const int b = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
   const int k = blockIdx.y;
-  if (b >= A.B) return;
-  if (!all && A.phase[b] != 1) return;
+  if (b < 0) return;
   const int N = A.N;
   const unsigned Bp = A.Bp;
   T xr[R::nP], ur[R::mP];
@@ -102,8 +110,8 @@ template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, int all) {
   constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
-  const int b0 = blockIdx.x * kBlock + threadIdx.x;
-  const bool lane_on = (b0 < A.B) && (all || A.phase[b0] == 1);
+  const int b0 = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
+  const bool lane_on = b0 >= 0;
   if (__ballot(lane_on) == 0ull) return;
   const int b = lane_on ? b0 : 0;
   const int N = A.N;
@@ -178,6 +186,150 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
     }
   }
   if (!lane_on) return;
+  A.J0[b] = J0;
+  if (A.need_init_cost[b]) {
+    A.initial_cost[b] = J0;
+    A.need_init_cost[b] = 0;
+  }
+  A.reg_log[b] = rho;  // stats_.Log("reg", rho_)
+  decrease_reg(o, &rho, &drho);
+  A.rho_reg[b] = rho;
+  A.drho[b] = drho;
+  A.dV0[b] = dV0;
+  A.dV1[b] = dV1;
+  A.status[b] = status;
+}
+
+// -------------------------------------------------------------------------------------------------
+// iLQR::BackwardPass on the fp64 matrix cores (n = 3, m = 2: the unicycle of the headline config).
+//
+// v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 blocks per instruction.  Lane layout
+// (probed on gfx950, scripts/probes/mfma_f64_probe.hip): with r = lane/16, blk = (lane/4)%4,
+// c = lane%4,
+//     A[blk][i][k] sits in lane (r=k, c=i),  B[blk][k][j] in lane (r=k, c=j),  D[blk][i][j] in (r=i, c=j).
+// So a tile kept in "D form" (lane (r,c) holds X[r][c]) is directly the RIGHT operand of the next
+// product, and the same register used as the LEFT operand means X^T.  The Riccati step only ever
+// needs A^T., B^T., K^T., Qux^T. on the left (and the symmetric P, Quu, Quu^-1), so the whole
+// recursion chains through the matrix cores with no lane shuffles:
+//     W_A = P A, W_B = P B                                   (P in D form = P^T = P)
+//     [Qxx|Qx] = [lxx|lx] + A^T [W_A|p]     [Qux|Qu] = [lux|lu] + B^T [W_A|p]     Quu = luu + B^T W_B
+//     [K|d] = -(Quu + rho I)^-1 [Qux|Qu]                     (2x2 Cholesky in VALU, explicit inverse)
+//     G = Quu [K|d]
+//     [P|p] = [Qxx|Qx] + K^T G + K^T [Qux|Qu] + Qux^T [K|d]  (3 accumulating MFMAs, reference order)
+// 10 MFMAs + ~150 VALU per knot instead of ~330 fp64 VALU, and each wavefront carries 4 instances
+// (16 lanes each), so a 4096-instance batch fills all 1024 SIMDs.  Vectors ride along as the 4th
+// column of the 4x4 tiles.  Rounding differs from the VALU kernel only in association
+// (A^T(PA) vs (A^T P)A, explicit 2x2 inverse); semantics (restart on Cholesky failure, quirks Q3/Q4)
+// are identical.
+// -------------------------------------------------------------------------------------------------
+ALTRO_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, DevOpts o, int all) {
+  static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
+  constexpr int n = 3, m = 2;
+  using R = Rec<double, n, m>;
+  const int lane = threadIdx.x;
+  const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
+  const int b0 = instance_of_slot(A, blockIdx.x * 4 + blk, all);
+  const bool inst_on = b0 >= 0;
+  if (__ballot(inst_on) == 0ull) return;
+  const int b = inst_on ? b0 : 0;
+  const int N = A.N;
+  const unsigned Bp = A.Bp;
+  // element of each tile this lane owns (offset inside the expansion record; -1: structural zero)
+  const int offA = (r < n && c < n) ? R::oAB + r + c * n : -1;
+  const int offB = (r < n && c < m) ? R::oAB + n * n + r + c * n : -1;
+  const int off1 = (r < n) ? (c < n ? R::oLxx + r + c * n : R::oLx + r) : -1;          // [lxx | lx]
+  const int off2 = (r < m) ? (c < n ? R::oLxu + c + r * n : R::oLu + r) : -1;          // [lux | lu]
+  const int off3 = (r < m && c < m) ? R::oLuu + r + c * m : -1;                        // luu
+  const int offKD = (r < m) ? (c < n ? R::oK + r + c * m : R::oD + r) : -1;            // [K | d]
+  const int offCT = (r < n) ? (c < n ? R::oP + r + c * n : R::op + r) : -1;            // [P | p]
+  auto ld = [&](const double* rec, int off) { return off >= 0 ? rec[off] : 0.0; };
+
+  double J0 = 0.0;
+#pragma unroll 8
+  for (int k = 0; k <= N; ++k) J0 += A.costs[(unsigned)k * Bp + (unsigned)b];
+  double rho = A.rho_reg[b], drho = A.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
+  int max_reg_count = 0;
+  int status = A.status[b];
+  bool need = inst_on && N > 0;
+  const int lane_d = (lane & 0x0f) | 0x03;  // lane (r=0, c=3) of this instance: row 0 of the vector column
+  while (__ballot(need) != 0ull) {
+    // CalcTerminalCostToGo: [P|p] = [lxx|lx] of knot N
+    double Pp = ld(RECP(A.EXP, N, R::EP), off1);
+    if (A.record_ctg && need && offCT >= 0) RECP(A.CTG, N, R::CP)[offCT] = Pp;
+    bool running = need;
+    const double* rec = RECP(A.EXP, N - 1, R::EP);
+    double tA = ld(rec, offA), tB = ld(rec, offB), t1 = ld(rec, off1), t2 = ld(rec, off2), t3 = ld(rec, off3);
+    for (int k = N - 1; k >= 0; --k) {
+      const double Pm = (c < n) ? Pp : 0.0;  // P without the vector column
+      const double WA = mfma4(Pm, tA, 0.0);
+      const double WB = mfma4(Pm, tB, 0.0);
+      const double Waug = (c < n) ? WA : Pp;  // [P A | p]
+      const double Q1 = mfma4(tA, Waug, t1);  // [Qxx | Qx]
+      const double Q2 = mfma4(tB, Waug, t2);  // [Qux | Qu]
+      const double Q3 = mfma4(tB, WB, t3);    // Quu
+      // prefetch the next knot's tiles while the Cholesky / gain / cost-to-go half executes
+      if (k > 0) {
+        rec = RECP(A.EXP, k - 1, R::EP);
+        tA = ld(rec, offA);
+        tB = ld(rec, offB);
+        t1 = ld(rec, off1);
+        t2 = ld(rec, off2);
+        t3 = ld(rec, off3);
+      }
+      // Quu entries to every lane of the instance: lanes (0,0), (1,0), (1,1) of the Quu tile
+      const int base = lane & 0x0c;  // 4*blk
+      const double q00 = __shfl(Q3, base + 0);
+      const double q10 = __shfl(Q3, base + 16);
+      const double q11 = __shfl(Q3, base + 17);
+      // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure (knot_point_function_type.hpp:197-211)
+      const double x1 = q00 + rho;
+      const double l11 = sqrt(x1);
+      const double i11 = 1.0 / l11;
+      const double l21 = q10 * i11;
+      const double x2 = (q11 + rho) - l21 * l21;
+      const double l22 = sqrt(x2);
+      const double i22 = 1.0 / l22;
+      const bool fail = (x1 <= 0.0) || (x2 <= 0.0);
+      // (L L^T)^-1 = L^-T L^-1 with L^-1 = [i11 0; i21 i22]
+      const double i21 = -(l21 * i11) * i22;
+      const double m00 = i11 * i11 + i21 * i21, m10 = i21 * i22, m11 = i22 * i22;
+      const double Minv = (r < m && c < m) ? (r == c ? (r == 0 ? m00 : m11) : m10) : 0.0;
+      const double KD = -mfma4(Minv, Q2, 0.0);  // [K | d], gains from the REGULARISED Quu (quirk Q3)
+      const double G = mfma4(Q3, KD, 0.0);      // Quu [K | d] with the UN-regularised Quu
+      const double KDm = (c < n) ? KD : 0.0, Q2m = (c < n) ? Q2 : 0.0;
+      double Pn = mfma4(KDm, G, Q1);  // + K^T Quu [K|d]
+      Pn = mfma4(KDm, Q2, Pn);        // + K^T [Qux|Qu]
+      Pn = mfma4(Q2m, KD, Pn);        // + Qux^T [K|d]
+      // expected cost decrease: d^T Qu and 0.5 d^T Quu d (rows 0,1 of the vector column)
+      const double e0 = KD * Q2, e1 = KD * G;
+      const double v0 = __shfl(e0, lane_d) + __shfl(e0, lane_d + 16);
+      const double v1 = __shfl(e1, lane_d) + __shfl(e1, lane_d + 16);
+      if (running) {
+        if (fail) {
+          // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
+          increase_reg(o, &rho, &drho);
+          if (rho >= o.bp_reg_max) max_reg_count++;
+          if (max_reg_count >= o.bp_reg_fail_threshold) {
+            status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
+            need = false;
+          }
+          running = false;
+        } else {
+          Pp = Pn;
+          dV0 += v0;
+          dV1 += 0.5 * v1;
+          if (offKD >= 0) RECP(A.KD, k, R::KP)[offKD] = KD;
+          if (A.record_ctg && offCT >= 0) RECP(A.CTG, k, R::CP)[offCT] = Pn;
+          if (k == 0) need = false;  // sweep completed
+        }
+      }
+    }
+  }
+  if (!inst_on || r != 0 || c != 0) return;
   A.J0[b] = J0;
   if (A.need_init_cost[b]) {
     A.initial_cost[b] = J0;
@@ -654,7 +806,7 @@ struct FwdLds {  // element counts of one instance's staged block (16-byte align
 template <class T, class M, bool LDS>
 __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const ProblemDesc* __restrict__ pd_global,
                                                     const ProblemDesc pd_arg, DevOpts o, int mode, int all,
-                                                    int per_wave, int* active_counter) {
+                                                    int per_wave) {
   // LDS variant: the problem description comes from the kernel arguments (scalar loads that the
   // compiler can keep in SGPRs across the serial loop)
   const ProblemDesc* pd = LDS ? &pd_arg : pd_global;
@@ -665,10 +817,10 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   const int lane = threadIdx.x;
   const int grp = lane / LS;
   const int t = lane - grp * LS;
-  const int b0 = blockIdx.x * per_wave + grp;
+  const int b0 = (grp < per_wave) ? instance_of_slot(A, blockIdx.x * per_wave + grp, all) : -1;
   const unsigned Bp = A.Bp;
   const int N = A.N;
-  const bool valid = (grp < per_wave) && (b0 < A.B) && (all || A.phase[b0] == 1);
+  const bool valid = b0 >= 0;
   if (__ballot(valid) == 0ull) return;  // nothing to do for this wave (finished instances)
   const int b = valid ? b0 : 0;         // idle lanes shadow instance 0's loads but never store
 
@@ -977,8 +1129,9 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   if (t != 0) return;
   if (!active) {
     A.phase[b] = 0;
-  } else if (active_counter) {
-    atomicAdd(active_counter, 1);
+  } else if (A.next_count) {
+    const int slot = atomicAdd(A.next_count, 1);  // order is arbitrary; instances are independent
+    A.next_list[slot] = b;
   }
 }
 
