@@ -363,10 +363,12 @@ class Engine final : public EngineBase {
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
-    if (fwd_lds_bytes_ > 0) {
-      hipLaunchKernelGGL((k_forward<T, M, true>), grid, dim3(kBlock), fwd_lds_bytes_, stream_, A, d_pd_, pd_, d,
-                         mode, all, fwd_per_wave_);
+    if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
+      // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS
+      hipLaunchKernelGGL((k_forward2<T, M>), grid, dim3(2 * kBlock), fwd_lds_bytes_, stream_, A, pd_, d, mode, all,
+                         fwd_per_wave_);
     } else {
+      // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)
       hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A, d_pd_, pd_, d, mode, all,
                          fwd_per_wave_);
     }
@@ -791,14 +793,14 @@ class Engine final : public EngineBase {
       const int lanes_max = kBlock / kLineSearchLanes;
       fwd_per_wave_ = lanes_max;
       while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
-      const size_t pool_bytes = pool.size() * sizeof(T);
-      while (fwd_per_wave_ > 1 && pool_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
-      fwd_lds_bytes_ = pool_bytes + fwd_per_wave_ * per_inst;
+      const size_t shared_bytes = (padv(pool.size()) + 2 * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int);
+      while (fwd_per_wave_ > 1 && shared_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
+      fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
       } else if (fwd_lds_bytes_ > 64 * 1024) {
-        ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward<T, M, true>),
+        ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
       }
     }

@@ -222,6 +222,17 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
 // (A^T(PA) vs (A^T P)A, explicit 2x2 inverse); semantics (restart on Cholesky failure, quirks Q3/Q4)
 // are identical.
 // -------------------------------------------------------------------------------------------------
+ALTRO_DEV double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  // y <- y + y * (0.5 - 0.5 x y^2): two steps take the ~2^-26 hardware estimate to full precision
+  double h = 0.5 * x * y;
+  double e = fma(-h, y, 0.5);
+  y = fma(y, e, y);
+  h = 0.5 * x * y;
+  e = fma(-h, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
 ALTRO_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 template <class M>
@@ -286,13 +297,13 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       const double q10 = __shfl(Q3, base + 16);
       const double q11 = __shfl(Q3, base + 17);
       // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure (knot_point_function_type.hpp:197-211)
+      // only 1/l11 and 1/l22 are needed: one refined reciprocal square root each (v_rsq_f64 + two
+      // Newton steps, ~1 ulp) instead of sqrt followed by a division on the dependent chain
       const double x1 = q00 + rho;
-      const double l11 = sqrt(x1);
-      const double i11 = 1.0 / l11;
+      const double i11 = rsqrt_nr(x1);
       const double l21 = q10 * i11;
       const double x2 = (q11 + rho) - l21 * l21;
-      const double l22 = sqrt(x2);
-      const double i22 = 1.0 / l22;
+      const double i22 = rsqrt_nr(x2);
       const bool fail = (x1 <= 0.0) || (x2 <= 0.0);
       // (L L^T)^-1 = L^-T L^-1 with L^-1 = [i11 0; i21 i22]
       const double i21 = -(l21 * i11) * i22;
@@ -635,6 +646,110 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
   const int st = A.status[b];
   conv_stats_and_done(A, o, b, gsum, (double)v);
   A.status[b] = st;  // the status change belongs to IsDone, which the step-level API does not call
+}
+
+// Phase 3 of the forward pass: per-instance state machine (shared by both forward kernels).
+// Lane 0 of the instance takes the decisions; the row sweeps of the AL transition (dual and penalty
+// updates) are spread over its 20 lanes.  sKD / sU: LDS copies of the gains / controls (or nullptr).
+template <class T, class M>
+ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
+                              int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
+                              int last_status, double viol, const T* sKD, const T* sU) {
+  constexpr int m = M::m;
+  constexpr int LS = kLineSearchLanes;
+  using R = Rec<T, M::n, M::m>;
+  const unsigned Bp = A.Bp;
+  const int N = A.N;
+  // ---- phase 3: per-instance state machine.  Lane 0 of the instance takes the decisions; the
+  //      row sweeps of the AL transition (dual and penalty updates) are spread over its 20 lanes.
+  int inner_done = 0;
+  if (t == 0) {
+    if (accepted) {
+      A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
+      A.alpha[b] = alpha_sel;
+      A.z[b] = z_sel;
+    } else {
+      double rho = A.rho_reg[b], drho = A.drho[b];
+      increase_reg(o, &rho, &drho);  // ilqr.hpp:550
+      A.rho_reg[b] = rho;
+      A.drho[b] = drho;
+    }
+    A.status[b] = last_status;
+    if (mode == kFwdStepOnly) {
+      A.viol[b] = viol;
+    } else {
+      double gsum = g_sel;
+      if (!accepted) {  // rejected step: the controls are unchanged (quirk Q12 uses the current Z_)
+        gsum = 0.0;
+        for (int k = 0; k < N; ++k) {
+          T mx = T(0);
+#pragma unroll
+          for (int i = 0; i < m; ++i) {
+            const T dv = sKD ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
+            const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
+            mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
+          }
+          gsum += (double)mx;
+        }
+      }
+      inner_done = conv_stats_and_done(A, o, b, gsum, viol) ? 1 : 0;
+    }
+  }
+  if (mode == kFwdStepOnly) return;
+  inner_done = __shfl(inner_done, grp * LS);
+  bool active = true;
+  if (inner_done) {
+    if (mode == kFwdAL) {
+      // AugmentedLagrangianiLQR: UpdateDuals, UpdateConvergenceStatistics, IsDone, UpdatePenalties
+      // (al_solver.hpp:313-401); each lane sweeps the rows of knots t, t+20, ...
+      T vpart = T(0), ppart = T(0);
+      for (int k = t; k <= N; k += LS) {
+        int rb;
+        const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+        for (int ci = 0; ci < kc.ncon; ++ci) {
+          const ConDesc& cd = kc.con[ci];
+          for (int i = 0; i < cd.p; ++i) {
+            const unsigned idx = (unsigned)(rb + cd.row_off + i) * Bp + (unsigned)b;
+            const T c = A.cval[idx], rho = A.pen[idx];
+            A.lam[idx] = dual_proj(cd.type, A.lam[idx] - rho * c);  // constraint_values.hpp:192-194
+            vpart = max_(vpart, violation(cd.type, c));
+            ppart = max_(ppart, rho);
+          }
+        }
+      }
+      T vm = vpart, pm = ppart;
+      for (int j = 0; j < LS; ++j) {
+        vm = max_(vm, __shfl(vpart, grp * LS + j));
+        pm = max_(pm, __shfl(ppart, grp * LS + j));
+      }
+      int cont = 0;
+      if (t == 0) cont = al_outer_decide(A, o, b, (double)vm, (double)pm) ? 1 : 0;
+      cont = __shfl(cont, grp * LS);
+      if (cont) {
+        for (int k = t; k <= N; k += LS) {  // constraint_values.hpp:202-207
+          const int cls = A.knot_class[k];
+          const KnotClass& kc = pd->cls[cls];
+          const int rb = A.knot_rowbase[k];
+          for (int ci = 0; ci < kc.ncon; ++ci) {
+            const T phi = T(A.phi[cls * kMaxConPerKnot + ci]);
+            for (int i = 0; i < kc.con[ci].p; ++i)
+              A.pen[(unsigned)(rb + kc.con[ci].row_off + i) * Bp + (unsigned)b] *= phi;
+          }
+        }
+        if (t == 0) begin_inner_solve(A, o, b);
+      }
+      active = cont != 0;
+    } else {
+      active = false;
+    }
+  }
+  if (t != 0) return;
+  if (!active) {
+    A.phase[b] = 0;
+  } else if (A.next_count) {
+    const int slot = atomicAdd(A.next_count, 1);  // order is arbitrary; instances are independent
+    A.next_list[slot] = b;
+  }
 }
 
 // One run of knots of the closed-loop rollout + cost of ONE line-search trial (one lane):
@@ -1043,96 +1158,421 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
     viol = vm;
   }
 
-  // ---- phase 3: per-instance state machine.  Lane 0 of the instance takes the decisions; the
-  //      row sweeps of the AL transition (dual and penalty updates) are spread over its 20 lanes.
-  int inner_done = 0;
-  if (t == 0) {
-    if (accepted) {
-      A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
-      A.alpha[b] = (double)alpha_sel;
-      A.z[b] = z_sel;
-    } else {
-      double rho = A.rho_reg[b], drho = A.drho[b];
-      increase_reg(o, &rho, &drho);  // ilqr.hpp:550
-      A.rho_reg[b] = rho;
-      A.drho[b] = drho;
-    }
-    A.status[b] = last_status;
-    if (mode == kFwdStepOnly) {
-      A.viol[b] = (double)viol;
-    } else {
-      double gsum = g_sel;
-      if (!accepted) {  // rejected step: the controls are unchanged (quirk Q12 uses the current Z_)
-        gsum = 0.0;
-        for (int k = 0; k < N; ++k) {
-          T mx = T(0);
+  forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
+                       (double)viol, LDS ? sKD : (const T*)nullptr, LDS ? sU : (const T*)nullptr);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Forward pass, two-wave pipeline (the production variant whenever the staged block fits in LDS).
+//
+// The dependent chain of a rollout is  x_k -> u_k = u + K dx + alpha d -> RK4 -> x_{k+1}.  The AL
+// cost, the gradient statistic and the candidate stores only CONSUME (x_k, u_k).  A single
+// wavefront issues one instruction per ~4.4 cycles no matter how few lanes are active, so the step
+// is split over the two wavefronts of a 128-thread workgroup (two SIMDs of one CU):
+//   wave 0 "rollout": LDS reads of (x,u,K,d)_k, control law, RK4 (3 sincos), bound checks, and a
+//                     5-value hand-off of (xbar_k, ubar_k) into a double-buffered LDS slot;
+//   wave 1 "cost":    one step behind: AL knot cost (compile-time constraint layout), gradient
+//                     statistic, candidate stores; then acceptance ballot, phases 2 and 3.
+// One workgroup barrier per knot; slot k&1 is rewritten by wave 0 only after barrier k+1, which wave
+// 1 reaches only after it has consumed slot k&1.  Same lane layout in both waves (3 instances x 20
+// trials).  Values and operation order are identical to the single-wave kernel.
+// -------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
+// make the cost wave wait for its (scattered, never re-read in the loop) candidate stores at every
+// knot -- and the rollout wave with it.
+ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class T, class M, int FK>
+ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
+                                 int kend, const T* sKD, const T* xch, int lane, bool valid, unsigned tb,
+                                 double& J, double& gs) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  constexpr int LS = kLineSearchLanes;
+  using R = Rec<T, n, m>;
+  const KnotClass& kc = pd->cls[run.cls];
+  RunConsts<T, n, m> RC;
+  load_run_consts<T, n, m>(C, pd, kc, RC);
+  constexpr bool kHasB = (FK == kFastB || FK == kFastCB || FK == kFastBC);
+  constexpr bool kHasC = (FK == kFastC || FK == kFastCB || FK == kFastBC);
+  constexpr int kCi = (FK == kFastBC) ? 1 : 0;
+  constexpr int kBi = (FK == kFastCB) ? 1 : 0;
+  int c_p = 0, c_pi = 0, c_off = 0, c_row = 0, b_row = 0;
+  if (kHasC) {
+    c_p = kc.con[kCi].p;
+    c_pi = kc.con[kCi].per_instance;
+    c_off = kc.con[kCi].param_off;
+    c_row = kc.con[kCi].row_off;
+  }
+  if (kHasB) b_row = kc.con[kBi].row_off;
+  const int nrows = kc.nrows;
+  for (int k = run.k_begin; k < kend; ++k) {
+    lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
+    const T* slot = xch + (k & 1) * (nm * kBlock);
+    T xb[n], ub[m], d[m];
 #pragma unroll
-          for (int i = 0; i < m; ++i) {
-            const T dv = LDS ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
-            const T uv = LDS ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
-            mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
-          }
-          gsum += (double)mx;
-        }
-      }
-      inner_done = conv_stats_and_done(A, o, b, gsum, (double)viol) ? 1 : 0;
+    for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
+#pragma unroll
+    for (int i = 0; i < m; ++i) d[i] = sKD[k * R::KP + R::oD + i];
+    const int rb = run.rowbase + (k - run.k_begin) * nrows;
+    T blam[2 * m], brho = T(1);
+    if (kHasB) {
+      brho = C.pen(rb + b_row);
+#pragma unroll
+      for (int j = 0; j < 2 * m; ++j) blam[j] = C.lam(rb + b_row + j);
     }
-  }
-  if (mode == kFwdStepOnly) return;
-  inner_done = __shfl(inner_done, grp * LS);
-  bool active = true;
-  if (inner_done) {
-    if (mode == kFwdAL) {
-      // AugmentedLagrangianiLQR: UpdateDuals, UpdateConvergenceStatistics, IsDone, UpdatePenalties
-      // (al_solver.hpp:313-401); each lane sweeps the rows of knots t, t+20, ...
-      T vpart = T(0), ppart = T(0);
-      for (int k = t; k <= N; k += LS) {
-        int rb;
-        const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-        for (int ci = 0; ci < kc.ncon; ++ci) {
-          const ConDesc& cd = kc.con[ci];
-          for (int i = 0; i < cd.p; ++i) {
-            const unsigned idx = (unsigned)(rb + cd.row_off + i) * Bp + (unsigned)b;
-            const T c = A.cval[idx], rho = A.pen[idx];
-            A.lam[idx] = dual_proj(cd.type, A.lam[idx] - rho * c);  // constraint_values.hpp:192-194
-            vpart = max_(vpart, violation(cd.type, c));
-            ppart = max_(ppart, rho);
-          }
-        }
+    // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
+    T gnum = T(0), gden = T(1);
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      const T num = abs_(d[i]), den = abs_(ub[i]) + T(1);
+      if (num * gden > gnum * den) {
+        gnum = num;
+        gden = den;
       }
-      T vm = vpart, pm = ppart;
-      for (int j = 0; j < LS; ++j) {
-        vm = max_(vm, __shfl(vpart, grp * LS + j));
-        pm = max_(pm, __shfl(ppart, grp * LS + j));
-      }
-      int cont = 0;
-      if (t == 0) cont = al_outer_decide(A, o, b, (double)vm, (double)pm) ? 1 : 0;
-      cont = __shfl(cont, grp * LS);
-      if (cont) {
-        for (int k = t; k <= N; k += LS) {  // constraint_values.hpp:202-207
-          const int cls = A.knot_class[k];
-          const KnotClass& kc = pd->cls[cls];
-          const int rb = A.knot_rowbase[k];
-          for (int ci = 0; ci < kc.ncon; ++ci) {
-            const T phi = T(A.phi[cls * kMaxConPerKnot + ci]);
-            for (int i = 0; i < kc.con[ci].p; ++i)
-              A.pen[(unsigned)(rb + kc.con[ci].row_off + i) * Bp + (unsigned)b] *= phi;
-          }
-        }
-        if (t == 0) begin_inner_solve(A, o, b);
-      }
-      active = cont != 0;
+    }
+    gs += (double)(gnum / gden);
+    if (FK == kFastGeneric) {
+      J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
     } else {
-      active = false;
+      T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        xQx += xb[i] * (RC.Qd[i] * xb[i]);
+        qx += RC.q[i] * xb[i];
+      }
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        uRu += ub[i] * (RC.Rd[i] * ub[i]);
+        ru += RC.r[i] * ub[i];
+      }
+      T Jk = T(0.5) * xQx + T(0.5) * uRu + qx + ru + RC.c;
+      auto circle_term = [&]() {
+        const T rho = C.pen(rb + c_row);
+        T a = T(0), bsum = T(0);
+        for (int i = 0; i < c_p; ++i) {
+          T dx = xb[0] - C.par(c_pi, c_off, 3 * i);
+          T dy = xb[1] - C.par(c_pi, c_off, 3 * i + 1);
+          T rr = C.par(c_pi, c_off, 3 * i + 2);
+          T c = -(dx * dx + dy * dy - rr * rr);
+          T lam = C.lam(rb + c_row + i);
+          T lp = dual_proj(1, lam - rho * c);
+          a += lp * lp;
+          bsum += lam * lam;
+        }
+        T Jc = a - bsum;
+        Jk += Jc / (2 * rho);
+      };
+      auto bound_term = [&]() {
+        T a = T(0), bsum = T(0);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          T c = RC.bnd[j] - ub[j];
+          T lp = dual_proj(1, blam[j] - brho * c);
+          a += lp * lp;
+          bsum += blam[j] * blam[j];
+        }
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          T c = ub[j] - RC.bnd[m + j];
+          T lp = dual_proj(1, blam[m + j] - brho * c);
+          a += lp * lp;
+          bsum += blam[m + j] * blam[m + j];
+        }
+        T Jc = a - bsum;
+        Jk += Jc / (2 * brho);
+      };
+      if (FK == kFastB) bound_term();
+      if (FK == kFastC) circle_term();
+      if (FK == kFastCB) {
+        circle_term();
+        bound_term();
+      }
+      if (FK == kFastBC) {
+        bound_term();
+        circle_term();
+      }
+      J += (double)Jk;
+    }
+    if (valid) {  // idle lanes must not touch instance 0's candidates
+      T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
+#pragma unroll
+      for (int i = 0; i < n; ++i) cand[i] = xb[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
     }
   }
-  if (t != 0) return;
-  if (!active) {
-    A.phase[b] = 0;
-  } else if (A.next_count) {
-    const int slot = atomicAdd(A.next_count, 1);  // order is arbitrary; instances are independent
-    A.next_list[slot] = b;
+}
+
+template <class T, class M>
+__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc pd_arg, DevOpts o, int mode,
+                                                         int all, int per_wave) {
+  const ProblemDesc* pd = &pd_arg;
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  constexpr int LS = kLineSearchLanes;
+  using R = Rec<T, n, m>;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LS;
+  const int t = lane - grp * LS;
+  const int b0 = (grp < per_wave) ? instance_of_slot(A, blockIdx.x * per_wave + grp, all) : -1;
+  const unsigned Bp = A.Bp;
+  const int N = A.N;
+  const bool valid = b0 >= 0;
+  if (__ballot(valid) == 0ull) return;  // both waves take the same decision
+  const int b = valid ? b0 : 0;
+
+  // ---- phase 0: stage the instance's read-only inputs in LDS (both waves copy) ------------------
+  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, R::V};
+  T* sm = reinterpret_cast<T*>(smem_raw) + (grp < per_wave ? grp : 0) * L.total();
+  T* sX = sm;
+  T* sU = sX + L.nX;
+  T* sKD = sU + L.nU;
+  T* sLam = sKD + L.nKD;
+  T* sPen = sLam + L.rowsP();
+  T* sIp = sPen + L.rowsP();
+  T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
+  T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
+  int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
+  {
+    for (int i = threadIdx.x; i < pd->npool; i += 2 * kBlock) sPool[i] = A.pool[i];
+    if (valid) {
+      using V = typename VecOf<T>::type;
+      constexpr int VN = R::V;
+      const int tt = t + LS * wave;
+      constexpr int kStride = 2 * LS;
+      auto stage_rec = [&](T* dst, const T* src, int knots, int EP) {
+        const int per = EP / VN;
+        const int total = knots * per;
+        constexpr int kDepth = 8;
+        for (int i0 = tt; i0 < total; i0 += kStride * kDepth) {
+          V v[kDepth];
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            int vi = i0 + j * kStride;
+            vi = vi < total ? vi : total - 1;
+            const int k = vi / per, w = vi - k * per;
+            v[j] = *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
+          }
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int vi = i0 + j * kStride;
+            if (vi < total) *reinterpret_cast<V*>(dst + vi * VN) = v[j];
+          }
+        }
+      };
+      auto stage_soa = [&](T* dst, const T* src, int cnt) {
+        constexpr int kDepth = 8;
+        for (int i0 = tt; i0 < cnt; i0 += kStride * kDepth) {
+          T v[kDepth];
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int i = i0 + j * kStride;
+            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)b] : T(0);
+          }
+#pragma unroll
+          for (int j = 0; j < kDepth; ++j) {
+            const int i = i0 + j * kStride;
+            if (i < cnt) dst[i] = v[j];
+          }
+        }
+      };
+      stage_rec(sX, A.X, N + 1, R::nP);
+      stage_rec(sU, A.U, N, R::mP);
+      stage_rec(sKD, A.KD, N, R::KP);
+      stage_soa(sLam, A.lam, L.nR);
+      stage_soa(sPen, A.pen, L.nR);
+      stage_soa(sIp, A.ipool, L.nS);
+    }
   }
+  __syncthreads();
+
+  T x0[R::nP];
+  load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
+  const T hh = T(pd->hstep);
+  const int ls_max = o.line_search_max_iterations;
+  // this lane's step length: alpha /= decrease_factor, t times (ilqr.hpp:544)
+  T alpha = T(1);
+  for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
+
+  if (wave == 0) {
+    // ================= rollout wave: iLQR::RolloutClosedLoop (ilqr.hpp:468-499) =================
+    const T state_max2 = T(o.state_max) * T(o.state_max);
+    const T control_max2 = T(o.control_max) * T(o.control_max);
+    const bool check = o.check_forwardpass_bounds != 0;
+    bool ok = true;
+    int st = ALTRO_UNSOLVED;
+    T xb[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xb[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      T xk[R::nP], uk[R::mP], kd[R::KP], ub[m], xn[n];
+      load_rec<T, R::nP>(sX + k * R::nP, xk);
+      load_rec<T, R::mP>(sU + k * R::mP, uk);
+      load_rec<T, R::KP>(sKD + k * R::KP, kd);
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          T s = T(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += kd[R::oK + i + l * m] * (xb[l] - xk[l]);
+          ub[i] = uk[i] + s + kd[R::oD + i] * alpha;
+        }
+        T* slot = xch + (k & 1) * (nm * kBlock);
+#pragma unroll
+        for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
+        rk4_step<T, M>(xb, ub, hh, xn);
+        if (check) {
+          // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2 (ilqr.hpp:484-495), no sqrt needed
+          T sx = T(0), su = T(0);
+#pragma unroll
+          for (int i = 0; i < n; ++i) sx += xn[i] * xn[i];
+#pragma unroll
+          for (int i = 0; i < m; ++i) su += ub[i] * ub[i];
+          if (sx > state_max2) {
+            ok = false;
+            st = ALTRO_STATE_LIMIT;
+          } else if (su > control_max2) {
+            ok = false;
+            st = ALTRO_CONTROL_LIMIT;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) xb[i] = xn[i];
+      }
+      lds_barrier();  // barrier k
+    }
+    // final hand-off: x_N, rollout outcome
+    T* slot = xch + (N & 1) * (nm * kBlock);
+#pragma unroll
+    for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
+    flags[lane] = ok ? 1 : 0;
+    flags[kBlock + lane] = st;
+    lds_barrier();  // barrier N
+    return;
+  }
+
+  // ===================== cost wave: iLQR::Cost per trial + everything after ======================
+  CtxL<T> C(A, b, sPool, sIp, sLam, sPen);
+  const double J0 = A.J0[b];
+  const double dV0 = A.dV0[b], dV1 = A.dV1[b];
+  // candidate scratch, instance-major [b][k][trial][x|u]
+  const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
+  double J = 0.0, gs = 0.0;
+  for (int r = 0; r < pd->nruns; ++r) {
+    const KnotRun run = pd->runs[r];
+    const int kend = run.k_end < N ? run.k_end : N;
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, sKD, xch, lane, valid, tb, J, gs)
+    switch (run.fast) {
+      case kFastNone: ALTRO_RUN(kFastNone); break;
+      case kFastB: ALTRO_RUN(kFastB); break;
+      case kFastCB: ALTRO_RUN(kFastCB); break;
+      case kFastBC: ALTRO_RUN(kFastBC); break;
+      case kFastC: ALTRO_RUN(kFastC); break;
+      default: ALTRO_RUN(kFastGeneric); break;
+    }
+#undef ALTRO_RUN
+  }
+  lds_barrier();  // barrier N: terminal state and rollout outcome
+  const bool ok = flags[lane] != 0;
+  const int st = flags[kBlock + lane];
+  {
+    const T* slot = xch + (N & 1) * (nm * kBlock);
+    T xN[n], uz[m];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
+#pragma unroll
+    for (int i = 0; i < m; ++i) uz[i] = T(0);
+    const KnotRun runN = pd->runs[pd->nruns - 1];  // the terminal knot closes the last run
+    const KnotClass& kcN = pd->cls[runN.cls];
+    J += (double)knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xN, uz, nullptr);
+    if (valid) {
+      T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
+#pragma unroll
+      for (int i = 0; i < n; ++i) cand[i] = xN[i];
+    }
+  }
+  // ---- acceptance test (ilqr.hpp:528-542) and selection of the first accepted trial --------------
+  const bool live = valid && (t < ls_max);
+  const double expected = -(double)alpha * (dV0 + (double)alpha * dV1);
+  const double z = (expected > 0.0) ? (J0 - J) / expected : -1.0;
+  const bool acc = live && ok && o.line_search_lower_bound <= z && z <= o.line_search_upper_bound && J < J0;
+  const unsigned long long accm = __ballot(acc);
+  const unsigned long long okm = __ballot(live && ok);
+  const unsigned gmask = (1u << LS) - 1u;
+  const unsigned acc_g = (unsigned)(accm >> (grp * LS)) & gmask;
+  const unsigned ok_g = (unsigned)(okm >> (grp * LS)) & gmask;
+  const int nlive = ls_max < LS ? ls_max : LS;
+  bool accepted = false;
+  T alpha_sel = T(0);
+  double J_sel = J0, z_sel = -1.0, g_sel = 0.0;
+  int t_replay = -1;
+  int last_status = ALTRO_UNSOLVED;
+  if (acc_g) {
+    const int tsel = __ffs(acc_g) - 1;
+    const int src = grp * LS + tsel;
+    alpha_sel = __shfl(alpha, src);
+    J_sel = __shfl(J, src);
+    z_sel = __shfl(z, src);
+    g_sel = __shfl(gs, src);
+    accepted = true;
+    last_status = ALTRO_UNSOLVED;  // the accepted rollout was the last one run (ilqr.hpp:497)
+    t_replay = tsel;
+  } else {
+    // the serial loop ran all trials; c_ holds the constraint values of the last trial whose rollout
+    // succeeded (quirk Q6), and status_ is the outcome of the very last rollout
+    last_status = __shfl(st, grp * LS + (nlive - 1));
+    if (ok_g) t_replay = 31 - __clz(ok_g);
+  }
+  if (!valid) return;
+  __threadfence_block();  // candidates written by the other lanes of this wave are read below
+
+  // ---- phase 2: copy the winner into Z_, evaluate the c_ it leaves behind (knots over lanes) ------
+  T viol = T(0);
+  if (t_replay >= 0) {
+    const unsigned rbo = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t_replay) * (unsigned)nm;
+    for (int k = t; k <= N; k += LS) {
+      T xs[n], us[m];
+      const T* cand = A.trial + (rbo + (unsigned)k * (unsigned)(LS * nm));
+#pragma unroll
+      for (int i = 0; i < n; ++i) xs[i] = cand[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) us[i] = (k < N) ? cand[n + i] : T(0);
+      int rb;
+      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+      T v;
+      knot_cost<T, n, m, true>(C, pd, kc, rb, xs, us, &v);
+      viol = max_(viol, v);
+      if (accepted) {
+        T xr[R::nP], ur[R::mP];
+#pragma unroll
+        for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[i < n ? i : 0] : T(0);
+#pragma unroll
+        for (int i = 0; i < R::mP; ++i) ur[i] = i < m ? us[i < m ? i : 0] : T(0);
+        store_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
+        if (k < N) store_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
+      }
+    }
+  } else {
+    for (int k = t; k <= N; k += LS) {  // c_ untouched since the expansion step
+      int rb;
+      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+      for (int ci = 0; ci < kc.ncon; ++ci)
+        for (int i = 0; i < kc.con[ci].p; ++i)
+          viol = max_(viol, violation(kc.con[ci].type, SOA(A.cval, rb + kc.con[ci].row_off + i)));
+    }
+  }
+  {
+    T vm = viol;
+    for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
+    viol = vm;
+  }
+  forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
+                       (double)viol, sKD, sU);
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)
