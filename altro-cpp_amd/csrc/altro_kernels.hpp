@@ -3,22 +3,23 @@
 // One batched iLQR "sweep" = three launches, each advancing EVERY still-active instance by one
 // inner iteration of altro::ilqr::iLQR<n,m>::Solve (altro/ilqr/ilqr.hpp:300-313):
 //
-//   k_expansions   grid (instance x knot): cost/AL expansion + RK4 Jacobian + knot cost.
-//                  Embarrassingly parallel (ilqr.hpp:670-677).
-//   k_backward     one lane per instance, serial in k: Riccati recursion with the reference's
-//                  restart-on-Cholesky-failure schedule (ilqr.hpp:385-445).  Next knot's
-//                  expansion is prefetched into registers while the current knot is computed.
-//   k_forward      SPECULATIVE PARALLEL LINE SEARCH: the (up to) 20 backtracking trials of
-//                  ilqr.hpp:525-545 are independent closed-loop rollouts, so each instance gets 20
-//                  lanes (3 instances per wavefront) that evaluate alpha = 1, 1/2, ... 2^-19 side
-//                  by side; a wave ballot picks the first trial the serial loop would have
-//                  accepted, so the result is identical to the reference's sequential search.  The
-//                  winner is then replayed by one lane, writing the new trajectory in place, and
-//                  the same lane runs the per-instance state machine: convergence statistics,
-//                  IsDone, dual/penalty update and the AL outer-loop transition
-//                  (ilqr.hpp:568-619, al_solver.hpp:313-401).
+//   k_expansions     grid (instance x knot): cost/AL expansion + RK4 Jacobian + knot cost.
+//                    Embarrassingly parallel (ilqr.hpp:670-677).
+//   k_backward_mfma  backward Riccati recursion on the fp64 4x4x4 matrix cores, 16 lanes per instance,
+//                    4 instances per wavefront (n = 3, m = 2, fp64);  k_backward: one lane per
+//                    instance on the VALU for every other shape.  Both keep the reference's
+//                    restart-on-Cholesky-failure schedule (ilqr.hpp:385-445) with a wave-uniform k.
+//   k_forward2       SPECULATIVE PARALLEL LINE SEARCH: the (up to) 20 backtracking trials of
+//                    ilqr.hpp:525-545 are independent closed-loop rollouts, so each instance gets 20
+//                    lanes that evaluate alpha = 1, 1/2, ... 2^-19 side by side; a wave ballot picks
+//                    the first trial the serial loop would have accepted.  Inputs are staged in LDS;
+//                    the step is pipelined over a rollout wave and a cost wave; every trial stores
+//                    its candidate trajectory so the winner is copied, not re-integrated; the same
+//                    kernel runs the per-instance state machine: convergence statistics, IsDone,
+//                    dual/penalty update and the AL outer-loop transition (ilqr.hpp:568-619,
+//                    al_solver.hpp:313-401).  k_forward is the single-wave, HBM-reading fallback.
 //
-// Instances are independent; a finished instance (phase == 0) simply masks its lanes.
+// Instances are independent; the ones still iterating are kept in a dense list rebuilt every sweep.
 #pragma once
 
 #include <type_traits>

@@ -175,25 +175,27 @@ def main():
             lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
             lib = ctypes.CDLL(lib_path)
             cores = os.cpu_count() or 1
-            sample = min(B, max(64, 8 * cores))
             omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
-            o = P.batch_turn90(omake, batch=sample, N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
-            lib.oracle_set_threads(o._h, ctypes.c_int(cores))
-            c0 = time.perf_counter()
-            o.solve()
-            cdt = time.perf_counter() - c0
-            ost = o.get_stats()
-            lib.oracle_set_threads(o._h, ctypes.c_int(1))
-            o1 = P.batch_turn90(omake, batch=min(sample, 32), N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
+            # single thread first: calibrates how many repetitions make ~10-30 s of CPU work
+            o1 = P.batch_turn90(omake, batch=64, N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
+            lib.oracle_set_threads(o1._h, ctypes.c_int(1))
             c1 = time.perf_counter()
             o1.solve()
             cdt1 = time.perf_counter() - c1
             o1st = o1.get_stats()
+            per_inst = cdt1 / 64
+            reps = int(max(1, min(64, round(20.0 / (per_inst * B)))))  # ~20 CPU-seconds in total
+            o = P.batch_turn90(omake, batch=B, N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
+            lib.oracle_set_threads(o._h, ctypes.c_int(cores))
+            c0 = time.perf_counter()
+            lib.oracle_bench_al(o._h, ctypes.c_int(reps))
+            cdt = time.perf_counter() - c0
+            ost = o.get_stats()
             cpu = {
-                "value": round(float((ost["status"] == 0).sum()) / cdt, 2), "unit": "trajectories/s",
+                "value": round(float((ost["status"] == 0).sum()) * reps / cdt, 2), "unit": "trajectories/s",
                 "cores": cores, "kind": "port",
-                "sample": f"first {sample} instances of the same seeded workload, one solve each, "
-                          f"{cores} host threads (one instance per task)",
+                "sample": f"the same seeded {B}-instance workload solved {reps}x back to back by {cores} host threads "
+                          f"(one instance per task, one thread team), about {per_inst * B * reps:.0f} CPU-seconds",
                 "single_thread_value": round(float((o1st["status"] == 0).sum()) / cdt1, 2),
                 "single_thread_ms_per_ilqr_iter": round(1e3 * cdt1 / float(o1st["iterations_total"].sum()), 4),
             }

@@ -228,6 +228,7 @@ struct Instance final : SolverBase {
   std::vector<T> K, d, P, p;
   T deltaV[2] = {0, 0};
   T rho_ = 0, drho_ = 0;
+  std::vector<T> scratch_jac_, scratch_jp_, scratch_lp_;
   int status_ = ALTRO_UNSOLVED;     // iLQR status_ (ilqr.hpp:798)
   int status_al_ = ALTRO_UNSOLVED;  // AL status_ (al_solver.hpp:222)
   Stats stats;
@@ -440,13 +441,18 @@ struct Instance final : SolverBase {
     for (int i = 0; i < n * n; ++i) hxx[i] = qc.Q[i];
     for (int i = 0; i < n * m; ++i) hxu[i] = qc.H[i];
     for (int i = 0; i < m * m; ++i) huu[i] = qc.R[i];
-    std::vector<T> jac, jp, lp;
+    // scratch reused across calls (one solver instance is only ever used by one thread at a time)
+    std::vector<T>& jac = scratch_jac_;
+    std::vector<T>& jp = scratch_jp_;
+    std::vector<T>& lp = scratch_lp_;
     for (Con& c : cons[k]) {
       const T rho = c.pen[0];
       ConEval(c, x, u);
-      jac.resize(c.p * nm);
-      jp.resize(c.p * nm);
-      lp.resize(c.p);
+      if ((int)jac.size() < c.p * nm) {
+        jac.resize(c.p * nm);
+        jp.resize(c.p * nm);
+      }
+      if ((int)lp.size() < c.p) lp.resize(c.p);
       ConJac(c, x, u, jac.data());
       for (int r = 0; r < c.p; ++r) {
         T v = c.lam[r] - rho * c.c[r];
@@ -1343,6 +1349,20 @@ altro_status oracle_solve_al(oracle_handle h) {
 altro_status oracle_solve_ilqr(oracle_handle h) {
   h->ilqr_mode = true;
   return ForAll(h, [](SolverBase& s, int) { s.SolveILQR(); });
+}
+// CPU-baseline helper for bench.py: `reps` x (re-install the initial guess, AL solve) per instance
+// inside ONE thread team, so that thread start-up is paid once.
+altro_status oracle_bench_al(oracle_handle h, int reps) {
+  h->ilqr_mode = false;
+  const altro_desc& D = h->desc;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
+    const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
+    for (int r = 0; r < reps; ++r) {
+      s.SetTrajectory(Xb, Ub);
+      s.SolveAL();
+    }
+  });
 }
 altro_status oracle_al_init(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.AlInit(); }); }
 altro_status oracle_solve_setup(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.SolveSetup(); }); }
