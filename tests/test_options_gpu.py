@@ -1,0 +1,126 @@
+"""GPU vs oracle under non-default SolverOptions and on the failure paths of the reference algorithm:
+regularisation restarts (Cholesky failure), exhausted line searches, state/control limits, warm starts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(o, g, traj_tol=1e-7, only_solved=False):
+    so, sg = o.get_stats(), g.get_stats()
+    for f in ("status", "status_ilqr", "iterations_total", "iterations_outer", "iterations_inner"):
+        assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
+    Xo, Uo = o.get_trajectory()
+    Xg, Ug = g.get_trajectory()
+    ok = (so["status"] == 0) if only_solved else np.isfinite(Xo).all(axis=(1, 2))
+    assert np.allclose(Xg[ok], Xo[ok], rtol=traj_tol, atol=traj_tol)
+    assert np.allclose(Ug[ok], Uo[ok], rtol=traj_tol, atol=traj_tol)
+    assert np.allclose(sg["regularization"], so["regularization"], rtol=1e-12)
+    return so
+
+
+@pytest.mark.parametrize("kw", [
+    dict(line_search_max_iterations=10),
+    dict(line_search_max_iterations=25, line_search_decrease_factor=1.5),  # > 20 lanes: single-wave fallback kernel
+    dict(line_search_max_iterations=4, max_iterations_inner=30),
+    dict(constraint_tolerance=1e-6),
+    dict(initial_penalty=10.0),
+    dict(check_forwardpass_bounds=0),
+    dict(bp_reg_initial=1e-3),
+    dict(max_iterations_inner=5, max_iterations_outer=4),
+    dict(max_iterations_total=7),
+    dict(cost_tolerance=1e-6, gradient_tolerance=1e-4),
+    dict(line_search_decrease_factor=3.0),
+])
+def test_option_variations(P, oracle_make, hip_make, kw):
+    o = P.batch_turn90(oracle_make, batch=12)
+    g = P.batch_turn90(hip_make, batch=12)
+    o.set_options(**kw); g.set_options(**kw)
+    o.solve(); g.solve()
+    _same(o, g, only_solved=True)
+
+
+def test_penalty_scaling_and_set_penalty(P, oracle_make, hip_make):
+    o = P.batch_turn90(oracle_make, batch=6)
+    g = P.batch_turn90(hip_make, batch=6)
+    for s in (o, g):
+        s.set_penalty_scaling(4.0)
+        s.set_options(initial_penalty=0.0)  # keep the penalties that SetPenalty installs (quirk Q8)
+        s.set_penalty(3.0)
+        s.solve()
+    so = _same(o, g, only_solved=True)
+    assert np.allclose(g.get_penalties(), o.get_penalties())
+    assert (so["max_penalty"] % 3.0 == 0).all()
+
+
+def test_warm_start_keeps_duals(P, oracle_make, hip_make):
+    # MPC pattern (al_solver.hpp:292-297): second solve with reset_duals = false, initial_penalty = 0
+    o = P.batch_turn90(oracle_make, batch=6)
+    g = P.batch_turn90(hip_make, batch=6)
+    for s in (o, g):
+        s.solve()
+        s.set_options(reset_duals=0, initial_penalty=0.0)
+        s.solve()
+    so = _same(o, g, only_solved=True)
+    assert (so["iterations_total"] <= 3).all()  # already converged: the warm start needs almost nothing
+
+
+def test_cholesky_restart_path(P, A, oracle_make, hip_make):
+    """Indefinite R makes Quu + rho I fail its Cholesky factorisation until the regularisation has grown:
+    exercises IncreaseRegularization + sweep restart (ilqr.hpp:409-427) on both backward kernels."""
+    def build(make, dtype):
+        s = make(3, 2, 40, 6, dtype)
+        h = np.float32(0.05)
+        s.set_model(A.MODEL_UNICYCLE)
+        s.set_uniform_step(h)
+        xf = np.tile(np.array([1.0, 0.5, 0.3]), (6, 1)) + np.linspace(0, 0.3, 6)[:, None]
+        R = np.diag([-2e-3, 1e-3])
+        s.set_lqr_cost(0, 40, np.eye(3) * 1e-3, R, xf, np.zeros(2))
+        s.set_lqr_cost(40, 41, np.eye(3) * 10.0, R * 0, xf, np.zeros(2))
+        s.set_initial_state(np.zeros(3))
+        s.set_trajectory(None, np.full((40, 2), 0.05))
+        return s
+    o, g = build(oracle_make, A.F64), build(hip_make, A.F64)
+    # the cost is unbounded below, so only the first iterations are compared (the iterates are chaotic later)
+    o.set_options(max_iterations_inner=4); g.set_options(max_iterations_inner=4)
+    o.solve_ilqr(); g.solve_ilqr()
+    so, sg = o.get_stats(), g.get_stats()
+    assert (so["regularization"] > 1e-8).any()  # the restart path was really taken
+    for f in ("status", "iterations_total"):
+        assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
+    assert np.allclose(sg["regularization"], so["regularization"], rtol=1e-12)
+    Xo, _ = o.get_trajectory()
+    Xg, _ = g.get_trajectory()
+    assert np.allclose(Xg, Xo, rtol=1e-6, atol=1e-8)
+
+
+def test_state_limit_and_rejected_line_search(P, oracle_make, hip_make):
+    """Huge feedforward steps: rollouts blow through state_max (kStateLimit) for large alpha and the line
+    search has to back off; with a tiny state_max every trial fails and the status must say so."""
+    o = P.batch_turn90(oracle_make, batch=4)
+    g = P.batch_turn90(hip_make, batch=4)
+    for s in (o, g):
+        s.set_options(state_max=2.5, control_max=50.0, max_iterations_inner=8, max_iterations_outer=2)
+        s.solve()
+    so = _same(o, g, traj_tol=1e-7)
+    assert set(np.unique(so["status"])) <= {0, 2, 3, 5, 6, 7}
+    o2 = P.batch_turn90(oracle_make, batch=4)
+    g2 = P.batch_turn90(hip_make, batch=4)
+    for s in (o2, g2):
+        s.set_options(state_max=1e-3, max_iterations_inner=3, max_iterations_outer=1)
+        s.solve()
+    so2 = _same(o2, g2)
+    assert (so2["status"] == 2).all()  # kStateLimit: every trial of the last line search left the box
+
+
+def test_valu_backward_matches_mfma(P, hip_make, monkeypatch):
+    """The one-lane-per-instance VALU backward pass and the MFMA one agree (same schedule, ~1e-12)."""
+    g1 = P.batch_turn90(hip_make, batch=16)
+    g1.solve()
+    monkeypatch.setenv("ALTRO_HIP_VALU_BACKWARD", "1")
+    g2 = P.batch_turn90(hip_make, batch=16)
+    g2.solve()
+    s1, s2 = g1.get_stats(), g2.get_stats()
+    assert (s1["iterations_total"] == s2["iterations_total"]).all() and (s1["status"] == s2["status"]).all()
+    ok = s1["status"] == 0
+    assert np.allclose(g1.get_trajectory()[0][ok], g2.get_trajectory()[0][ok], rtol=1e-8, atol=1e-10)
