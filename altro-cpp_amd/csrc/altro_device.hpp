@@ -110,6 +110,12 @@ struct DevArrays {
   int act_count_const;
   int* next_list;
   int* next_count;
+  // host-visible (pinned, mapped) word that receives this launch's instance count: the host sizes the
+  // next grid from it without a device-to-host copy in the stream (nullptr: not published)
+  int* host_count;
+#ifdef ALTRO_X
+  long long* dbg;
+#endif
   // optional per-iteration history [field][cap][Bp]
   double* hist;
   int* hist_len;

@@ -65,7 +65,6 @@ template <class T, class M>
 class Engine final : public EngineBase {
   static constexpr int n = M::n, m = M::m, nm = n + m;
   using R = Rec<T, n, m>;
-  static constexpr int kRing = 4;
 
  public:
   explicit Engine(const altro_desc& d) : desc_(d) {}
@@ -75,9 +74,21 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    ALTRO_HIP_CHECK(hipHostMalloc((void**)&h_counter_, kRing * sizeof(int)));
-    ALTRO_HIP_CHECK(hipMalloc((void**)&d_counter_, kRing * sizeof(int)));
-    for (int i = 0; i < kRing; ++i) ALTRO_HIP_CHECK(hipEventCreateWithFlags(&ring_ev_[i], hipEventDisableTiming));
+    return ReserveCounters(1024);
+  }
+  // one counter per sweep (device: filled by the forward kernel's atomics; host: pinned + mapped,
+  // written by the next sweep's first kernel), so no memset / copy sits between the sweeps
+  altro_status ReserveCounters(int count) {
+    if (count <= counter_cap_) return ALTRO_OK;
+    if (d_counter_) hipFree(d_counter_);
+    if (h_counter_) hipHostFree((void*)h_counter_);
+    d_counter_ = nullptr;
+    h_counter_ = nullptr;
+    counter_cap_ = 0;
+    ALTRO_HIP_CHECK(hipHostMalloc((void**)&h_counter_, (size_t)count * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    ALTRO_HIP_CHECK(hipHostGetDevicePointer((void**)&h_counter_dev_, (void*)h_counter_, 0));
+    ALTRO_HIP_CHECK(hipMalloc((void**)&d_counter_, (size_t)count * sizeof(int)));
+    counter_cap_ = count;
     return ALTRO_OK;
   }
 
@@ -353,7 +364,10 @@ class Engine final : public EngineBase {
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
       if (!force_valu_backward_) {
-        hipLaunchKernelGGL((k_backward_mfma<M>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+        if (A.record_ctg)
+          hipLaunchKernelGGL((k_backward_mfma<M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+        else
+          hipLaunchKernelGGL((k_backward_mfma<M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         return;
       }
     }
@@ -392,9 +406,7 @@ class Engine final : public EngineBase {
     if (A_.hist) hipFree(A_.hist);
     if (A_.hist_len) hipFree(A_.hist_len);
     if (d_counter_) hipFree(d_counter_);
-    if (h_counter_) hipHostFree(h_counter_);
-    for (auto& e : ring_ev_)
-      if (e) hipEventDestroy(e);
+    if (h_counter_) hipHostFree((void*)h_counter_);
     for (auto& e : prof_ev_) hipEventDestroy(e);
     if (stream_) hipStreamDestroy(stream_);
   }
@@ -726,7 +738,7 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.x0, (size_t)R::nP * bp);
     ALTRO_ALLOC(A_.X, (size_t)(N_ + 1) * R::nP * bp);
     ALTRO_ALLOC(A_.U, (size_t)N_ * R::mP * bp);
-    ALTRO_ALLOC(A_.EXP, (size_t)(N_ + 1) * R::EP * bp);
+    ALTRO_ALLOC(A_.EXP, (size_t)(N_ + 1) * R::EP * bp + R::EP);  // + a zeroed pad record (k_backward_mfma)
     ALTRO_ALLOC(A_.costs, (size_t)(N_ + 1) * bp);
     ALTRO_ALLOC(A_.KD, (size_t)N_ * R::KP * bp);
     ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
@@ -848,24 +860,34 @@ class Engine final : public EngineBase {
     int sweeps = 0;
     bool finished = false;
     // Sweep i works on the instances that sweep i-1 left active: a dense list built by the forward
-    // kernel (two list buffers, a ring of counters that the host reads back one sweep late).  The
-    // grid is sized with the newest count the host knows -- counts only shrink, so it is an upper
-    // bound -- and tail sweeps launch a handful of workgroups instead of B/3.
+    // kernel (two list buffers, one counter per sweep).  Sweep i+1's first kernel publishes the
+    // length of its list (= what sweep i left) to pinned host memory; the host polls that word,
+    // stays one sweep ahead of the device, and sizes each grid with the newest count it knows --
+    // counts only shrink, so it is an upper bound -- so tail sweeps launch a handful of workgroups.
+    {
+      altro_status rs = ReserveCounters(max_sweeps + 2);
+      if (rs != ALTRO_OK) return rs;
+    }
+    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 2) * sizeof(int), stream_));
+#ifdef ALTRO_X
+    if (!A_.dbg) hipMalloc((void**)&A_.dbg, 24 * sizeof(long long));
+#endif
+    for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
     auto enqueue_sweep = [&](int i) -> altro_status {
-      const int slot = i % kRing;
-      ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_ + slot, 0, sizeof(int), stream_));
       DevArrays<T> A = A_;
       if (i == 0) {
         A.act_list = nullptr;
         A.act_count = nullptr;
         A.act_count_const = B_;
+        A.host_count = nullptr;
       } else {
         A.act_list = d_list_[i % 2];
-        A.act_count = d_counter_ + ((i - 1) % kRing);
+        A.act_count = d_counter_ + (i - 1);
+        A.host_count = h_counter_dev_ + (i - 1);
       }
       A.next_list = d_list_[(i + 1) % 2];
-      A.next_count = d_counter_ + slot;
+      A.next_count = d_counter_ + i;
       const int ninst = std::max(1, known_count);
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0);
@@ -874,32 +896,62 @@ class Engine final : public EngineBase {
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
       LaunchForward(A, d, mode, 0, ninst);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-      ALTRO_HIP_CHECK(hipMemcpyAsync(h_counter_ + slot, d_counter_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
-      ALTRO_HIP_CHECK(hipEventRecord(ring_ev_[slot], stream_));
       timing_.launches += 3;
       return ALTRO_OK;
+    };
+    // count left by sweep j, published by sweep j+1 (which must already be enqueued)
+    auto wait_count = [&](int j, int* out) -> altro_status {
+      unsigned spins = 0;
+      for (;;) {
+        const int v = __atomic_load_n(&h_counter_[j], __ATOMIC_ACQUIRE);
+        if (v >= 0) {
+          *out = v;
+          return ALTRO_OK;
+        }
+        if ((++spins & 0x3ff) == 0) {
+          const hipError_t q = hipStreamQuery(stream_);
+          if (q == hipSuccess) {  // stream drained: the word must be there, or the launch failed
+            const int v2 = __atomic_load_n(&h_counter_[j], __ATOMIC_ACQUIRE);
+            if (v2 >= 0) {
+              *out = v2;
+              return ALTRO_OK;
+            }
+            ALTRO_HIP_CHECK(hipGetLastError());
+            err_ = "sweep counter was never published";
+            return ALTRO_HIP_ERROR;
+          }
+          if (q != hipErrorNotReady) ALTRO_HIP_CHECK(q);
+        }
+      }
     };
     altro_status st = enqueue_sweep(0);
     if (st != ALTRO_OK) return st;
     sweeps = 1;
     while (!finished) {
-      // keep one sweep in flight beyond the one whose counter we are about to read
-      if (sweeps < max_sweeps) {
-        st = enqueue_sweep(sweeps);
-        if (st != ALTRO_OK) return st;
-        sweeps++;
-      }
-      const int check = sweeps - 2 >= 0 ? sweeps - 2 : 0;
-      ALTRO_HIP_CHECK(hipEventSynchronize(ring_ev_[check % kRing]));
-      known_count = h_counter_[check % kRing];
-      if (known_count == 0) finished = true;
-      if (!finished && sweeps >= max_sweeps) {
-        ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+      if (sweeps >= max_sweeps) {  // the iteration caps bound the sweeps; nothing left to learn
         finished = true;
+        break;
       }
+      st = enqueue_sweep(sweeps);  // publishes the count left by sweep (sweeps - 1)
+      if (st != ALTRO_OK) return st;
+      sweeps++;
+      st = wait_count(sweeps - 2, &known_count);
+      if (st != ALTRO_OK) return st;
+      if (known_count == 0) finished = true;
     }
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     ALTRO_HIP_CHECK(hipGetLastError());
+#ifdef ALTRO_X
+    {
+      long long h[24];
+      hipMemcpy(h, A_.dbg, sizeof(h), hipMemcpyDeviceToHost);
+      fprintf(stderr, "stamps(cycles rel. to wave0 entry): R:");
+      for (int i = 0; i < 4; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
+      fprintf(stderr, "  C:");
+      for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
+      fprintf(stderr, "  B: %lld %lld\n", h[17] - h[16], h[18] - h[16]);
+    }
+#endif
     timing_.sweeps = sweeps;
     if (prof) {
       float ms = 0;
@@ -946,9 +998,10 @@ class Engine final : public EngineBase {
   std::vector<int> knot_class_, knot_rowbase_;
   std::vector<void*> allocs_;
   hipStream_t stream_ = nullptr;
-  int* h_counter_ = nullptr;
+  volatile int* h_counter_ = nullptr;  // pinned + mapped: one word per sweep
+  int* h_counter_dev_ = nullptr;       // the same words as the device sees them
   int* d_counter_ = nullptr;
-  hipEvent_t ring_ev_[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  int counter_cap_ = 0;
   std::vector<hipEvent_t> prof_ev_;
   altro_timing timing_{};
   std::string err_;

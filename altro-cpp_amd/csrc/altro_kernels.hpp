@@ -77,6 +77,11 @@ __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const Pro
   using R = Rec<T, n, m>;
   const int b = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
   const int k = blockIdx.y;
+  if (A.host_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    // tell the host how many instances this sweep works on (it is polling the mapped word)
+    __hip_atomic_store(A.host_count, A.act_count ? *A.act_count : A.act_count_const, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (b < 0) return;
   const int N = A.N;
   const unsigned Bp = A.Bp;
@@ -234,9 +239,46 @@ ALTRO_DEV double rsqrt_nr(double x) {
   y = fma(y, e, y);
   return y;
 }
+ALTRO_DEV double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  // two Newton steps on the ~2^-26 hardware estimate: y <- y + y (1 - x y)
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  return y;
+}
 ALTRO_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
-template <class M>
+// Cross-lane moves of the MFMA layout without the LDS crossbar.  quad_bcast<J>: every lane reads the
+// value of lane c = J of its own quad (one instance's row r) -- a DPP quad_perm.  rows01: the values
+// that rows r = 0 and r = 1 (lanes 0-15 / 16-31) hold, delivered to both rows (v_permlane16_swap
+// exchanges row 1 of its first operand with row 0 of its second).  Rows 2 and 3 receive their own
+// pair (2, 3), which the callers never use.
+template <int J>
+ALTRO_DEV double quad_bcast(double x) {
+  constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+ALTRO_DEV void rows01(double x, double& from_row0, double& from_row1) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto bb = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  from_row0 = __hiloint2double((int)bb[0], (int)a[0]);
+  from_row1 = __hiloint2double((int)bb[1], (int)a[1]);
+}
+// lanes 32-63 receive what lanes 0-31 hold (v_permlane32_swap); lanes 0-31 keep their value
+ALTRO_DEV int lower_half(int x) {
+  const auto a = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return (int)a[0];
+}
+
+constexpr int kBwdAhead = 6;    // knots per prefetch block of the MFMA backward pass
+constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bulk stores (4 instances: 32 KiB)
+
+template <class M, bool CTG>
 __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, DevOpts o, int all) {
   static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
   constexpr int n = 3, m = 2;
@@ -249,6 +291,13 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   const int b = inst_on ? b0 : 0;
   const int N = A.N;
   const unsigned Bp = A.Bp;
+#ifdef ALTRO_X
+  const bool dbg_on = A.dbg && blockIdx.x == 0 && lane == 0 && A.it_total[b] == 60;
+#define BSTAMP(i) if (dbg_on) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
+#else
+#define BSTAMP(i)
+#endif
+  BSTAMP(16);
   // element of each tile this lane owns (offset inside the expansion record; -1: structural zero)
   const int offA = (r < n && c < n) ? R::oAB + r + c * n : -1;
   const int offB = (r < n && c < m) ? R::oAB + n * n + r + c * n : -1;
@@ -257,91 +306,209 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   const int off3 = (r < m && c < m) ? R::oLuu + r + c * m : -1;                        // luu
   const int offKD = (r < m) ? (c < n ? R::oK + r + c * m : R::oD + r) : -1;            // [K | d]
   const int offCT = (r < n) ? (c < n ? R::oP + r + c * n : R::op + r) : -1;            // [P | p]
-  auto ld = [&](const double* rec, int off) { return off >= 0 ? rec[off] : 0.0; };
+  // Every tile load is unconditional: lanes that own a structural zero read the zeroed pad behind the
+  // last record with stride 0, so the loop carries no exec-mask branches.  Indices are 32-bit
+  // elements (guarded at upload).
+  const unsigned stride = Bp * (unsigned)R::EP;
+  const unsigned zidx = (unsigned)(N + 1) * stride;
+  const unsigned rec0 = (unsigned)b * (unsigned)R::EP;
+  const unsigned sA = offA >= 0 ? stride : 0u, sB = offB >= 0 ? stride : 0u, s1 = off1 >= 0 ? stride : 0u,
+                 s2 = off2 >= 0 ? stride : 0u, s3 = off3 >= 0 ? stride : 0u;
+  const unsigned bA = offA >= 0 ? rec0 + offA : zidx, bB = offB >= 0 ? rec0 + offB : zidx,
+                 b1 = off1 >= 0 ? rec0 + off1 : zidx, b2 = off2 >= 0 ? rec0 + off2 : zidx,
+                 b3 = off3 >= 0 ? rec0 + off3 : zidx;
+  const double* __restrict__ E = A.EXP;
 
-  double J0 = 0.0;
-#pragma unroll 8
-  for (int k = 0; k <= N; ++k) J0 += A.costs[(unsigned)k * Bp + (unsigned)b];
+  struct Tiles {
+    double tA, tB, t1, t2, t3;
+  };
   double rho = A.rho_reg[b], drho = A.drho[b];
   double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
   int max_reg_count = 0;
   int status = A.status[b];
   bool need = inst_on && N > 0;
-  const int lane_d = (lane & 0x0f) | 0x03;  // lane (r=0, c=3) of this instance: row 0 of the vector column
-  while (__ballot(need) != 0ull) {
-    // CalcTerminalCostToGo: [P|p] = [lxx|lx] of knot N
-    double Pp = ld(RECP(A.EXP, N, R::EP), off1);
-    if (A.record_ctg && need && offCT >= 0) RECP(A.CTG, N, R::CP)[offCT] = Pp;
-    bool running = need;
-    const double* rec = RECP(A.EXP, N - 1, R::EP);
-    double tA = ld(rec, offA), tB = ld(rec, offB), t1 = ld(rec, off1), t2 = ld(rec, off2), t3 = ld(rec, off3);
-    for (int k = N - 1; k >= 0; --k) {
-      const double Pm = (c < n) ? Pp : 0.0;  // P without the vector column
-      const double WA = mfma4(Pm, tA, 0.0);
-      const double WB = mfma4(Pm, tB, 0.0);
-      const double Waug = (c < n) ? WA : Pp;  // [P A | p]
-      const double Q1 = mfma4(tA, Waug, t1);  // [Qxx | Qx]
-      const double Q2 = mfma4(tB, Waug, t2);  // [Qux | Qu]
-      const double Q3 = mfma4(tB, WB, t3);    // Quu
-      // prefetch the next knot's tiles while the Cholesky / gain / cost-to-go half executes
-      if (k > 0) {
-        rec = RECP(A.EXP, k - 1, R::EP);
-        tA = ld(rec, offA);
-        tB = ld(rec, offB);
-        t1 = ld(rec, off1);
-        t2 = ld(rec, off2);
-        t3 = ld(rec, off3);
+  // Tile loads run a block of kBwdAhead knots ahead of the recursion: HBM / Infinity-Cache latency
+  // (~1 us) is longer than one knot of the dependent chain (~0.3 us).  Two register blocks ping-pong;
+  // the loads of the next block are issued right after the first knot of the current one, so every
+  // wait -- including the conservative one the compiler places at the loop header -- only covers
+  // loads that are at least kBwdAhead - 1 knots old.
+  constexpr int H = kBwdAhead;
+  int kl;
+  unsigned iA, iB, i1, i2, i3;
+  Tiles Sa[H], Sb[H];
+  double Pp;
+  auto issue = [&](Tiles& S) __attribute__((always_inline)) {
+    // unconditional (past knot 0 the cursor stays put and knot 0 is fetched again): a load count that
+    // does not depend on control flow lets the compiler wait for exactly the set it needs
+    S.tA = E[iA];
+    S.tB = E[iB];
+    S.t1 = E[i1];
+    S.t2 = E[i2];
+    S.t3 = E[i3];
+    const unsigned live = kl > 0 ? 0xffffffffu : 0u;
+    iA -= sA & live;
+    iB -= sB & live;
+    i1 -= s1 & live;
+    i2 -= s2 & live;
+    i3 -= s3 & live;
+    kl--;
+  };
+  auto prime = [&]() __attribute__((always_inline)) {
+    Pp = E[b1 + (unsigned)N * s1];  // CalcTerminalCostToGo: [P|p] = [lxx|lx] of knot N
+    kl = N > 1 ? N - 1 : 0;
+    iA = bA + (unsigned)kl * sA;
+    iB = bB + (unsigned)kl * sB;
+    i1 = b1 + (unsigned)kl * s1;
+    i2 = b2 + (unsigned)kl * s2;
+    i3 = b3 + (unsigned)kl * s3;
+#pragma unroll
+    for (int j = 0; j < H; ++j) issue(Sa[j]);
+  };
+  prime();  // in flight while the running cost is summed
+  bool primed = true;
+
+  // Running cost of the current trajectory, summed in knot order (ilqr.hpp:326-334): the 16 lanes of
+  // the instance fetch the per-knot costs side by side, then hand them over one by one.
+  double J0 = 0.0;
+  {
+    const int q = r * 4 + c;  // 0..15 inside the instance
+    for (int base = 0; base <= N; base += 128) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = base + j * 16 + q;
+        v[j] = A.costs[(unsigned)(k <= N ? k : N) * Bp + (unsigned)b];
       }
-      // Quu entries to every lane of the instance: lanes (0,0), (1,0), (1,1) of the Quu tile
-      const int base = lane & 0x0c;  // 4*blk
-      const double q00 = __shfl(Q3, base + 0);
-      const double q10 = __shfl(Q3, base + 16);
-      const double q11 = __shfl(Q3, base + 17);
-      // Eigen::LLT of Quu + rho I (lower); a pivot <= 0 is a failure (knot_point_function_type.hpp:197-211)
-      // only 1/l11 and 1/l22 are needed: one refined reciprocal square root each (v_rsq_f64 + two
-      // Newton steps, ~1 ulp) instead of sqrt followed by a division on the dependent chain
-      const double x1 = q00 + rho;
-      const double i11 = rsqrt_nr(x1);
-      const double l21 = q10 * i11;
-      const double x2 = (q11 + rho) - l21 * l21;
-      const double i22 = rsqrt_nr(x2);
-      const bool fail = (x1 <= 0.0) || (x2 <= 0.0);
-      // (L L^T)^-1 = L^-T L^-1 with L^-1 = [i11 0; i21 i22]
-      const double i21 = -(l21 * i11) * i22;
-      const double m00 = i11 * i11 + i21 * i21, m10 = i21 * i22, m11 = i22 * i22;
-      const double Minv = (r < m && c < m) ? (r == c ? (r == 0 ? m00 : m11) : m10) : 0.0;
-      const double KD = -mfma4(Minv, Q2, 0.0);  // [K | d], gains from the REGULARISED Quu (quirk Q3)
-      const double G = mfma4(Q3, KD, 0.0);      // Quu [K | d] with the UN-regularised Quu
-      const double KDm = (c < n) ? KD : 0.0, Q2m = (c < n) ? Q2 : 0.0;
-      double Pn = mfma4(KDm, G, Q1);  // + K^T Quu [K|d]
-      Pn = mfma4(KDm, Q2, Pn);        // + K^T [Qux|Qu]
-      Pn = mfma4(Q2m, KD, Pn);        // + Qux^T [K|d]
-      // expected cost decrease: d^T Qu and 0.5 d^T Quu d (rows 0,1 of the vector column)
-      const double e0 = KD * Q2, e1 = KD * G;
-      const double v0 = __shfl(e0, lane_d) + __shfl(e0, lane_d + 16);
-      const double v1 = __shfl(e1, lane_d) + __shfl(e1, lane_d + 16);
-      if (running) {
-        if (fail) {
-          // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
-          increase_reg(o, &rho, &drho);
-          if (rho >= o.bp_reg_max) max_reg_count++;
-          if (max_reg_count >= o.bp_reg_fail_threshold) {
-            status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
-            need = false;
-          }
-          running = false;
-        } else {
-          Pp = Pn;
-          dV0 += v0;
-          dV1 += 0.5 * v1;
-          if (offKD >= 0) RECP(A.KD, k, R::KP)[offKD] = KD;
-          if (A.record_ctg && offCT >= 0) RECP(A.CTG, k, R::CP)[offCT] = Pn;
-          if (k == 0) need = false;  // sweep completed
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (base + j * 16 > N) break;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+          const double t = __shfl(v[j], (qq >> 2) * 16 + blk * 4 + (qq & 3));
+          if (base + j * 16 + qq <= N) J0 += t;
         }
       }
     }
   }
-  if (!inst_on || r != 0 || c != 0) return;
+
+  BSTAMP(17);
+  // The gains are collected in LDS and written out in bulk: a store in the loop would share the memory
+  // counter with the prefetched tiles (loads and stores retire out of order with respect to each
+  // other), and every wait on a tile would have to drain the whole queue.
+  __shared__ double sKD[kBwdChunk * 4 * R::KP + kBlock];  // + one junk slot per lane
+  double* const sink = A.trial + lane;  // CTG build only: junk sink of the lanes that own no element
+  while (__ballot(need) != 0ull) {
+    if (!primed) prime();  // restart after a failed factorisation
+    primed = false;
+    if (CTG) *((need && offCT >= 0) ? RECP(A.CTG, N, R::CP) + offCT : sink) = Pp;
+    bool running = need;
+    // write the buffered knots (k_top, k_top - 1, ... in slots 0 .. slot-1) of the four instances out
+    int slot = 0, k_top = N - 1;
+    auto flush = [&]() __attribute__((always_inline)) {
+      for (int i = lane; i < slot * 4 * R::KP; i += kBlock) {
+        const int e = i % R::KP, ib = (i / R::KP) % 4, sl = i / (4 * R::KP);
+        const int bi = __shfl(b, ib * 4);  // instance of block ib (its lane r = 0, c = 0)
+        const int on = __shfl(inst_on ? 1 : 0, ib * 4);
+        if (on) A.KD[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)bi) * R::KP + e] = sKD[i];
+      }
+      k_top -= slot;
+      slot = 0;
+    };
+    auto step = [&](int k, Tiles& S) __attribute__((always_inline)) {
+      // The vector column / the gain rows ride along unmasked: used as a LEFT operand they only add
+      // a fourth output row, which meets the structurally-zero fourth row of A and B in every later
+      // product (and is never stored).
+      const double WA = mfma4(Pp, S.tA, 0.0);
+      const double WB = mfma4(Pp, S.tB, 0.0);
+      const double Waug = (c < n) ? WA : Pp;      // [P A | p]
+      const double Q1 = mfma4(S.tA, Waug, S.t1);  // [Qxx | Qx]
+      const double Q2 = mfma4(S.tB, Waug, S.t2);  // [Qux | Qu]
+      const double Q3 = mfma4(S.tB, WB, S.t3);    // Quu
+      // Quu entries to rows 0 and 1 of the instance
+      double q00, q10, q01, q11;
+      rows01(quad_bcast<0>(Q3), q00, q10);
+      rows01(quad_bcast<1>(Q3), q01, q11);
+      (void)q01;
+      // (Quu + rho I)^-1.  Eigen::LLT fails on a pivot <= 0 (knot_point_function_type.hpp:197-211);
+      // its pivots are a and det / a, so the verdict is a <= 0 || det <= 0, and the inverse of the 2x2
+      // SPD matrix is the adjugate over det: one reciprocal on the dependent chain instead of two
+      // reciprocal square roots in sequence (same O(cond) * eps accuracy as forming L^-T L^-1).
+      const double qa = q00 + rho, qc = q11 + rho;
+      const double det = fma(qa, qc, -(q10 * q10));
+      const double rd = rcp_nr(det);
+      // rows 2 and 3 did not receive Quu: they take the verdict of rows 0 / 1
+      const bool fail = lower_half(((qa <= 0.0) || (det <= 0.0)) ? 1 : 0) != 0;
+      // -(Quu + rho I)^-1, this lane's entry (zero outside the 2x2 block)
+      // (rows 2 and 3 hold det = 0 / rd = inf: the zero must be selected after the product)
+      const double MinvNeg = (r < m && c < m) ? (r == c ? (r == 0 ? -qc : -qa) : q10) * rd : 0.0;
+      const double KD = mfma4(MinvNeg, Q2, 0.0);  // [K | d], gains from the REGULARISED Quu (quirk Q3)
+      const double G = mfma4(Q3, KD, 0.0);        // Quu [K | d] with the UN-regularised Quu
+      // [P|p] = [Qxx|Qx] + K^T [Qux|Qu] + Qux^T [K|d] + K^T Quu [K|d]; the term that needs G goes last
+      double Pn = mfma4(Q2, KD, Q1);
+      Pn = mfma4(KD, Q2, Pn);
+      Pn = mfma4(KD, G, Pn);
+      // expected cost decrease: d^T Qu and 0.5 d^T Quu d (rows 0,1 of the vector column; the sums
+      // are formed in every lane, lane (r=0, c=3) owns the meaningful one)
+      double e00, e01, e10, e11;
+      rows01(KD * Q2, e00, e01);
+      rows01(KD * G, e10, e11);
+      const double v0 = e00 + e01, v1 = e10 + e11;
+      // Branch-free state update: a divergent branch costs ~50 cycles on this chain.  The only real
+      // branch is the (wave-uniform, rare) regularisation increase.
+      const bool failed = running && fail;
+      const bool commit = running && !fail;
+      running = commit;
+      bool gave_up = false;
+      if (__ballot(failed) != 0ull) {
+        // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
+        double rho2 = rho, drho2 = drho;
+        increase_reg(o, &rho2, &drho2);
+        const int cnt2 = max_reg_count + (rho2 >= o.bp_reg_max ? 1 : 0);
+        const bool give = cnt2 >= o.bp_reg_fail_threshold;
+        rho = failed ? rho2 : rho;
+        drho = failed ? drho2 : drho;
+        max_reg_count = failed ? cnt2 : max_reg_count;
+        status = (failed && give) ? (int)ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED : status;
+        gave_up = failed && give;
+      }
+      Pp = commit ? Pn : Pp;
+      dV0 += commit ? v0 : 0.0;
+      dV1 += commit ? 0.5 * v1 : 0.0;
+      // gains into the LDS block (lanes with nothing to store hit a junk slot)
+      sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
+      if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = Pn;
+      need = need && !gave_up && !(commit && k == 0);
+      slot++;
+    };
+    int k = N - 1;
+    // one block of H knots from `Cur`; false once knot 0 has been processed
+    auto block = [&](Tiles* Cur, Tiles* Nxt) __attribute__((always_inline)) -> bool {
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        step(k - j, Cur[j]);
+        if (j == 0) {
+#pragma unroll
+          for (int jj = 0; jj < H; ++jj) issue(Nxt[jj]);
+        }
+        if (k - j == 0) return false;
+      }
+      k -= H;
+      if (slot + H > kBwdChunk) flush();
+      return true;
+    };
+    for (;;) {
+      if (!block(Sa, Sb)) break;
+      if (!block(Sb, Sa)) break;
+    }
+    flush();
+  }
+  BSTAMP(18);
+  if (!inst_on || r != 0) return;
+  if (c == 3) {  // the lane that holds row 0 of the vector column
+    A.dV0[b] = dV0;
+    A.dV1[b] = dV1;
+  }
+  if (c != 0) return;
   A.J0[b] = J0;
   if (A.need_init_cost[b]) {
     A.initial_cost[b] = J0;
@@ -351,8 +518,6 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   decrease_reg(o, &rho, &drho);
   A.rho_reg[b] = rho;
   A.drho[b] = drho;
-  A.dV0[b] = dV0;
-  A.dV1[b] = dV1;
   A.status[b] = status;
 }
 
@@ -663,6 +828,26 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   const int N = A.N;
   // ---- phase 3: per-instance state machine.  Lane 0 of the instance takes the decisions; the
   //      row sweeps of the AL transition (dual and penalty updates) are spread over its 20 lanes.
+  // rejected step: the controls are unchanged and quirk Q12 evaluates the gradient measure with the
+  // current Z_.  The per-knot terms are spread over the instance's lanes; the sum keeps the serial
+  // order k = 0 .. N-1 of ilqr.hpp:574-583 (lanes hand their term over in knot order).
+  double gsum_rej = 0.0;
+  if (!accepted && mode != kFwdStepOnly) {
+    for (int base = 0; base < N; base += LS) {
+      const int k = base + t;
+      T mx = T(0);
+      if (k < N) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          const T dv = sKD ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
+          const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
+          mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
+        }
+      }
+      const int cnt = (N - base) < LS ? (N - base) : LS;
+      for (int j = 0; j < cnt; ++j) gsum_rej += (double)__shfl(mx, grp * LS + j);
+    }
+  }
   int inner_done = 0;
   if (t == 0) {
     if (accepted) {
@@ -679,20 +864,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     if (mode == kFwdStepOnly) {
       A.viol[b] = viol;
     } else {
-      double gsum = g_sel;
-      if (!accepted) {  // rejected step: the controls are unchanged (quirk Q12 uses the current Z_)
-        gsum = 0.0;
-        for (int k = 0; k < N; ++k) {
-          T mx = T(0);
-#pragma unroll
-          for (int i = 0; i < m; ++i) {
-            const T dv = sKD ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
-            const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
-            mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
-          }
-          gsum += (double)mx;
-        }
-      }
+      const double gsum = accepted ? g_sel : gsum_rej;
       inner_done = conv_stats_and_done(A, o, b, gsum, viol) ? 1 : 0;
     }
   }
@@ -823,7 +995,9 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
         J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
       } else {
         // quadratic cost (diagonal Q, R guaranteed by the host for the fast kinds)
-        T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+        T Jk = T(0);
+      {
+      T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
         for (int i = 0; i < n; ++i) {
           xQx += xb[i] * (RC.Qd[i] * xb[i]);
@@ -834,7 +1008,7 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
           uRu += ub[i] * (RC.Rd[i] * ub[i]);
           ru += RC.r[i] * ub[i];
         }
-        T Jk = T(0.5) * xQx + T(0.5) * uRu + qx + ru + RC.c;
+        Jk = T(0.5) * xQx + T(0.5) * uRu + qx + ru + RC.c;
         auto circle_term = [&]() {
           const T rho = C.pen(rb + c_row);
           T a = T(0), bsum = T(0);
@@ -880,7 +1054,8 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
           bound_term();
           circle_term();
         }
-        J += (double)Jk;
+        }
+      J += (double)Jk;
       }
       if (valid) {  // idle lanes must not touch instance 0's candidates
         T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
@@ -1324,6 +1499,13 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   const bool valid = b0 >= 0;
   if (__ballot(valid) == 0ull) return;  // both waves take the same decision
   const int b = valid ? b0 : 0;
+#ifdef ALTRO_X
+  const bool dbg_on = A.dbg && blockIdx.x == 0 && lane == 0 && A.it_total[b] == 60;
+#define STAMP(i) if (dbg_on) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
+#else
+#define STAMP(i)
+#endif
+  STAMP(wave * 8 + 0);
 
   // ---- phase 0: stage the instance's read-only inputs in LDS (both waves copy) ------------------
   const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, R::V};
@@ -1339,15 +1521,20 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
   {
     for (int i = threadIdx.x; i < pd->npool; i += 2 * kBlock) sPool[i] = A.pool[i];
-    if (valid) {
-      using V = typename VecOf<T>::type;
-      constexpr int VN = R::V;
-      const int tt = t + LS * wave;
-      constexpr int kStride = 2 * LS;
+    // every thread of the workgroup copies, one instance after the other (wave-uniform instance)
+    using V = typename VecOf<T>::type;
+    constexpr int VN = R::V;
+    constexpr int kStride = 2 * kBlock;
+    constexpr int kDepth = 8;
+    const int tt = threadIdx.x;
+    for (int g = 0; g < per_wave; ++g) {
+      const int bg = instance_of_slot(A, blockIdx.x * per_wave + g, all);
+      if (bg < 0) continue;
+      T* gm = reinterpret_cast<T*>(smem_raw) + g * L.total();
       auto stage_rec = [&](T* dst, const T* src, int knots, int EP) {
+        const int b = bg;
         const int per = EP / VN;
         const int total = knots * per;
-        constexpr int kDepth = 8;
         for (int i0 = tt; i0 < total; i0 += kStride * kDepth) {
           V v[kDepth];
 #pragma unroll
@@ -1365,13 +1552,12 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
         }
       };
       auto stage_soa = [&](T* dst, const T* src, int cnt) {
-        constexpr int kDepth = 8;
         for (int i0 = tt; i0 < cnt; i0 += kStride * kDepth) {
           T v[kDepth];
 #pragma unroll
           for (int j = 0; j < kDepth; ++j) {
             const int i = i0 + j * kStride;
-            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)b] : T(0);
+            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)bg] : T(0);
           }
 #pragma unroll
           for (int j = 0; j < kDepth; ++j) {
@@ -1380,15 +1566,22 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
           }
         }
       };
-      stage_rec(sX, A.X, N + 1, R::nP);
-      stage_rec(sU, A.U, N, R::mP);
-      stage_rec(sKD, A.KD, N, R::KP);
-      stage_soa(sLam, A.lam, L.nR);
-      stage_soa(sPen, A.pen, L.nR);
-      stage_soa(sIp, A.ipool, L.nS);
+      T* gX = gm;
+      T* gU = gX + L.nX;
+      T* gKD = gU + L.nU;
+      T* gLam = gKD + L.nKD;
+      T* gPen = gLam + L.rowsP();
+      T* gIp = gPen + L.rowsP();
+      stage_rec(gX, A.X, N + 1, R::nP);
+      stage_rec(gU, A.U, N, R::mP);
+      stage_rec(gKD, A.KD, N, R::KP);
+      stage_soa(gLam, A.lam, L.nR);
+      stage_soa(gPen, A.pen, L.nR);
+      stage_soa(gIp, A.ipool, L.nS);
     }
   }
   __syncthreads();
+  STAMP(wave * 8 + 1);
 
   T x0[R::nP];
   load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
@@ -1453,7 +1646,9 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
     flags[lane] = ok ? 1 : 0;
     flags[kBlock + lane] = st;
+    STAMP(2);
     lds_barrier();  // barrier N
+    STAMP(3);
     return;
   }
 
@@ -1478,7 +1673,9 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     }
 #undef ALTRO_RUN
   }
+  STAMP(8 + 2);
   lds_barrier();  // barrier N: terminal state and rollout outcome
+  STAMP(8 + 3);
   const bool ok = flags[lane] != 0;
   const int st = flags[kBlock + lane];
   {
@@ -1530,6 +1727,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     if (ok_g) t_replay = 31 - __clz(ok_g);
   }
   if (!valid) return;
+  STAMP(8 + 4);
   __threadfence_block();  // candidates written by the other lanes of this wave are read below
 
   // ---- phase 2: copy the winner into Z_, evaluate the c_ it leaves behind (knots over lanes) ------
@@ -1572,8 +1770,10 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
   }
+  STAMP(8 + 5);
   forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU);
+  STAMP(8 + 6);
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)
