@@ -379,7 +379,7 @@ class Engine final : public EngineBase {
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS
-      hipLaunchKernelGGL((k_forward2<T, M>), grid, dim3(2 * kBlock), fwd_lds_bytes_, stream_, A, pd_, d, mode, all,
+      hipLaunchKernelGGL((k_forward2<T, M>), grid, dim3(2 * kBlock), fwd_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, all,
                          fwd_per_wave_);
     } else {
       // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)

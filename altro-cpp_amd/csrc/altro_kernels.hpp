@@ -814,13 +814,66 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
   A.status[b] = st;  // the status change belongs to IsDone, which the step-level API does not call
 }
 
+// Per-instance scalars that the state machine of the forward pass reads: fetched at kernel start so the
+// ~1 us of memory latency hides behind the rollout instead of sitting at the end of the kernel.
+struct InstPre {
+  int it_inner, it_total;
+  double initial_cost, cost_cur, cost_prev, rho_reg, drho;
+};
+template <class T>
+ALTRO_DEV InstPre load_inst_pre(const DevArrays<T>& A, int b) {
+  InstPre p;
+  p.it_inner = A.it_inner[b];
+  p.it_total = A.it_total[b];
+  p.initial_cost = A.initial_cost[b];
+  p.cost_cur = A.cost_cur[b];
+  p.cost_prev = A.cost_prev[b];
+  p.rho_reg = A.rho_reg[b];
+  p.drho = A.drho[b];
+  return p;
+}
+// conv_stats_and_done on pre-fetched scalars; cost_cur / status are the values this forward pass set
+template <class T>
+ALTRO_DEV bool conv_stats_and_done_pre(const DevArrays<T>& A, const DevOpts& o, int b, double gsum, double viol,
+                                       const InstPre& pre, double cost_cur, int status) {
+  const double grad = A.N > 0 ? gsum / (double)A.N : 0.0;
+  const int it = pre.it_inner;
+  const double dJ = (it == 0) ? pre.initial_cost - cost_cur : pre.cost_prev - cost_cur;
+  A.it_inner[b] = it + 1;
+  const int itot = pre.it_total + 1;
+  A.it_total[b] = itot;
+  A.dJ[b] = dJ;
+  A.viol[b] = viol;
+  A.grad[b] = grad;
+  if (A.hist) {
+    A.status[b] = status;  // hist_push snapshots the stored row
+    hist_push(A, b);
+  }
+  A.cost_prev[b] = cost_cur;  // NewIteration copies the row (solver_stats.cpp:54-66)
+  bool done = false;
+  if (dJ < o.cost_tolerance && grad < o.gradient_tolerance) {
+    status = ALTRO_SOLVED;
+    done = true;
+  } else if (it + 1 >= o.max_iterations_inner) {
+    status = ALTRO_MAX_INNER_ITERATIONS;
+    done = true;
+  } else if (itot >= o.max_iterations_total) {
+    status = ALTRO_MAX_ITERATIONS;
+    done = true;
+  } else if (status != ALTRO_UNSOLVED) {
+    done = true;
+  }
+  A.status[b] = status;
+  return done;
+}
+
 // Phase 3 of the forward pass: per-instance state machine (shared by both forward kernels).
 // Lane 0 of the instance takes the decisions; the row sweeps of the AL transition (dual and penalty
 // updates) are spread over its 20 lanes.  sKD / sU: LDS copies of the gains / controls (or nullptr).
 template <class T, class M>
 ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
-                              int last_status, double viol, const T* sKD, const T* sU) {
+                              int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -829,43 +882,47 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   // ---- phase 3: per-instance state machine.  Lane 0 of the instance takes the decisions; the
   //      row sweeps of the AL transition (dual and penalty updates) are spread over its 20 lanes.
   // rejected step: the controls are unchanged and quirk Q12 evaluates the gradient measure with the
-  // current Z_.  The per-knot terms are spread over the instance's lanes; the sum keeps the serial
-  // order k = 0 .. N-1 of ilqr.hpp:574-583 (lanes hand their term over in knot order).
+  // current Z_ (ilqr.hpp:574-583).  Each lane sums a contiguous block of knots in order, the blocks
+  // are then added in lane order: the same sum up to the association of the partial sums.
   double gsum_rej = 0.0;
   if (!accepted && mode != kFwdStepOnly) {
-    for (int base = 0; base < N; base += LS) {
-      const int k = base + t;
-      T mx = T(0);
+    const int per = (N + LS - 1) / LS;
+    double part = 0.0;
+    for (int j = 0; j < per; ++j) {
+      const int k = t * per + j;
       if (k < N) {
+        T mx = T(0);
 #pragma unroll
         for (int i = 0; i < m; ++i) {
           const T dv = sKD ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
           const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
           mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
         }
+        part += (double)mx;
       }
-      const int cnt = (N - base) < LS ? (N - base) : LS;
-      for (int j = 0; j < cnt; ++j) gsum_rej += (double)__shfl(mx, grp * LS + j);
     }
+    for (int j = 0; j < LS; ++j) gsum_rej += __shfl(part, grp * LS + j);
   }
   int inner_done = 0;
   if (t == 0) {
+    double cost_cur = pre.cost_cur;
     if (accepted) {
       A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
       A.alpha[b] = alpha_sel;
       A.z[b] = z_sel;
+      cost_cur = J_sel;
     } else {
-      double rho = A.rho_reg[b], drho = A.drho[b];
+      double rho = pre.rho_reg, drho = pre.drho;
       increase_reg(o, &rho, &drho);  // ilqr.hpp:550
       A.rho_reg[b] = rho;
       A.drho[b] = drho;
     }
-    A.status[b] = last_status;
     if (mode == kFwdStepOnly) {
+      A.status[b] = last_status;
       A.viol[b] = viol;
     } else {
       const double gsum = accepted ? g_sel : gsum_rej;
-      inner_done = conv_stats_and_done(A, o, b, gsum, viol) ? 1 : 0;
+      inner_done = conv_stats_and_done_pre(A, o, b, gsum, viol, pre, cost_cur, last_status) ? 1 : 0;
     }
   }
   if (mode == kFwdStepOnly) return;
@@ -1334,8 +1391,11 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
     viol = vm;
   }
 
-  forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
-                       (double)viol, LDS ? sKD : (const T*)nullptr, LDS ? sU : (const T*)nullptr);
+  {
+    const InstPre pre = load_inst_pre(A, b);
+    forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
+                       (double)viol, LDS ? sKD : (const T*)nullptr, LDS ? sU : (const T*)nullptr, pre);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1356,6 +1416,69 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // make the cost wave wait for its (scattered, never re-read in the loop) candidate stores at every
 // knot -- and the rollout wave with it.
+// Phase 2 of the forward pass for the knots k0, k0 + stride, ...: copy the replayed trial (the accepted
+// one, or the last whose rollout succeeded: quirk Q6) out of the candidate scratch, evaluate and store
+// the constraint values it leaves in c_, and -- if accepted -- install it as the new trajectory.
+// Returns the max violation over those knots.  t_replay < 0: c_ is untouched since the expansion step.
+template <class T, class M, class Ctx>
+ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const Ctx& C, int b, int t_replay, bool accepted,
+                           int k0, int stride) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  constexpr int LS = kLineSearchLanes;
+  using R = Rec<T, n, m>;
+  const unsigned Bp = A.Bp;
+  const int N = A.N;
+  T viol = T(0);
+  if (t_replay >= 0) {
+    const unsigned rbo = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t_replay) * (unsigned)nm;
+    constexpr int kAhead = 3;  // candidates fetched before the first is used
+    for (int kb = k0; kb <= N; kb += kAhead * stride) {
+      T xs[kAhead][n], us[kAhead][m];
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        const int k = kb + j * stride;
+        const T* cand = A.trial + (rbo + (unsigned)(k <= N ? k : N) * (unsigned)(LS * nm));
+#pragma unroll
+        for (int i = 0; i < n; ++i) xs[j][i] = cand[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) us[j][i] = cand[n + i];  // knot N: never written, replaced below
+      }
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        const int k = kb + j * stride;
+        if (k > N) break;
+        if (k == N) {
+#pragma unroll
+          for (int i = 0; i < m; ++i) us[j][i] = T(0);
+        }
+        int rb;
+        const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+        T v;
+        knot_cost<T, n, m, true>(C, pd, kc, rb, xs[j], us[j], &v);
+        viol = max_(viol, v);
+        if (accepted) {
+          T xr[R::nP], ur[R::mP];
+#pragma unroll
+          for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[j][i < n ? i : 0] : T(0);
+#pragma unroll
+          for (int i = 0; i < R::mP; ++i) ur[i] = i < m ? us[j][i < m ? i : 0] : T(0);
+          store_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
+          if (k < N) store_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
+        }
+      }
+    }
+  } else {
+    for (int k = k0; k <= N; k += stride) {
+      int rb;
+      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
+      for (int ci = 0; ci < kc.ncon; ++ci)
+        for (int i = 0; i < kc.con[ci].p; ++i)
+          viol = max_(viol, violation(kc.con[ci].type, SOA(A.cval, rb + kc.con[ci].row_off + i)));
+    }
+  }
+  return viol;
+}
+
 ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class T, class M, int FK>
@@ -1482,8 +1605,12 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
 }
 
 template <class T, class M>
-__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc pd_arg, DevOpts o, int mode,
-                                                         int all, int per_wave) {
+__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+                                                         const ProblemDesc pd_arg, DevOpts o, int mode, int all,
+                                                         int per_wave) {
+  // pd: the description in the kernel arguments -- wave-uniform accesses become scalar loads that stay
+  // in SGPRs across the serial loop.  pdg: the same bytes in global memory, for the per-lane (divergent)
+  // indexing of phases 2 and 3; indexing the by-value copy that way would force it into scratch.
   const ProblemDesc* pd = &pd_arg;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -1521,63 +1648,68 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
   {
     for (int i = threadIdx.x; i < pd->npool; i += 2 * kBlock) sPool[i] = A.pool[i];
-    // every thread of the workgroup copies, one instance after the other (wave-uniform instance)
+    // Every thread of the workgroup copies for every instance (wave-uniform instance index).  Memory
+    // latency (~1 us from HBM / Infinity Cache, more when 500 workgroups start together) dwarfs the
+    // copy itself, so ALL loads -- six arrays, up to three instances -- are issued before the first
+    // LDS store: one round trip for the whole block.
     using V = typename VecOf<T>::type;
     constexpr int VN = R::V;
     constexpr int kStride = 2 * kBlock;
-    constexpr int kDepth = 8;
+    constexpr int D = 2;  // items per thread, array and instance in flight (N = 100: two rounds)
     const int tt = threadIdx.x;
-    for (int g = 0; g < per_wave; ++g) {
-      const int bg = instance_of_slot(A, blockIdx.x * per_wave + g, all);
-      if (bg < 0) continue;
-      T* gm = reinterpret_cast<T*>(smem_raw) + g * L.total();
-      auto stage_rec = [&](T* dst, const T* src, int knots, int EP) {
-        const int b = bg;
-        const int per = EP / VN;
-        const int total = knots * per;
-        for (int i0 = tt; i0 < total; i0 += kStride * kDepth) {
-          V v[kDepth];
+    const int perX = R::nP / VN, perU = R::mP / VN, perK = R::KP / VN;
+    const int cX = (N + 1) * perX, cU = N * perU, cK = N * perK, cR = L.nR, cS = L.nS;
+    int cmax = cX > cK ? cX : cK;
+    cmax = cmax > cR ? cmax : cR;
+    cmax = cmax > cS ? cmax : cS;
+    constexpr int G = kBlock / LS;  // instances per wave at most
+    for (int i0 = tt; i0 < cmax; i0 += kStride * D) {
+      V vx[G][D], vu[G][D], vk[G][D];
+      T sl[G][D], sp[G][D], si[G][D];
+      int bgs[G];
 #pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            int vi = i0 + j * kStride;
-            vi = vi < total ? vi : total - 1;
-            const int k = vi / per, w = vi - k * per;
-            v[j] = *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
-          }
+      for (int g = 0; g < G; ++g) {
+        bgs[g] = g < per_wave ? instance_of_slot(A, blockIdx.x * per_wave + g, all) : -1;
+        if (bgs[g] < 0) continue;
+        const int b = bgs[g];  // RECP / SOA address this instance
+        auto ldrec = [&](const T* src, int per, int cnt, int EP, int vi) -> V {
+          vi = vi < cnt ? vi : cnt - 1;  // clamped: the load is unconditional, the store is not
+          const int k = vi / per, w = vi - k * per;
+          return *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
+        };
 #pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int vi = i0 + j * kStride;
-            if (vi < total) *reinterpret_cast<V*>(dst + vi * VN) = v[j];
-          }
+        for (int j = 0; j < D; ++j) {
+          const int i = i0 + j * kStride;
+          vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
+          vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
+          vk[g][j] = ldrec(A.KD, perK, cK, R::KP, i);
+          sl[g][j] = cR > 0 ? SOA(A.lam, i < cR ? i : cR - 1) : T(0);
+          sp[g][j] = cR > 0 ? SOA(A.pen, i < cR ? i : cR - 1) : T(0);
+          si[g][j] = cS > 0 ? SOA(A.ipool, i < cS ? i : cS - 1) : T(0);
         }
-      };
-      auto stage_soa = [&](T* dst, const T* src, int cnt) {
-        for (int i0 = tt; i0 < cnt; i0 += kStride * kDepth) {
-          T v[kDepth];
+      }
 #pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int i = i0 + j * kStride;
-            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)bg] : T(0);
-          }
+      for (int g = 0; g < G; ++g) {
+        if (bgs[g] < 0) continue;
+        T* gX = reinterpret_cast<T*>(smem_raw) + g * L.total();
+        T* gU = gX + L.nX;
+        T* gKD = gU + L.nU;
+        T* gLam = gKD + L.nKD;
+        T* gPen = gLam + L.rowsP();
+        T* gIp = gPen + L.rowsP();
 #pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int i = i0 + j * kStride;
-            if (i < cnt) dst[i] = v[j];
+        for (int j = 0; j < D; ++j) {
+          const int i = i0 + j * kStride;
+          if (i < cX) *reinterpret_cast<V*>(gX + i * VN) = vx[g][j];
+          if (i < cU) *reinterpret_cast<V*>(gU + i * VN) = vu[g][j];
+          if (i < cK) *reinterpret_cast<V*>(gKD + i * VN) = vk[g][j];
+          if (i < cR) {
+            gLam[i] = sl[g][j];
+            gPen[i] = sp[g][j];
           }
+          if (i < cS) gIp[i] = si[g][j];
         }
-      };
-      T* gX = gm;
-      T* gU = gX + L.nX;
-      T* gKD = gU + L.nU;
-      T* gLam = gKD + L.nKD;
-      T* gPen = gLam + L.rowsP();
-      T* gIp = gPen + L.rowsP();
-      stage_rec(gX, A.X, N + 1, R::nP);
-      stage_rec(gU, A.U, N, R::mP);
-      stage_rec(gKD, A.KD, N, R::KP);
-      stage_soa(gLam, A.lam, L.nR);
-      stage_soa(gPen, A.pen, L.nR);
-      stage_soa(gIp, A.ipool, L.nS);
+      }
     }
   }
   __syncthreads();
@@ -1649,6 +1781,21 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     STAMP(2);
     lds_barrier();  // barrier N
     STAMP(3);
+    // phase 2 is shared by both waves: wait for the selection, take the odd blocks of knots
+    __syncthreads();  // barrier S
+    {
+      const int* sel = reinterpret_cast<const int*>(xch);
+      T* vpart = xch + 8;
+      T viol = T(0);
+      if (valid) {
+        CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
+        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, 2 * LS);
+        T vm = viol;
+        for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
+        if (t == 0) vpart[grp] = vm;
+      }
+    }
+    __syncthreads();  // barrier V
     return;
   }
 
@@ -1656,6 +1803,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   CtxL<T> C(A, b, sPool, sIp, sLam, sPen);
   const double J0 = A.J0[b];
   const double dV0 = A.dV0[b], dV1 = A.dV1[b];
+  const InstPre pre = load_inst_pre(A, b);  // consumed by the state machine at the very end
   // candidate scratch, instance-major [b][k][trial][x|u]
   const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
   double J = 0.0, gs = 0.0;
@@ -1726,53 +1874,30 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     last_status = __shfl(st, grp * LS + (nlive - 1));
     if (ok_g) t_replay = 31 - __clz(ok_g);
   }
-  if (!valid) return;
   STAMP(8 + 4);
-  __threadfence_block();  // candidates written by the other lanes of this wave are read below
-
-  // ---- phase 2: copy the winner into Z_, evaluate the c_ it leaves behind (knots over lanes) ------
-  T viol = T(0);
-  if (t_replay >= 0) {
-    const unsigned rbo = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t_replay) * (unsigned)nm;
-    for (int k = t; k <= N; k += LS) {
-      T xs[n], us[m];
-      const T* cand = A.trial + (rbo + (unsigned)k * (unsigned)(LS * nm));
-#pragma unroll
-      for (int i = 0; i < n; ++i) xs[i] = cand[i];
-#pragma unroll
-      for (int i = 0; i < m; ++i) us[i] = (k < N) ? cand[n + i] : T(0);
-      int rb;
-      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-      T v;
-      knot_cost<T, n, m, true>(C, pd, kc, rb, xs, us, &v);
-      viol = max_(viol, v);
-      if (accepted) {
-        T xr[R::nP], ur[R::mP];
-#pragma unroll
-        for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[i < n ? i : 0] : T(0);
-#pragma unroll
-        for (int i = 0; i < R::mP; ++i) ur[i] = i < m ? us[i < m ? i : 0] : T(0);
-        store_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
-        if (k < N) store_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
-      }
-    }
-  } else {
-    for (int k = t; k <= N; k += LS) {  // c_ untouched since the expansion step
-      int rb;
-      const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-      for (int ci = 0; ci < kc.ncon; ++ci)
-        for (int i = 0; i < kc.con[ci].p; ++i)
-          viol = max_(viol, violation(kc.con[ci].type, SOA(A.cval, rb + kc.con[ci].row_off + i)));
+  // ---- phase 2: copy the winner into Z_, evaluate the c_ it leaves behind; the knots are spread over
+  //      the lanes of BOTH waves (the rollout wave has nothing else left to do)
+  {
+    int* sel = reinterpret_cast<int*>(xch);  // the hand-off slots are free now
+    if (valid && t == 0) {
+      sel[2 * grp] = t_replay;
+      sel[2 * grp + 1] = accepted ? 1 : 0;
     }
   }
-  {
+  __syncthreads();  // barrier S: selection visible, candidate stores of this wave drained
+  T viol = T(0);
+  if (valid) {
+    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, 2 * LS);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
   }
+  __syncthreads();  // barrier V: the other wave's share of the violation
+  if (!valid) return;
+  viol = max_(viol, (xch + 8)[grp]);
   STAMP(8 + 5);
-  forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
-                       (double)viol, sKD, sU);
+  forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
+                       (double)viol, sKD, sU, pre);
   STAMP(8 + 6);
 }
 
