@@ -252,9 +252,10 @@ struct UnicycleM {  // examples/unicycle.cpp:12-33
       sincos_small(d2, &sd, &cd);
       s2 = s1 * cd + c1 * sd;
       c2 = c1 * cd - s1 * sd;
-      sincos_small(d4, &sd, &cd);
-      s4 = s1 * cd + c1 * sd;
-      c4 = c1 * cd - s1 * sd;
+      // d4 = 2 d2 exactly (the factor 0.5 is exact): double-angle formulas instead of a second kernel
+      const T sdd = T(2) * sd * cd, cdd = fma(T(-2) * sd, sd, T(1));
+      s4 = s1 * cdd + c1 * sdd;
+      c4 = c1 * cdd - s1 * sdd;
     } else {
       sincos_(x[2] + d2, &s2, &c2);
       sincos_(x[2] + d4, &s4, &c4);

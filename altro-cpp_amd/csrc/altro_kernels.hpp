@@ -1481,10 +1481,51 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 
 ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the cost wave so that they
+// stay off the rollout wave's serial chain.  Step k of the rollout fails with kStateLimit when
+// ||x_{k+1}|| > state_max, else with kControlLimit when ||u_k|| > control_max; the first failing step
+// decides.  visit() sees (x_k, u_k): it settles step k-1 (x_k and the remembered verdict on u_{k-1}),
+// then remembers u_k.  The rollout wave keeps integrating a failed trial; nothing reads the result.
+template <class T>
+struct RolloutBounds {
+  bool check;
+  T smax2, umax2;
+  bool ok = true;
+  int st = ALTRO_UNSOLVED;
+  bool pend_u = false;
+  bool first = true;
+  template <int n>
+  ALTRO_DEV void settle(const T* x) {
+    if (!check) return;
+    T sx = T(0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) sx += x[i] * x[i];
+    if (ok && !first) {
+      if (sx > smax2) {  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
+        ok = false;
+        st = ALTRO_STATE_LIMIT;
+      } else if (pend_u) {
+        ok = false;
+        st = ALTRO_CONTROL_LIMIT;
+      }
+    }
+    first = false;
+  }
+  template <int n, int m>
+  ALTRO_DEV void visit(const T* x, const T* u) {
+    if (!check) return;
+    settle<n>(x);
+    T su = T(0);
+#pragma unroll
+    for (int i = 0; i < m; ++i) su += u[i] * u[i];
+    pend_u = su > umax2;
+  }
+};
+
 template <class T, class M, int FK>
 ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
                                  int kend, const T* sKD, const T* xch, int lane, bool valid, unsigned tb,
-                                 double& J, double& gs) {
+                                 double& J, double& gs, RolloutBounds<T>& bnd) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1514,6 +1555,7 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
     for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
 #pragma unroll
     for (int i = 0; i < m; ++i) d[i] = sKD[k * R::KP + R::oD + i];
+    bnd.template visit<n, m>(xb, ub);
     const int rb = run.rowbase + (k - run.k_begin) * nrows;
     T blam[2 * m], brho = T(1);
     if (kHasB) {
@@ -1725,11 +1767,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
 
   if (wave == 0) {
     // ================= rollout wave: iLQR::RolloutClosedLoop (ilqr.hpp:468-499) =================
-    const T state_max2 = T(o.state_max) * T(o.state_max);
-    const T control_max2 = T(o.control_max) * T(o.control_max);
-    const bool check = o.check_forwardpass_bounds != 0;
-    bool ok = true;
-    int st = ALTRO_UNSOLVED;
+    // (the state / control limit checks of the reference run in the cost wave: RolloutBounds)
     T xb[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = x0[i];
@@ -1738,46 +1776,27 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
       load_rec<T, R::nP>(sX + k * R::nP, xk);
       load_rec<T, R::mP>(sU + k * R::mP, uk);
       load_rec<T, R::KP>(sKD + k * R::KP, kd);
-      if (ok) {
 #pragma unroll
-        for (int i = 0; i < m; ++i) {
-          T s = T(0);
+      for (int i = 0; i < m; ++i) {
+        T s = T(0);
 #pragma unroll
-          for (int l = 0; l < n; ++l) s += kd[R::oK + i + l * m] * (xb[l] - xk[l]);
-          ub[i] = uk[i] + s + kd[R::oD + i] * alpha;
-        }
-        T* slot = xch + (k & 1) * (nm * kBlock);
-#pragma unroll
-        for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
-#pragma unroll
-        for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
-        rk4_step<T, M>(xb, ub, hh, xn);
-        if (check) {
-          // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2 (ilqr.hpp:484-495), no sqrt needed
-          T sx = T(0), su = T(0);
-#pragma unroll
-          for (int i = 0; i < n; ++i) sx += xn[i] * xn[i];
-#pragma unroll
-          for (int i = 0; i < m; ++i) su += ub[i] * ub[i];
-          if (sx > state_max2) {
-            ok = false;
-            st = ALTRO_STATE_LIMIT;
-          } else if (su > control_max2) {
-            ok = false;
-            st = ALTRO_CONTROL_LIMIT;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < n; ++i) xb[i] = xn[i];
+        for (int l = 0; l < n; ++l) s += kd[R::oK + i + l * m] * (xb[l] - xk[l]);
+        ub[i] = uk[i] + s + kd[R::oD + i] * alpha;
       }
+      T* slot = xch + (k & 1) * (nm * kBlock);
+#pragma unroll
+      for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
+      rk4_step<T, M>(xb, ub, hh, xn);
+#pragma unroll
+      for (int i = 0; i < n; ++i) xb[i] = xn[i];
       lds_barrier();  // barrier k
     }
-    // final hand-off: x_N, rollout outcome
+    // final hand-off: x_N
     T* slot = xch + (N & 1) * (nm * kBlock);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
-    flags[lane] = ok ? 1 : 0;
-    flags[kBlock + lane] = st;
     STAMP(2);
     lds_barrier();  // barrier N
     STAMP(3);
@@ -1807,10 +1826,14 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   // candidate scratch, instance-major [b][k][trial][x|u]
   const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
   double J = 0.0, gs = 0.0;
+  RolloutBounds<T> bnd;
+  bnd.check = o.check_forwardpass_bounds != 0;
+  bnd.smax2 = T(o.state_max) * T(o.state_max);
+  bnd.umax2 = T(o.control_max) * T(o.control_max);
   for (int r = 0; r < pd->nruns; ++r) {
     const KnotRun run = pd->runs[r];
     const int kend = run.k_end < N ? run.k_end : N;
-#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, sKD, xch, lane, valid, tb, J, gs)
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, sKD, xch, lane, valid, tb, J, gs, bnd)
     switch (run.fast) {
       case kFastNone: ALTRO_RUN(kFastNone); break;
       case kFastB: ALTRO_RUN(kFastB); break;
@@ -1824,13 +1847,16 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   STAMP(8 + 2);
   lds_barrier();  // barrier N: terminal state and rollout outcome
   STAMP(8 + 3);
-  const bool ok = flags[lane] != 0;
-  const int st = flags[kBlock + lane];
+  bool ok;
+  int st;
   {
     const T* slot = xch + (N & 1) * (nm * kBlock);
     T xN[n], uz[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
+    bnd.template settle<n>(xN);  // the last step of the rollout
+    ok = bnd.ok;
+    st = bnd.st;
 #pragma unroll
     for (int i = 0; i < m; ++i) uz[i] = T(0);
     const KnotRun runN = pd->runs[pd->nruns - 1];  // the terminal knot closes the last run
