@@ -232,15 +232,27 @@ ALTRO_DEV T max_(T a, T b) {
 struct UnicycleM {  // examples/unicycle.cpp:12-33
   static constexpr int n = 3, m = 2;
   static constexpr bool kHasFusedRk4 = true;
+  static constexpr bool kHasCarriedTrig = true;
   // RK4 step with the duplicated work of the generic formula removed.  theta' = omega is constant
   // over the step, so the stage angles are theta, theta + (omega*0.5)*h (stages 2 AND 3: the two
   // expressions are the same floating-point computation) and theta + omega*h: 3 sincos instead of
   // 4.  Every other operation is performed exactly as rk4_step_generic does, in the same order.
   template <class T>
   static ALTRO_DEV void rk4_fused(const T* x, const T* u, T hh, T* xn) {
-    const T v = u[0], w = u[1];
-    T s1, c1, s2, c2, s4, c4;
+    T s1, c1;
     sincos_(x[2], &s1, &c1);
+    rk4_fused_sc(x, u, hh, xn, s1, c1);
+  }
+  // The same step with sin / cos of theta supplied by the caller and sin / cos of the stage-4 angle
+  // theta + omega*h handed back.  theta_{k+1} is that angle (up to the rounding of the RK4 combination,
+  // ~1e-17 rad), so a rollout may carry (s4, c4) into the next step instead of evaluating a full sincos
+  // on its serial chain; it re-evaluates every kTrigResync knots, which bounds the drift of the
+  // rotations to ~3e-15.
+  static constexpr int kTrigResync = 8;
+  template <class T>
+  static ALTRO_DEV void rk4_fused_sc(const T* x, const T* u, T hh, T* xn, T& s1, T& c1) {
+    const T v = u[0], w = u[1];
+    T s2, c2, s4, c4;
     const T k1x = v * c1, k1y = v * s1;
     // stage angles theta + d2 and theta + d4 with d2 = (w*0.5)*h, d4 = w*h: |d| < pi/4 in any sane
     // rollout, so sin/cos of the stage angle come from the angle-addition formulas with the fdlibm
@@ -265,6 +277,8 @@ struct UnicycleM {  // examples/unicycle.cpp:12-33
     xn[0] = x[0] + div6(hh * (k1x + 2 * k2x + 2 * k2x + k4x));
     xn[1] = x[1] + div6(hh * (k1y + 2 * k2y + 2 * k2y + k4y));
     xn[2] = x[2] + div6(hh * (w + 2 * w + 2 * w + w));
+    s1 = s4;
+    c1 = c4;
   }
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
@@ -292,6 +306,7 @@ template <int DOF>
 struct TripleIntegratorM {  // examples/triple_integrator.cpp:9-33
   static constexpr int n = 3 * DOF, m = DOF;
   static constexpr bool kHasFusedRk4 = false;
+  static constexpr bool kHasCarriedTrig = false;
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
 #pragma unroll
@@ -319,6 +334,7 @@ struct TripleIntegratorM {  // examples/triple_integrator.cpp:9-33
 struct Quadrotor12M {
   static constexpr int n = 12, m = 4;
   static constexpr bool kHasFusedRk4 = false;
+  static constexpr bool kHasCarriedTrig = false;
   template <class T>
   static ALTRO_DEV void f(const T* x, const T* u, T* xd) {
     const T g = T(9.81);

@@ -1769,6 +1769,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
     // ================= rollout wave: iLQR::RolloutClosedLoop (ilqr.hpp:468-499) =================
     // (the state / control limit checks of the reference run in the cost wave: RolloutBounds)
     T xb[n];
+    T trig_s = T(0), trig_c = T(1);
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = x0[i];
     for (int k = 0; k < N; ++k) {
@@ -1788,7 +1789,13 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
       for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
 #pragma unroll
       for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
-      rk4_step<T, M>(xb, ub, hh, xn);
+      if constexpr (M::kHasCarriedTrig) {
+        // sin / cos of the heading ride along from the previous step (see rk4_fused_sc)
+        if ((k % M::kTrigResync) == 0) sincos_(xb[2], &trig_s, &trig_c);
+        M::rk4_fused_sc(xb, ub, hh, xn, trig_s, trig_c);
+      } else {
+        rk4_step<T, M>(xb, ub, hh, xn);
+      }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
       lds_barrier();  // barrier k
