@@ -74,6 +74,7 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     return ReserveCounters(1024);
   }
   // one counter per sweep (device: filled by the forward kernel's atomics; host: pinned + mapped,
@@ -363,7 +364,7 @@ class Engine final : public EngineBase {
   static constexpr bool kMfmaBackward = std::is_same<T, double>::value && n == 3 && m == 2;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
-      if (!force_valu_backward_) {
+      if (!force_valu_backward_ && mfma_offsets_ok_) {
         if (A.record_ctg)
           hipLaunchKernelGGL((k_backward_mfma<M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         else
@@ -376,12 +377,19 @@ class Engine final : public EngineBase {
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
-    const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
-      // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS
-      hipLaunchKernelGGL((k_forward2<T, M>), grid, dim3(2 * kBlock), fwd_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, all,
-                         fwd_per_wave_);
-    } else {
+      // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
+      // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
+      // epilogue of the kernel (staging, winner copy) shrink with the instances per workgroup.
+      const int per_wave = (ninst <= num_cus_) ? 1 : fwd_per_wave_;
+      const size_t lds = fwd_shared_bytes_ + (size_t)per_wave * fwd_per_inst_bytes_;
+      const dim3 grid2((ninst + per_wave - 1) / per_wave);
+      hipLaunchKernelGGL((k_forward2<T, M>), grid2, dim3(2 * kBlock), lds, stream_, A, d_pd_, pd_, d, mode, all,
+                         per_wave);
+      return;
+    }
+    const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
+    {
       // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)
       hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A, d_pd_, pd_, d, mode, all,
                          fwd_per_wave_);
@@ -738,7 +746,14 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.x0, (size_t)R::nP * bp);
     ALTRO_ALLOC(A_.X, (size_t)(N_ + 1) * R::nP * bp);
     ALTRO_ALLOC(A_.U, (size_t)N_ * R::mP * bp);
-    ALTRO_ALLOC(A_.EXP, (size_t)(N_ + 1) * R::EP * bp + R::EP);  // + a zeroed pad record (k_backward_mfma)
+    {
+      // k_backward_mfma reads a zeroed pad record behind the last knot and lets its prefetch run up to
+      // kBwdFrontPad records below knot 0
+      const size_t front = (size_t)kBwdFrontPad * R::EP * bp;
+      ALTRO_ALLOC(A_.EXP, front + (size_t)(N_ + 1) * R::EP * bp + R::EP);
+      A_.EXP += front;
+      mfma_offsets_ok_ = (front + (size_t)(N_ + 2) * R::EP * bp) * sizeof(T) < (size_t)0xffffffffu;
+    }
     ALTRO_ALLOC(A_.costs, (size_t)(N_ + 1) * bp);
     ALTRO_ALLOC(A_.KD, (size_t)N_ * R::KP * bp);
     ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
@@ -808,6 +823,8 @@ class Engine final : public EngineBase {
       const size_t shared_bytes = (padv(pool.size()) + 2 * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int);
       while (fwd_per_wave_ > 1 && shared_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
+      fwd_shared_bytes_ = shared_bytes;
+      fwd_per_inst_bytes_ = per_inst;
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
@@ -988,9 +1005,11 @@ class Engine final : public EngineBase {
   DevArrays<T> A_{};
   double* d_tmp_ = nullptr;
   int* d_list_[2] = {nullptr, nullptr};
+  bool mfma_offsets_ok_ = false;
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr;
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
-  size_t fwd_lds_bytes_ = 0;
+  size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
+  int num_cus_ = 256;
   T *X_init_ = nullptr, *U_init_ = nullptr;
   double* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;

@@ -276,6 +276,7 @@ ALTRO_DEV int lower_half(int x) {
 }
 
 constexpr int kBwdAhead = 6;    // knots per prefetch block of the MFMA backward pass
+constexpr int kBwdFrontPad = 2 * kBwdAhead;  // records in front of knot 0 that the prefetch may touch
 constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bulk stores (4 instances: 32 KiB)
 
 template <class M, bool CTG>
@@ -306,18 +307,22 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   const int off3 = (r < m && c < m) ? R::oLuu + r + c * m : -1;                        // luu
   const int offKD = (r < m) ? (c < n ? R::oK + r + c * m : R::oD + r) : -1;            // [K | d]
   const int offCT = (r < n) ? (c < n ? R::oP + r + c * n : R::op + r) : -1;            // [P | p]
-  // Every tile load is unconditional: lanes that own a structural zero read the zeroed pad behind the
-  // last record with stride 0, so the loop carries no exec-mask branches.  Indices are 32-bit
-  // elements (guarded at upload).
-  const unsigned stride = Bp * (unsigned)R::EP;
-  const unsigned zidx = (unsigned)(N + 1) * stride;
-  const unsigned rec0 = (unsigned)b * (unsigned)R::EP;
-  const unsigned sA = offA >= 0 ? stride : 0u, sB = offB >= 0 ? stride : 0u, s1 = off1 >= 0 ? stride : 0u,
-                 s2 = off2 >= 0 ? stride : 0u, s3 = off3 >= 0 ? stride : 0u;
-  const unsigned bA = offA >= 0 ? rec0 + offA : zidx, bB = offB >= 0 ? rec0 + offB : zidx,
-                 b1 = off1 >= 0 ? rec0 + off1 : zidx, b2 = off2 >= 0 ? rec0 + off2 : zidx,
-                 b3 = off3 >= 0 ? rec0 + off3 : zidx;
-  const double* __restrict__ E = A.EXP;
+  // Every tile load is unconditional: lanes that own a structural zero read the zeroed pad record behind
+  // the last knot with stride 0, and the prefetch cursor may run below knot 0 into the front pad
+  // (kBwdFrontPad records, see the allocation).  Offsets are 32-bit BYTE offsets from the start of the
+  // front pad, so a load is one instruction (scalar base + vector offset) and a cursor step one
+  // subtraction; the engine only selects this kernel when the array is smaller than 4 GiB.
+  const unsigned strideB = Bp * (unsigned)R::EP * 8u;
+  const unsigned frontB = (unsigned)kBwdFrontPad * strideB;
+  const unsigned zoff = frontB + (unsigned)(N + 1) * strideB;
+  const unsigned rec0 = frontB + (unsigned)b * (unsigned)R::EP * 8u;
+  const unsigned sA = offA >= 0 ? strideB : 0u, sB = offB >= 0 ? strideB : 0u, s1 = off1 >= 0 ? strideB : 0u,
+                 s2 = off2 >= 0 ? strideB : 0u, s3 = off3 >= 0 ? strideB : 0u;
+  const unsigned bA = offA >= 0 ? rec0 + 8u * offA : zoff, bB = offB >= 0 ? rec0 + 8u * offB : zoff,
+                 b1 = off1 >= 0 ? rec0 + 8u * off1 : zoff, b2 = off2 >= 0 ? rec0 + 8u * off2 : zoff,
+                 b3 = off3 >= 0 ? rec0 + 8u * off3 : zoff;
+  const char* __restrict__ Eb = reinterpret_cast<const char*>(A.EXP) - (size_t)frontB;
+  auto ldE = [&](unsigned off) __attribute__((always_inline)) { return *reinterpret_cast<const double*>(Eb + off); };
 
   struct Tiles {
     double tA, tB, t1, t2, t3;
@@ -327,35 +332,33 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   int max_reg_count = 0;
   int status = A.status[b];
   bool need = inst_on && N > 0;
+  const unsigned verdict_bit = 1u << (blk * 4);
   // Tile loads run a block of kBwdAhead knots ahead of the recursion: HBM / Infinity-Cache latency
   // (~1 us) is longer than one knot of the dependent chain (~0.3 us).  Two register blocks ping-pong;
   // the loads of the next block are issued right after the first knot of the current one, so every
   // wait -- including the conservative one the compiler places at the loop header -- only covers
   // loads that are at least kBwdAhead - 1 knots old.
   constexpr int H = kBwdAhead;
-  int kl;
   unsigned iA, iB, i1, i2, i3;
   Tiles Sa[H], Sb[H];
   double Pp;
   auto issue = [&](Tiles& S) __attribute__((always_inline)) {
-    // unconditional (past knot 0 the cursor stays put and knot 0 is fetched again): a load count that
-    // does not depend on control flow lets the compiler wait for exactly the set it needs
-    S.tA = E[iA];
-    S.tB = E[iB];
-    S.t1 = E[i1];
-    S.t2 = E[i2];
-    S.t3 = E[i3];
-    const unsigned live = kl > 0 ? 0xffffffffu : 0u;
-    iA -= sA & live;
-    iB -= sB & live;
-    i1 -= s1 & live;
-    i2 -= s2 & live;
-    i3 -= s3 & live;
-    kl--;
+    // unconditional (past knot 0 the cursor walks into the front pad): a load count that does not
+    // depend on control flow lets the compiler wait for exactly the set it needs
+    S.tA = ldE(iA);
+    S.tB = ldE(iB);
+    S.t1 = ldE(i1);
+    S.t2 = ldE(i2);
+    S.t3 = ldE(i3);
+    iA -= sA;
+    iB -= sB;
+    i1 -= s1;
+    i2 -= s2;
+    i3 -= s3;
   };
   auto prime = [&]() __attribute__((always_inline)) {
-    Pp = E[b1 + (unsigned)N * s1];  // CalcTerminalCostToGo: [P|p] = [lxx|lx] of knot N
-    kl = N > 1 ? N - 1 : 0;
+    Pp = ldE(b1 + (unsigned)N * s1);  // CalcTerminalCostToGo: [P|p] = [lxx|lx] of knot N
+    const int kl = N - 1;
     iA = bA + (unsigned)kl * sA;
     iB = bB + (unsigned)kl * sB;
     i1 = b1 + (unsigned)kl * s1;
@@ -436,8 +439,8 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       const double qa = q00 + rho, qc = q11 + rho;
       const double det = fma(qa, qc, -(q10 * q10));
       const double rd = rcp_nr(det);
-      // rows 2 and 3 did not receive Quu: they take the verdict of rows 0 / 1
-      const bool fail = lower_half(((qa <= 0.0) || (det <= 0.0)) ? 1 : 0) != 0;
+      // rows 2 and 3 did not receive Quu: every lane reads the verdict of lane (r = 0, c = 0) of its block
+      const bool fail = ((unsigned)__ballot((qa <= 0.0) || (det <= 0.0)) & verdict_bit) != 0u;
       // -(Quu + rho I)^-1, this lane's entry (zero outside the 2x2 block)
       // (rows 2 and 3 hold det = 0 / rd = inf: the zero must be selected after the product)
       const double MinvNeg = (r < m && c < m) ? (r == c ? (r == 0 ? -qc : -qa) : q10) * rd : 0.0;
@@ -447,12 +450,6 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       double Pn = mfma4(Q2, KD, Q1);
       Pn = mfma4(KD, Q2, Pn);
       Pn = mfma4(KD, G, Pn);
-      // expected cost decrease: d^T Qu and 0.5 d^T Quu d (rows 0,1 of the vector column; the sums
-      // are formed in every lane, lane (r=0, c=3) owns the meaningful one)
-      double e00, e01, e10, e11;
-      rows01(KD * Q2, e00, e01);
-      rows01(KD * G, e10, e11);
-      const double v0 = e00 + e01, v1 = e10 + e11;
       // Branch-free state update: a divergent branch costs ~50 cycles on this chain.  The only real
       // branch is the (wave-uniform, rare) regularisation increase.
       const bool failed = running && fail;
@@ -472,12 +469,15 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
         gave_up = failed && give;
       }
       Pp = commit ? Pn : Pp;
-      dV0 += commit ? v0 : 0.0;
-      dV1 += commit ? 0.5 * v1 : 0.0;
+      // expected cost decrease d^T Qu, d^T Quu d: every lane accumulates its own product (rows 0 and 1
+      // of the vector column are the meaningful ones); the two rows are added once, after the sweep
+      const double KDc = commit ? KD : 0.0;
+      dV0 = fma(KDc, Q2, dV0);
+      dV1 = fma(KDc, G, dV1);
       // gains into the LDS block (lanes with nothing to store hit a junk slot)
       sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = Pn;
-      need = need && !gave_up && !(commit && k == 0);
+      need = need && !gave_up;
       slot++;
     };
     int k = N - 1;
@@ -500,13 +500,21 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       if (!block(Sa, Sb)) break;
       if (!block(Sb, Sa)) break;
     }
+    need = need && !running;  // instances that reached knot 0 are done
     flush();
   }
   BSTAMP(18);
+  {
+    double a0, a1;
+    rows01(dV0, a0, a1);
+    dV0 = a0 + a1;
+    rows01(dV1, a0, a1);
+    dV1 = a0 + a1;
+  }
   if (!inst_on || r != 0) return;
   if (c == 3) {  // the lane that holds row 0 of the vector column
     A.dV0[b] = dV0;
-    A.dV1[b] = dV1;
+    A.dV1[b] = 0.5 * dV1;
   }
   if (c != 0) return;
   A.J0[b] = J0;
