@@ -914,16 +914,19 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   int inner_done = 0;
   if (t == 0) {
     double cost_cur = pre.cost_cur;
+    {
+      // (unconditional stores: sibling branches that each store one double get merged into a store
+      // through a pointer table in scratch memory)
+      double rho = pre.rho_reg, drho = pre.drho;
+      if (!accepted) increase_reg(o, &rho, &drho);  // ilqr.hpp:550
+      A.rho_reg[b] = rho;
+      A.drho[b] = drho;
+    }
     if (accepted) {
       A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
       A.alpha[b] = alpha_sel;
       A.z[b] = z_sel;
       cost_cur = J_sel;
-    } else {
-      double rho = pre.rho_reg, drho = pre.drho;
-      increase_reg(o, &rho, &drho);  // ilqr.hpp:550
-      A.rho_reg[b] = rho;
-      A.drho[b] = drho;
     }
     if (mode == kFwdStepOnly) {
       A.status[b] = last_status;
@@ -1654,18 +1657,95 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   }
 }
 
+// Phase 0 of the two-wave forward pass: copy the read-only inputs of up to kBlock / 20 instances into
+// LDS with `nthreads` threads (tt = index of this thread).  with_kd = false leaves the gains alone
+// (the fused sweep kernel has the backward pass write them straight into LDS).
 template <class T, class M>
-__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
-                                                         const ProblemDesc pd_arg, DevOpts o, int mode, int all,
-                                                         int per_wave) {
-  // pd: the description in the kernel arguments -- wave-uniform accesses become scalar loads that stay
-  // in SGPRs across the serial loop.  pdg: the same bytes in global memory, for the per-lane (divergent)
-  // indexing of phases 2 and 3; indexing the by-value copy that way would force it into scratch.
-  const ProblemDesc* pd = &pd_arg;
+ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, const FwdLds<T>& L, unsigned char* smem_raw,
+                              T* sPool, int per_wave, int all, int tt, int nthreads, bool with_kd) {
+  constexpr int LS = kLineSearchLanes;
+  using R = Rec<T, M::n, M::m>;
+  const unsigned Bp = A.Bp;
+  const int N = A.N;
+  {
+    for (int i = tt; i < pd->npool; i += nthreads) sPool[i] = A.pool[i];
+    // Every thread of the workgroup copies for every instance (wave-uniform instance index).  Memory
+    // latency (~1 us from HBM / Infinity Cache, more when 500 workgroups start together) dwarfs the
+    // copy itself, so ALL loads -- six arrays, up to three instances -- are issued before the first
+    // LDS store: one round trip for the whole block.
+    using V = typename VecOf<T>::type;
+    constexpr int VN = R::V;
+    const int kStride = nthreads;
+    constexpr int D = 2;  // items per thread, array and instance in flight (N = 100: two rounds)
+    const int perX = R::nP / VN, perU = R::mP / VN, perK = R::KP / VN;
+    const int cX = (N + 1) * perX, cU = N * perU, cK = N * perK, cR = L.nR, cS = L.nS;
+    int cmax = (with_kd && cK > cX) ? cK : cX;
+    cmax = cmax > cR ? cmax : cR;
+    cmax = cmax > cS ? cmax : cS;
+    constexpr int G = kBlock / LS;  // instances per wave at most
+    for (int i0 = tt; i0 < cmax; i0 += kStride * D) {
+      V vx[G][D], vu[G][D], vk[G][D];
+      T sl[G][D], sp[G][D], si[G][D];
+      int bgs[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bgs[g] = g < per_wave ? instance_of_slot(A, blockIdx.x * per_wave + g, all) : -1;
+        if (bgs[g] < 0) continue;
+        const int b = bgs[g];  // RECP / SOA address this instance
+        auto ldrec = [&](const T* src, int per, int cnt, int EP, int vi) -> V {
+          vi = vi < cnt ? vi : cnt - 1;  // clamped: the load is unconditional, the store is not
+          const int k = vi / per, w = vi - k * per;
+          return *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int i = i0 + j * kStride;
+          vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
+          vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
+          if (with_kd) vk[g][j] = ldrec(A.KD, perK, cK, R::KP, i);
+          sl[g][j] = cR > 0 ? SOA(A.lam, i < cR ? i : cR - 1) : T(0);
+          sp[g][j] = cR > 0 ? SOA(A.pen, i < cR ? i : cR - 1) : T(0);
+          si[g][j] = cS > 0 ? SOA(A.ipool, i < cS ? i : cS - 1) : T(0);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (bgs[g] < 0) continue;
+        T* gX = reinterpret_cast<T*>(smem_raw) + g * L.total();
+        T* gU = gX + L.nX;
+        T* gKD = gU + L.nU;
+        T* gLam = gKD + L.nKD;
+        T* gPen = gLam + L.rowsP();
+        T* gIp = gPen + L.rowsP();
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int i = i0 + j * kStride;
+          if (i < cX) *reinterpret_cast<V*>(gX + i * VN) = vx[g][j];
+          if (i < cU) *reinterpret_cast<V*>(gU + i * VN) = vu[g][j];
+          if (with_kd && i < cK) *reinterpret_cast<V*>(gKD + i * VN) = vk[g][j];
+          if (i < cR) {
+            gLam[i] = sl[g][j];
+            gPen[i] = sp[g][j];
+          }
+          if (i < cS) gIp[i] = si[g][j];
+        }
+      }
+    }
+  }
+}
+
+// Body of the two-wave forward pass (128 threads).  pd: the description in the kernel arguments --
+// wave-uniform accesses become scalar loads that stay in SGPRs across the serial loop.  pdg: the same
+// bytes in global memory, for the per-lane (divergent) indexing of phases 2 and 3; indexing the
+// by-value copy that way would force it into scratch.  FUSED: called by k_sweep_fused with the LDS
+// block already filled; fh = {J0, dV0, dV1, initial_cost} handed over in LDS.
+template <class T, class M, bool FUSED>
+ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
+                             const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
+                             const double* fh) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int grp = lane / LS;
@@ -1696,73 +1776,10 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
-  {
-    for (int i = threadIdx.x; i < pd->npool; i += 2 * kBlock) sPool[i] = A.pool[i];
-    // Every thread of the workgroup copies for every instance (wave-uniform instance index).  Memory
-    // latency (~1 us from HBM / Infinity Cache, more when 500 workgroups start together) dwarfs the
-    // copy itself, so ALL loads -- six arrays, up to three instances -- are issued before the first
-    // LDS store: one round trip for the whole block.
-    using V = typename VecOf<T>::type;
-    constexpr int VN = R::V;
-    constexpr int kStride = 2 * kBlock;
-    constexpr int D = 2;  // items per thread, array and instance in flight (N = 100: two rounds)
-    const int tt = threadIdx.x;
-    const int perX = R::nP / VN, perU = R::mP / VN, perK = R::KP / VN;
-    const int cX = (N + 1) * perX, cU = N * perU, cK = N * perK, cR = L.nR, cS = L.nS;
-    int cmax = cX > cK ? cX : cK;
-    cmax = cmax > cR ? cmax : cR;
-    cmax = cmax > cS ? cmax : cS;
-    constexpr int G = kBlock / LS;  // instances per wave at most
-    for (int i0 = tt; i0 < cmax; i0 += kStride * D) {
-      V vx[G][D], vu[G][D], vk[G][D];
-      T sl[G][D], sp[G][D], si[G][D];
-      int bgs[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        bgs[g] = g < per_wave ? instance_of_slot(A, blockIdx.x * per_wave + g, all) : -1;
-        if (bgs[g] < 0) continue;
-        const int b = bgs[g];  // RECP / SOA address this instance
-        auto ldrec = [&](const T* src, int per, int cnt, int EP, int vi) -> V {
-          vi = vi < cnt ? vi : cnt - 1;  // clamped: the load is unconditional, the store is not
-          const int k = vi / per, w = vi - k * per;
-          return *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
-        };
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const int i = i0 + j * kStride;
-          vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
-          vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
-          vk[g][j] = ldrec(A.KD, perK, cK, R::KP, i);
-          sl[g][j] = cR > 0 ? SOA(A.lam, i < cR ? i : cR - 1) : T(0);
-          sp[g][j] = cR > 0 ? SOA(A.pen, i < cR ? i : cR - 1) : T(0);
-          si[g][j] = cS > 0 ? SOA(A.ipool, i < cS ? i : cS - 1) : T(0);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (bgs[g] < 0) continue;
-        T* gX = reinterpret_cast<T*>(smem_raw) + g * L.total();
-        T* gU = gX + L.nX;
-        T* gKD = gU + L.nU;
-        T* gLam = gKD + L.nKD;
-        T* gPen = gLam + L.rowsP();
-        T* gIp = gPen + L.rowsP();
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const int i = i0 + j * kStride;
-          if (i < cX) *reinterpret_cast<V*>(gX + i * VN) = vx[g][j];
-          if (i < cU) *reinterpret_cast<V*>(gU + i * VN) = vu[g][j];
-          if (i < cK) *reinterpret_cast<V*>(gKD + i * VN) = vk[g][j];
-          if (i < cR) {
-            gLam[i] = sl[g][j];
-            gPen[i] = sp[g][j];
-          }
-          if (i < cS) gIp[i] = si[g][j];
-        }
-      }
-    }
+  if (!FUSED) {
+    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, 2 * kBlock, true);
+    __syncthreads();
   }
-  __syncthreads();
   STAMP(wave * 8 + 1);
 
   T x0[R::nP];
@@ -1835,9 +1852,10 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
 
   // ===================== cost wave: iLQR::Cost per trial + everything after ======================
   CtxL<T> C(A, b, sPool, sIp, sLam, sPen);
-  const double J0 = A.J0[b];
-  const double dV0 = A.dV0[b], dV1 = A.dV1[b];
-  const InstPre pre = load_inst_pre(A, b);  // consumed by the state machine at the very end
+  const double J0 = FUSED ? fh[0] : A.J0[b];
+  const double dV0 = FUSED ? fh[1] : A.dV0[b], dV1 = FUSED ? fh[2] : A.dV1[b];
+  InstPre pre = load_inst_pre(A, b);  // consumed by the state machine at the very end
+  if (FUSED) pre.initial_cost = fh[3];
   // candidate scratch, instance-major [b][k][trial][x|u]
   const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
   double J = 0.0, gs = 0.0;
@@ -1940,6 +1958,14 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre);
   STAMP(8 + 6);
+}
+
+template <class T, class M>
+__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+                                                         const ProblemDesc pd_arg, DevOpts o, int mode, int all,
+                                                         int per_wave) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  forward2_body<T, M, false>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)
