@@ -374,6 +374,13 @@ class Engine final : public EngineBase {
     }
     hipLaunchKernelGGL((k_backward<T, M>), dim3((ninst + kBlock - 1) / kBlock), dim3(kBlock), 0, stream_, A, d, all);
   }
+  // The fused sweep kernel needs the MFMA backward pass, the LDS-staged forward pass with one instance
+  // per workgroup, no cost-to-go recording and at most 20 line-search trials.
+  bool FusedOk(const DevOpts& d) const {
+    if constexpr (!kMfmaBackward) return false;
+    return !force_valu_backward_ && !no_fused_ && mfma_offsets_ok_ && fwd_lds_bytes_ > 0 && !A_.record_ctg &&
+           d.line_search_max_iterations <= kLineSearchLanes && fused_lds_bytes_ <= 64 * 1024;
+  }
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
@@ -825,6 +832,7 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
+      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock) * sizeof(double);
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
@@ -891,6 +899,8 @@ class Engine final : public EngineBase {
 #endif
     for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
+    std::vector<char> fused_flag;
+    const bool fused_ok = FusedOk(d);
     auto enqueue_sweep = [&](int i) -> altro_status {
       DevArrays<T> A = A_;
       if (i == 0) {
@@ -906,6 +916,23 @@ class Engine final : public EngineBase {
       A.next_list = d_list_[(i + 1) % 2];
       A.next_count = d_counter_ + i;
       const int ninst = std::max(1, known_count);
+      if (fused_ok && i > 0 && ninst <= num_cus_) {
+        // the tail: every instance gets a workgroup that runs the whole iteration (k_sweep_fused)
+        if (prof) {
+          hipEventRecord(ProfEvent(nev++), stream_);
+          hipEventRecord(ProfEvent(nev++), stream_);
+        }
+        if constexpr (kMfmaBackward) {
+          hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(2 * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
+                             mode);
+        }
+        if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+        fused_flag.push_back(1);
+        timing_.launches += 1;
+        timing_.fused_sweeps += 1;
+        return ALTRO_OK;
+      }
+      fused_flag.push_back(0);
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
       hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
@@ -981,7 +1008,10 @@ class Engine final : public EngineBase {
         hipEventElapsedTime(&ms, prof_ev_[e0 + 1], prof_ev_[e0 + 2]);
         timing_.backward_pass_ms += ms;
         hipEventElapsedTime(&ms, prof_ev_[e0 + 2], prof_ev_[e0 + 3]);
-        timing_.forward_pass_ms += ms;
+        if (fused_flag[i])
+          timing_.fused_ms += ms;
+        else
+          timing_.forward_pass_ms += ms;
       }
     }
     {
@@ -1010,6 +1040,8 @@ class Engine final : public EngineBase {
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
+  size_t fused_lds_bytes_ = 0;
+  bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;
   T *X_init_ = nullptr, *U_init_ = nullptr;
   double* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;

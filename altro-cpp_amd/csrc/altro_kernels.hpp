@@ -70,19 +70,11 @@ ALTRO_DEV void hist_push(const DevArrays<T>& A, int b) {
 // -------------------------------------------------------------------------------------------------
 // iLQR::UpdateExpansionsBlock (ilqr.hpp:670-677) over grid (instance, knot)
 // -------------------------------------------------------------------------------------------------
+// One (instance, knot) of iLQR::UpdateExpansions: returns the knot cost, writes the record.
 template <class T, class M>
-__global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
-                                                       int all) {
-  constexpr int n = M::n, m = M::m, nm = n + m;
+ALTRO_DEV T expansion_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pd, int b, int k) {
+  constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
-  const int b = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
-  const int k = blockIdx.y;
-  if (A.host_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    // tell the host how many instances this sweep works on (it is polling the mapped word)
-    __hip_atomic_store(A.host_count, A.act_count ? *A.act_count : A.act_count_const, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (b < 0) return;
   const int N = A.N;
   const unsigned Bp = A.Bp;
   T xr[R::nP], ur[R::mP];
@@ -96,11 +88,27 @@ __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const Pro
   for (int e = 0; e < R::EP; ++e) E[e] = T(0);
   int rb;
   const KnotClass& kc = class_of_knot(A, pd, k, &rb);
-  T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
-                                     E + R::oLuu);
+  const T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
+                                           E + R::oLuu);
   A.costs[(unsigned)k * Bp + (unsigned)b] = J;
   if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
   store_rec<T, R::EP>(RECP(A.EXP, k, R::EP), E);
+  return J;
+}
+// tell the host how many instances this sweep works on (it is polling the mapped word)
+template <class T>
+ALTRO_DEV void publish_count(const DevArrays<T>& A) {
+  if (A.host_count)
+    __hip_atomic_store(A.host_count, A.act_count ? *A.act_count : A.act_count_const, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
+                                                       int all) {
+  const int b = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) publish_count(A);
+  if (b < 0) return;
+  expansion_body<T, M>(A, pd, b, blockIdx.y);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -279,14 +287,19 @@ constexpr int kBwdAhead = 6;    // knots per prefetch block of the MFMA backward
 constexpr int kBwdFrontPad = 2 * kBwdAhead;  // records in front of knot 0 that the prefetch may touch
 constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bulk stores (4 instances: 32 KiB)
 
-template <class M, bool CTG>
-__global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, DevOpts o, int all) {
+// Body of the MFMA backward pass for one wavefront (lane = 0..63; the instance of block blk is slot
+// slot_base + blk of the launch).  sKD: LDS buffer of kBwdChunk * 4 * KP + 64 doubles.
+// FUSED (k_sweep_fused): one instance per wavefront (block 0), the gains go straight into the forward
+// pass's LDS block sKDf[k * KP + e] (+ a junk slot at sKDf[fused_junk + lane]) and are also written to
+// A.KD at the end; the running cost J0 is summed by the other wave; dV0 / dV1 are handed over in fh[1..2].
+template <class M, bool CTG, bool FUSED>
+ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, int all, int lane, int slot_base,
+                                  double* sKD, double* sKDf, int fused_junk, double* fh) {
   static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
   constexpr int n = 3, m = 2;
   using R = Rec<double, n, m>;
-  const int lane = threadIdx.x;
   const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
-  const int b0 = instance_of_slot(A, blockIdx.x * 4 + blk, all);
+  const int b0 = (FUSED && blk != 0) ? -1 : instance_of_slot(A, slot_base + blk, all);
   const bool inst_on = b0 >= 0;
   if (__ballot(inst_on) == 0ull) return;
   const int b = inst_on ? b0 : 0;
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   // Running cost of the current trajectory, summed in knot order (ilqr.hpp:326-334): the 16 lanes of
   // the instance fetch the per-knot costs side by side, then hand them over one by one.
   double J0 = 0.0;
-  {
+  if (!FUSED) {
     const int q = r * 4 + c;  // 0..15 inside the instance
     for (int base = 0; base <= N; base += 128) {
       double v[8];
@@ -398,7 +411,6 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   // The gains are collected in LDS and written out in bulk: a store in the loop would share the memory
   // counter with the prefetched tiles (loads and stores retire out of order with respect to each
   // other), and every wait on a tile would have to drain the whole queue.
-  __shared__ double sKD[kBwdChunk * 4 * R::KP + kBlock];  // + one junk slot per lane
   double* const sink = A.trial + lane;  // CTG build only: junk sink of the lanes that own no element
   while (__ballot(need) != 0ull) {
     if (!primed) prime();  // restart after a failed factorisation
@@ -475,7 +487,10 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       dV0 = fma(KDc, Q2, dV0);
       dV1 = fma(KDc, G, dV1);
       // gains into the LDS block (lanes with nothing to store hit a junk slot)
-      sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
+      if (FUSED)
+        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = KD;
+      else
+        sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = Pn;
       need = need && !gave_up;
       slot++;
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
         if (k - j == 0) return false;
       }
       k -= H;
-      if (slot + H > kBwdChunk) flush();
+      if (!FUSED && slot + H > kBwdChunk) flush();
       return true;
     };
     for (;;) {
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
       if (!block(Sb, Sa)) break;
     }
     need = need && !running;  // instances that reached knot 0 are done
-    flush();
+    if (!FUSED) flush();
   }
   BSTAMP(18);
   {
@@ -515,18 +530,36 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, D
   if (c == 3) {  // the lane that holds row 0 of the vector column
     A.dV0[b] = dV0;
     A.dV1[b] = 0.5 * dV1;
+    if (FUSED) {
+      fh[1] = dV0;
+      fh[2] = 0.5 * dV1;
+    }
   }
   if (c != 0) return;
-  A.J0[b] = J0;
-  if (A.need_init_cost[b]) {
-    A.initial_cost[b] = J0;
-    A.need_init_cost[b] = 0;
+  if (!FUSED) {
+    A.J0[b] = J0;
+    if (A.need_init_cost[b]) {
+      A.initial_cost[b] = J0;
+      A.need_init_cost[b] = 0;
+    }
   }
-  A.reg_log[b] = rho;  // stats_.Log("reg", rho_)
+  const double rho_used = rho;
+  A.reg_log[b] = rho_used;  // stats_.Log("reg", rho_)
   decrease_reg(o, &rho, &drho);
   A.rho_reg[b] = rho;
   A.drho[b] = drho;
   A.status[b] = status;
+  if (FUSED) {  // the forward pass of the same kernel must not depend on L1 seeing these stores
+    fh[4] = rho;
+    fh[5] = drho;
+  }
+}
+
+template <class M, bool CTG>
+__global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, DevOpts o, int all) {
+  using R = Rec<double, M::n, M::m>;
+  __shared__ double sKD[kBwdChunk * 4 * R::KP + kBlock];  // + one junk slot per lane
+  backward_mfma_body<M, CTG, false>(A, o, all, threadIdx.x, blockIdx.x * 4, sKD, nullptr, 0, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1855,7 +1888,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const double J0 = FUSED ? fh[0] : A.J0[b];
   const double dV0 = FUSED ? fh[1] : A.dV0[b], dV1 = FUSED ? fh[2] : A.dV1[b];
   InstPre pre = load_inst_pre(A, b);  // consumed by the state machine at the very end
-  if (FUSED) pre.initial_cost = fh[3];
+  if (FUSED) {
+    pre.initial_cost = fh[3];
+    pre.rho_reg = fh[4];
+    pre.drho = fh[5];
+  }
   // candidate scratch, instance-major [b][k][trial][x|u]
   const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
   double J = 0.0, gs = 0.0;
@@ -1966,6 +2003,87 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
                                                          int per_wave) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   forward2_body<T, M, false>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
+}
+
+// -------------------------------------------------------------------------------------------------
+// One whole iLQR iteration of ONE instance per workgroup (128 threads), for the long tail of a batched
+// solve: a few dozen stragglers iterate ~100 times after everyone else has converged, and each sweep
+// is then a pure latency chain.  Fusing the three kernels removes two kernel boundaries, the staging
+// of the gains (the backward wave writes them straight into the forward pass's LDS block), and hides
+// the rest of the staging and the running-cost sum behind the backward recursion:
+//   E  expansions of the 101 knots over the 128 threads (global memory; visible after the barrier)
+//   B  wave 0: MFMA backward pass (one of the four 4x4 blocks carries the instance)
+//   S  wave 1, meanwhile: X, U, lambda, rho, parameters -> LDS; J0 = sum of the knot costs in order
+//   F  both waves: the two-wave forward pass on the LDS block (forward2_body)
+// Same device code as the separate kernels, hence the same numbers.  fp64, n = 3, m = 2 only.
+// -------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A, const ProblemDesc* __restrict__ pdg,
+                                                            const ProblemDesc pd_arg, DevOpts o, int mode) {
+  using T = double;
+  using R = Rec<T, M::n, M::m>;
+  constexpr int nm = M::n + M::m;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const ProblemDesc* pd = &pd_arg;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (blockIdx.x == 0 && tid == 0) publish_count(A);
+  const int b = instance_of_slot(A, blockIdx.x, 0);
+  if (b < 0) return;  // uniform over the workgroup
+  const int N = A.N;
+  const unsigned Bp = A.Bp;
+  // LDS: the forward block of one instance, then {pool, hand-off slots, flags} exactly as k_forward2
+  // lays them out, then the fused extras: fh[4] and a junk slot per lane for the backward wave
+  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, R::V};
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  T* sKDf = sm + L.nX + L.nU;
+  T* sPool = sm + L.total();
+  T* xch = sPool + L.padv(pd->npool);
+  int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);
+  double* fh = reinterpret_cast<double*>(flags + 2 * kBlock);
+  const int fused_junk = (int)((fh + 6) - sKDf);
+
+  // ---- E ----
+  for (int k = tid; k <= N; k += 2 * kBlock) expansion_body<T, M>(A, pdg, b, k);
+  __syncthreads();  // drains the stores: the records are in L2 for the backward wave
+
+  if (wave == 0) {
+    // ---- B ----
+    backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+  } else {
+    // ---- S ----
+    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, kBlock, false);
+    // running cost in knot order (ilqr.hpp:326-334): fetch side by side, hand over one by one
+    double J0 = 0.0;
+    for (int base = 0; base <= N; base += 2 * kBlock) {
+      const int k0 = base + lane, k1 = base + kBlock + lane;
+      const double v0 = A.costs[(unsigned)(k0 <= N ? k0 : N) * Bp + (unsigned)b];
+      const double v1 = A.costs[(unsigned)(k1 <= N ? k1 : N) * Bp + (unsigned)b];
+      for (int j = 0; j < kBlock && base + j <= N; ++j) J0 += __shfl(v0, j);
+      for (int j = 0; j < kBlock && base + kBlock + j <= N; ++j) J0 += __shfl(v1, j);
+    }
+    if (lane == 0) {
+      A.J0[b] = J0;
+      double ic = A.initial_cost[b];
+      if (A.need_init_cost[b]) {
+        ic = J0;
+        A.initial_cost[b] = J0;
+        A.need_init_cost[b] = 0;
+      }
+      fh[0] = J0;
+      fh[3] = ic;
+    }
+  }
+  __syncthreads();
+
+  // ---- F ----
+  forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh);
+
+  // the gains for the getters (the next sweep does not read them)
+  __syncthreads();
+  for (int i = tid; i < N * R::KP; i += 2 * kBlock) {
+    const int k = i / R::KP, e = i - k * R::KP;
+    RECP(A.KD, k, R::KP)[e] = sKDf[i];
+  }
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)

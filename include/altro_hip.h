@@ -145,7 +145,9 @@ typedef struct altro_timing {
   double expansions_ms;    /* sum over sweeps of the expansions kernel (HIP events)         */
   double backward_pass_ms; /* sum over sweeps of the backward-pass kernel                   */
   double forward_pass_ms;  /* sum over sweeps of the forward-pass (+AL update) kernel       */
-  int sweeps;              /* number of batched iLQR sweeps launched                        */
+  double fused_ms;         /* sum over the tail sweeps that ran as ONE fused kernel         */
+  int sweeps;              /* number of batched iLQR sweeps launched (fused ones included)  */
+  int fused_sweeps;        /* how many of them were fused                                   */
   int launches;            /* number of kernel launches                                     */
   long long instance_iterations; /* sum over instances of iterations_total                  */
 } altro_timing;

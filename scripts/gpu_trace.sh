@@ -11,18 +11,24 @@ rows = list(csv.DictReader(open(f)))
 ev=[]
 for r in rows:
     name=r['Kernel_Name']
-    short = 'fwd' if 'k_forward' in name else 'bwd' if 'k_backward' in name else 'exp' if 'k_expansions' in name else 'oth:'+name[:30]
-    ev.append((int(r['Start_Timestamp']),int(r['End_Timestamp']),short))
+    short = 'fused' if 'k_sweep_fused' in name else 'fwd' if 'k_forward' in name else 'bwd' if 'k_backward' in name else 'exp' if 'k_expansions' in name else None
+    if short: ev.append((int(r['Start_Timestamp']),int(r['End_Timestamp']),short))
 ev.sort()
-seq=[e for e in ev]
-first=[i for i,e in enumerate(seq) if e[2]=='exp'][0]
-print('kernels', len(seq))
-for base in (first, first+3*5, first+3*60):
-    for j in range(base, base+7):
-        s,e,k=seq[j]
+# first solve = up to the first long gap (> 1 ms) after it started
+end = len(ev)
+for i in range(1, len(ev)):
+    if ev[i][0] - ev[i-1][1] > 1_000_000: end = i; break
+seq = ev[:end]
+def show(lo, hi):
+    for j in range(lo, min(hi, len(seq)-1)):
+        s,e,k = seq[j]
         print(k, 'dur %.1f' % ((e-s)/1e3), 'gap_to_next %.1f' % ((seq[j+1][0]-e)/1e3))
     print('--')
-n=3*119
-tot=seq[first+n-1][1]-seq[first][0]
-print('first solve span ms',tot/1e6, 'kernel sum ms', sum(e-s for s,e,k in seq[first:first+n])/1e6)
+show(0, 7); show(15, 22)
+nf = [i for i,e in enumerate(seq) if e[2]=='fused']
+if nf: show(nf[0]-3, nf[0]+4); show(nf[len(nf)//2], nf[len(nf)//2]+4)
+import collections
+tot = collections.defaultdict(float); cnt = collections.Counter()
+for s,e,k in seq: tot[k] += (e-s)/1e3; cnt[k] += 1
+print({k: (cnt[k], round(tot[k]/1e3,3)) for k in tot}, 'first solve span ms', (seq[-1][1]-seq[0][0])/1e6)
 PY
