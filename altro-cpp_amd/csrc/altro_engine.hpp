@@ -832,7 +832,7 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
-      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock) * sizeof(double);
+      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock + 2) * sizeof(double);
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
@@ -900,6 +900,7 @@ class Engine final : public EngineBase {
     for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
     std::vector<char> fused_flag;
+    bool persistent_launched = false;
     const bool fused_ok = FusedOk(d);
     auto enqueue_sweep = [&](int i) -> altro_status {
       DevArrays<T> A = A_;
@@ -923,13 +924,15 @@ class Engine final : public EngineBase {
           hipEventRecord(ProfEvent(nev++), stream_);
         }
         if constexpr (kMfmaBackward) {
+          A.next_list = nullptr;  // nobody comes after this launch
+          A.next_count = nullptr;
           hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(2 * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
-                             mode);
+                             mode, 1, d_counter_ + max_sweeps + 1);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+        persistent_launched = true;
         fused_flag.push_back(1);
         timing_.launches += 1;
-        timing_.fused_sweeps += 1;
         return ALTRO_OK;
       }
       fused_flag.push_back(0);
@@ -979,6 +982,7 @@ class Engine final : public EngineBase {
       st = enqueue_sweep(sweeps);  // publishes the count left by sweep (sweeps - 1)
       if (st != ALTRO_OK) return st;
       sweeps++;
+      if (persistent_launched) break;  // that launch iterates every remaining instance to the end
       st = wait_count(sweeps - 2, &known_count);
       if (st != ALTRO_OK) return st;
       if (known_count == 0) finished = true;
@@ -996,12 +1000,19 @@ class Engine final : public EngineBase {
       fprintf(stderr, "  B: %lld %lld\n", h[17] - h[16], h[18] - h[16]);
     }
 #endif
+    const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
+    if (persistent_launched) {
+      int extra = 0;
+      ALTRO_HIP_CHECK(hipMemcpy(&extra, d_counter_ + max_sweeps + 1, sizeof(int), hipMemcpyDeviceToHost));
+      timing_.fused_sweeps = extra;
+      sweeps += extra - 1;
+    }
     timing_.sweeps = sweeps;
     if (prof) {
       float ms = 0;
       hipEventElapsedTime(&ms, prof_ev_[0], prof_ev_[1]);
       timing_.init_ms = ms;
-      for (int i = 0; i < sweeps; ++i) {
+      for (int i = 0; i < launched_sweeps; ++i) {
         const size_t e0 = 1 + (size_t)i * 3;
         hipEventElapsedTime(&ms, prof_ev_[e0], prof_ev_[e0 + 1]);
         timing_.expansions_ms += ms;

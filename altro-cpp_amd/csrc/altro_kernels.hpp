@@ -914,7 +914,8 @@ ALTRO_DEV bool conv_stats_and_done_pre(const DevArrays<T>& A, const DevOpts& o, 
 template <class T, class M>
 ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
-                              int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre) {
+                              int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
+                              int* active_out = nullptr) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -1018,6 +1019,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     }
   }
   if (t != 0) return;
+  if (active_out) *active_out = active ? 1 : 0;  // persistent sweep kernel: keep iterating?
   if (!active) {
     A.phase[b] = 0;
   } else if (A.next_count) {
@@ -1775,7 +1777,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 template <class T, class M, bool FUSED>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
-                             const double* fh) {
+                             const double* fh, int* active_out = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1993,7 +1995,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   viol = max_(viol, (xch + 8)[grp]);
   STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
-                       (double)viol, sKD, sU, pre);
+                       (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr);
   STAMP(8 + 6);
 }
 
@@ -2016,10 +2018,14 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
 //   S  wave 1, meanwhile: X, U, lambda, rho, parameters -> LDS; J0 = sum of the knot costs in order
 //   F  both waves: the two-wave forward pass on the LDS block (forward2_body)
 // Same device code as the separate kernels, hence the same numbers.  fp64, n = 3, m = 2 only.
+// persistent != 0: instances are independent, so the workgroup simply keeps iterating until ITS
+// instance is finished (the AL state machine of phase 3 says so) -- no further launches, no host in
+// the loop; *sweeps_out receives the largest number of iterations any workgroup ran.
 // -------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A, const ProblemDesc* __restrict__ pdg,
-                                                            const ProblemDesc pd_arg, DevOpts o, int mode) {
+                                                            const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
+                                                            int* sweeps_out) {
   using T = double;
   using R = Rec<T, M::n, M::m>;
   constexpr int nm = M::n + M::m;
@@ -2042,48 +2048,57 @@ __global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A,
   double* fh = reinterpret_cast<double*>(flags + 2 * kBlock);
   const int fused_junk = (int)((fh + 6) - sKDf);
 
-  // ---- E ----
-  for (int k = tid; k <= N; k += 2 * kBlock) expansion_body<T, M>(A, pdg, b, k);
-  __syncthreads();  // drains the stores: the records are in L2 for the backward wave
+  int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
+  int loops = 0;
+  for (;;) {
+    // ---- E ----
+    for (int k = tid; k <= N; k += 2 * kBlock) expansion_body<T, M>(A, pdg, b, k);
+    __syncthreads();  // drains the stores: the records are in L2 for the backward wave
 
-  if (wave == 0) {
-    // ---- B ----
-    backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
-  } else {
-    // ---- S ----
-    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, kBlock, false);
-    // running cost in knot order (ilqr.hpp:326-334): fetch side by side, hand over one by one
-    double J0 = 0.0;
-    for (int base = 0; base <= N; base += 2 * kBlock) {
-      const int k0 = base + lane, k1 = base + kBlock + lane;
-      const double v0 = A.costs[(unsigned)(k0 <= N ? k0 : N) * Bp + (unsigned)b];
-      const double v1 = A.costs[(unsigned)(k1 <= N ? k1 : N) * Bp + (unsigned)b];
-      for (int j = 0; j < kBlock && base + j <= N; ++j) J0 += __shfl(v0, j);
-      for (int j = 0; j < kBlock && base + kBlock + j <= N; ++j) J0 += __shfl(v1, j);
-    }
-    if (lane == 0) {
-      A.J0[b] = J0;
-      double ic = A.initial_cost[b];
-      if (A.need_init_cost[b]) {
-        ic = J0;
-        A.initial_cost[b] = J0;
-        A.need_init_cost[b] = 0;
+    if (wave == 0) {
+      // ---- B ----
+      backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+    } else {
+      // ---- S ----
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, kBlock, false);
+      // running cost in knot order (ilqr.hpp:326-334): fetch side by side, hand over one by one
+      double J0 = 0.0;
+      for (int base = 0; base <= N; base += 2 * kBlock) {
+        const int k0 = base + lane, k1 = base + kBlock + lane;
+        const double v0 = A.costs[(unsigned)(k0 <= N ? k0 : N) * Bp + (unsigned)b];
+        const double v1 = A.costs[(unsigned)(k1 <= N ? k1 : N) * Bp + (unsigned)b];
+        for (int j = 0; j < kBlock && base + j <= N; ++j) J0 += __shfl(v0, j);
+        for (int j = 0; j < kBlock && base + kBlock + j <= N; ++j) J0 += __shfl(v1, j);
       }
-      fh[0] = J0;
-      fh[3] = ic;
+      if (lane == 0) {
+        A.J0[b] = J0;
+        double ic = A.initial_cost[b];
+        if (A.need_init_cost[b]) {
+          ic = J0;
+          A.initial_cost[b] = J0;
+          A.need_init_cost[b] = 0;
+        }
+        fh[0] = J0;
+        fh[3] = ic;
+      }
     }
+    __syncthreads();
+
+    // ---- F ----
+    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag);
+    ++loops;
+    __syncthreads();
+    if (!persistent || *active_flag == 0) break;
+    // (waves of a workgroup share the CU's vector L1, which stores write through and keep coherent,
+    // so what this iteration wrote -- trajectory, multipliers, records -- is what the next one reads)
+    __syncthreads();  // everyone has read the flag before phase 3 of the next iteration rewrites it
   }
-  __syncthreads();
-
-  // ---- F ----
-  forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh);
-
-  // the gains for the getters (the next sweep does not read them)
-  __syncthreads();
+  // the gains for the getters (nothing inside the sweep reads them from global memory)
   for (int i = tid; i < N * R::KP; i += 2 * kBlock) {
     const int k = i / R::KP, e = i - k * R::KP;
     RECP(A.KD, k, R::KP)[e] = sKDf[i];
   }
+  if (sweeps_out && tid == 0) atomicMax(sweeps_out, loops);
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)
