@@ -75,6 +75,8 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
+    persist_at_ = num_cus_;
+    if (const char* e = std::getenv("ALTRO_HIP_PERSIST_AT")) persist_at_ = atoi(e);
     return ReserveCounters(1024);
   }
   // one counter per sweep (device: filled by the forward kernel's atomics; host: pinned + mapped,
@@ -391,7 +393,7 @@ class Engine final : public EngineBase {
       const int per_wave = (ninst <= num_cus_) ? 1 : fwd_per_wave_;
       const size_t lds = fwd_shared_bytes_ + (size_t)per_wave * fwd_per_inst_bytes_;
       const dim3 grid2((ninst + per_wave - 1) / per_wave);
-      hipLaunchKernelGGL((k_forward2<T, M>), grid2, dim3(2 * kBlock), lds, stream_, A, d_pd_, pd_, d, mode, all,
+      hipLaunchKernelGGL((k_forward2<T, M>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode, all,
                          per_wave);
       return;
     }
@@ -827,8 +829,10 @@ class Engine final : public EngineBase {
       const int lanes_max = kBlock / kLineSearchLanes;
       fwd_per_wave_ = lanes_max;
       while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
-      const size_t shared_bytes = (padv(pool.size()) + 2 * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int);
+      const size_t shared_bytes = (padv(pool.size()) + 2 * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int) +
+                                  kBlock * sizeof(double);
       while (fwd_per_wave_ > 1 && shared_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
+      if (const char* e = std::getenv("ALTRO_HIP_FWD_PER_WAVE")) fwd_per_wave_ = std::max(1, std::min(fwd_per_wave_, atoi(e)));
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
@@ -917,7 +921,7 @@ class Engine final : public EngineBase {
       A.next_list = d_list_[(i + 1) % 2];
       A.next_count = d_counter_ + i;
       const int ninst = std::max(1, known_count);
-      if (fused_ok && i > 0 && ninst <= num_cus_) {
+      if (fused_ok && i > 0 && ninst <= persist_at_) {
         // the tail: every instance gets a workgroup that runs the whole iteration (k_sweep_fused)
         if (prof) {
           hipEventRecord(ProfEvent(nev++), stream_);
@@ -926,7 +930,7 @@ class Engine final : public EngineBase {
         if constexpr (kMfmaBackward) {
           A.next_list = nullptr;  // nobody comes after this launch
           A.next_count = nullptr;
-          hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(2 * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
+          hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
                              mode, 1, d_counter_ + max_sweeps + 1);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
@@ -994,7 +998,7 @@ class Engine final : public EngineBase {
       long long h[24];
       hipMemcpy(h, A_.dbg, sizeof(h), hipMemcpyDeviceToHost);
       fprintf(stderr, "stamps(cycles rel. to wave0 entry): R:");
-      for (int i = 0; i < 4; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
+      for (int i = 0; i < 5; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
       fprintf(stderr, "  C:");
       for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
       fprintf(stderr, "  B: %lld %lld\n", h[17] - h[16], h[18] - h[16]);
@@ -1051,6 +1055,7 @@ class Engine final : public EngineBase {
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
+  int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;
   T *X_init_ = nullptr, *U_init_ = nullptr;

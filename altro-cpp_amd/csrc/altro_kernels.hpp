@@ -29,6 +29,7 @@
 namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
+constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost wave, auxiliary wave
 
 // constraint rows and per-instance scalars: arr[row*Bp + b]
 #define SOA(arr, row) (arr)[(unsigned)(row) * (unsigned)Bp + (unsigned)b]
@@ -1568,13 +1569,51 @@ struct RolloutBounds {
   }
 };
 
-template <class T, class M, int FK>
-ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
-                                 int kend, const T* sKD, const T* xch, int lane, bool valid, unsigned tb,
-                                 double& J, double& gs, RolloutBounds<T>& bnd) {
+// The auxiliary wave of the forward pass, one knot per barrier like the cost wave: the rollout's bound
+// checks (RolloutBounds), the gradient measure of the trial (ilqr.hpp:574-583 with the trial's controls)
+// and the candidate store.  None of it feeds the cost, so it runs beside the cost wave.
+template <class T, class M>
+ALTRO_DEV void aux_consumer_run(const DevArrays<T>& A, int kbegin, int kend, const T* sKD, const T* xch, int lane,
+                                bool valid, unsigned tb, double& gs, RolloutBounds<T>& bnd) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
+  for (int k = kbegin; k < kend; ++k) {
+    lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
+    const T* slot = xch + (k & 1) * (nm * kBlock);
+    T xb[n], ub[m], d[m];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
+#pragma unroll
+    for (int i = 0; i < m; ++i) d[i] = sKD[k * R::KP + R::oD + i];
+    bnd.template visit<n, m>(xb, ub);
+    // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
+    T gnum = T(0), gden = T(1);
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      const T num = abs_(d[i]), den = abs_(ub[i]) + T(1);
+      if (num * gden > gnum * den) {
+        gnum = num;
+        gden = den;
+      }
+    }
+    gs += (double)(gnum / gden);
+    if (valid) {  // idle lanes must not touch instance 0's candidates
+      T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
+#pragma unroll
+      for (int i = 0; i < n; ++i) cand[i] = xb[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
+    }
+  }
+}
+
+template <class T, class M, int FK>
+ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
+                                 int kend, const T* xch, int lane, double& J) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
   const KnotClass& kc = pd->cls[run.cls];
   RunConsts<T, n, m> RC;
   load_run_consts<T, n, m>(C, pd, kc, RC);
@@ -1594,14 +1633,11 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   for (int k = run.k_begin; k < kend; ++k) {
     lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
     const T* slot = xch + (k & 1) * (nm * kBlock);
-    T xb[n], ub[m], d[m];
+    T xb[n], ub[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
 #pragma unroll
     for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
-#pragma unroll
-    for (int i = 0; i < m; ++i) d[i] = sKD[k * R::KP + R::oD + i];
-    bnd.template visit<n, m>(xb, ub);
     const int rb = run.rowbase + (k - run.k_begin) * nrows;
     T blam[2 * m], brho = T(1);
     if (kHasB) {
@@ -1609,17 +1645,6 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
 #pragma unroll
       for (int j = 0; j < 2 * m; ++j) blam[j] = C.lam(rb + b_row + j);
     }
-    // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
-    T gnum = T(0), gden = T(1);
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      const T num = abs_(d[i]), den = abs_(ub[i]) + T(1);
-      if (num * gden > gnum * den) {
-        gnum = num;
-        gden = den;
-      }
-    }
-    gs += (double)(gnum / gden);
     if (FK == kFastGeneric) {
       J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
     } else {
@@ -1681,13 +1706,6 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
         circle_term();
       }
       J += (double)Jk;
-    }
-    if (valid) {  // idle lanes must not touch instance 0's candidates
-      T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
-#pragma unroll
-      for (int i = 0; i < n; ++i) cand[i] = xb[i];
-#pragma unroll
-      for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
     }
   }
 }
@@ -1811,8 +1829,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
+  double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
-    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, 2 * kBlock, true);
+    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock, true);
     __syncthreads();
   }
   STAMP(wave * 8 + 1);
@@ -1867,7 +1886,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     STAMP(2);
     lds_barrier();  // barrier N
     STAMP(3);
-    // phase 2 is shared by both waves: wait for the selection, take the odd blocks of knots
+    lds_barrier();  // barrier A (auxiliary wave -> cost wave)
+    // phase 2 is shared by all waves: wait for the selection, take every third block of knots
     __syncthreads();  // barrier S
     {
       const int* sel = reinterpret_cast<const int*>(xch);
@@ -1875,10 +1895,54 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       T viol = T(0);
       if (valid) {
         CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
-        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, 2 * LS);
+        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart[grp] = vm;
+      }
+    }
+    __syncthreads();  // barrier V
+    return;
+  }
+
+  // candidate scratch, instance-major [b][k][trial][x|u]
+  const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
+  if (wave == 2) {
+    // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
+    double gs = 0.0;
+    RolloutBounds<T> bnd;
+    bnd.check = o.check_forwardpass_bounds != 0;
+    bnd.smax2 = T(o.state_max) * T(o.state_max);
+    bnd.umax2 = T(o.control_max) * T(o.control_max);
+    aux_consumer_run<T, M>(A, 0, N, sKD, xch, lane, valid, tb, gs, bnd);
+    lds_barrier();  // barrier N: terminal state
+    {
+      const T* slot = xch + (N & 1) * (nm * kBlock);
+      T xN[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
+      bnd.template settle<n>(xN);  // the last step of the rollout
+      if (valid) {
+        T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
+#pragma unroll
+        for (int i = 0; i < n; ++i) cand[i] = xN[i];
+      }
+      flags[lane] = bnd.ok ? 1 : 0;
+      flags[kBlock + lane] = bnd.st;
+      gsx[lane] = gs;
+    }
+    lds_barrier();    // barrier A
+    __syncthreads();  // barrier S
+    {
+      const int* sel = reinterpret_cast<const int*>(xch);
+      T* vpart2 = xch + 12;
+      if (valid) {
+        CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
+        const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
+                                            kFwdWaves * LS);
+        T vm = viol;
+        for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
+        if (t == 0) vpart2[grp] = vm;
       }
     }
     __syncthreads();  // barrier V
@@ -1895,17 +1959,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     pre.rho_reg = fh[4];
     pre.drho = fh[5];
   }
-  // candidate scratch, instance-major [b][k][trial][x|u]
-  const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
-  double J = 0.0, gs = 0.0;
-  RolloutBounds<T> bnd;
-  bnd.check = o.check_forwardpass_bounds != 0;
-  bnd.smax2 = T(o.state_max) * T(o.state_max);
-  bnd.umax2 = T(o.control_max) * T(o.control_max);
+  double J = 0.0;
   for (int r = 0; r < pd->nruns; ++r) {
     const KnotRun run = pd->runs[r];
     const int kend = run.k_end < N ? run.k_end : N;
-#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, sKD, xch, lane, valid, tb, J, gs, bnd)
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, xch, lane, J)
     switch (run.fast) {
       case kFastNone: ALTRO_RUN(kFastNone); break;
       case kFastB: ALTRO_RUN(kFastB); break;
@@ -1919,27 +1977,21 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   STAMP(8 + 2);
   lds_barrier();  // barrier N: terminal state and rollout outcome
   STAMP(8 + 3);
-  bool ok;
-  int st;
   {
     const T* slot = xch + (N & 1) * (nm * kBlock);
     T xN[n], uz[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
-    bnd.template settle<n>(xN);  // the last step of the rollout
-    ok = bnd.ok;
-    st = bnd.st;
 #pragma unroll
     for (int i = 0; i < m; ++i) uz[i] = T(0);
     const KnotRun runN = pd->runs[pd->nruns - 1];  // the terminal knot closes the last run
     const KnotClass& kcN = pd->cls[runN.cls];
     J += (double)knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xN, uz, nullptr);
-    if (valid) {
-      T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
-#pragma unroll
-      for (int i = 0; i < n; ++i) cand[i] = xN[i];
-    }
   }
+  lds_barrier();  // barrier A: the auxiliary wave's verdicts
+  const bool ok = flags[lane] != 0;
+  const int st = flags[kBlock + lane];
+  const double gs = gsx[lane];
   // ---- acceptance test (ilqr.hpp:528-542) and selection of the first accepted trial --------------
   const bool live = valid && (t < ls_max);
   const double expected = -(double)alpha * (dV0 + (double)alpha * dV1);
@@ -1985,14 +2037,14 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   __syncthreads();  // barrier S: selection visible, candidate stores of this wave drained
   T viol = T(0);
   if (valid) {
-    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, 2 * LS);
+    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
   }
   __syncthreads();  // barrier V: the other wave's share of the violation
   if (!valid) return;
-  viol = max_(viol, (xch + 8)[grp]);
+  viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
   STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr);
@@ -2000,7 +2052,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 }
 
 template <class T, class M>
-__global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+__global__ __launch_bounds__(kFwdWaves * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                          const ProblemDesc pd_arg, DevOpts o, int mode, int all,
                                                          int per_wave) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2023,7 +2075,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_forward2(DevArrays<T> A, const P
 // the loop; *sweeps_out receives the largest number of iterations any workgroup ran.
 // -------------------------------------------------------------------------------------------------
 template <class M>
-__global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A, const ProblemDesc* __restrict__ pdg,
+__global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<double> A, const ProblemDesc* __restrict__ pdg,
                                                             const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
                                                             int* sweeps_out) {
   using T = double;
@@ -2045,22 +2097,33 @@ __global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A,
   T* sPool = sm + L.total();
   T* xch = sPool + L.padv(pd->npool);
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);
-  double* fh = reinterpret_cast<double*>(flags + 2 * kBlock);
+  double* fh = reinterpret_cast<double*>(flags + 2 * kBlock) + kBlock;  // behind the gradient slots
   const int fused_junk = (int)((fh + 6) - sKDf);
 
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
   int loops = 0;
+#ifdef ALTRO_X
+#define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
+#else
+#define FSTAMP(i)
+#endif
   for (;;) {
+    FSTAMP(wave * 8 + 0);
     // ---- E ----
-    for (int k = tid; k <= N; k += 2 * kBlock) expansion_body<T, M>(A, pdg, b, k);
+    for (int k = tid; k <= N; k += kFwdWaves * kBlock) expansion_body<T, M>(A, pdg, b, k);
     __syncthreads();  // drains the stores: the records are in L2 for the backward wave
+    FSTAMP(wave * 8 + 1);
 
     if (wave == 0) {
       // ---- B ----
       backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+      FSTAMP(2);
+    } else if (wave == 2) {
+      // ---- S (first half) ----
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, 2 * kBlock, false);
     } else {
-      // ---- S ----
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, kBlock, false);
+      // ---- S (second half) ----
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, kBlock + lane, 2 * kBlock, false);
       // running cost in knot order (ilqr.hpp:326-334): fetch side by side, hand over one by one
       double J0 = 0.0;
       for (int base = 0; base <= N; base += 2 * kBlock) {
@@ -2081,11 +2144,14 @@ __global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A,
         fh[0] = J0;
         fh[3] = ic;
       }
+      FSTAMP(8 + 2);
     }
     __syncthreads();
+    FSTAMP(wave * 8 + 3);
 
     // ---- F ----
     forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag);
+    FSTAMP(wave * 8 + 4);
     ++loops;
     __syncthreads();
     if (!persistent || *active_flag == 0) break;
@@ -2094,7 +2160,7 @@ __global__ __launch_bounds__(2 * kBlock) void k_sweep_fused(DevArrays<double> A,
     __syncthreads();  // everyone has read the flag before phase 3 of the next iteration rewrites it
   }
   // the gains for the getters (nothing inside the sweep reads them from global memory)
-  for (int i = tid; i < N * R::KP; i += 2 * kBlock) {
+  for (int i = tid; i < N * R::KP; i += kFwdWaves * kBlock) {
     const int k = i / R::KP, e = i - k * R::KP;
     RECP(A.KD, k, R::KP)[e] = sKDf[i];
   }
