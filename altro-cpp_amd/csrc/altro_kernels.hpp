@@ -1851,17 +1851,27 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     T trig_s = T(0), trig_c = T(1);
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      T xk[R::nP], uk[R::mP], kd[R::KP], ub[m], xn[n];
-      load_rec<T, R::nP>(sX + k * R::nP, xk);
-      load_rec<T, R::mP>(sU + k * R::mP, uk);
-      load_rec<T, R::KP>(sKD + k * R::KP, kd);
+    // One knot of the rollout.  The nominal knot (xbar, ubar, K, d) comes from LDS one knot AHEAD: the
+    // reads for knot k + 1 are issued before the arithmetic of knot k, so their latency hides behind
+    // it; two register sets alternate (the loop is unrolled by two, no copies).
+    struct Nominal {
+      T xk[R::nP], uk[R::mP], kd[R::KP];
+    };
+    auto fetch = [&](int k, Nominal& q) __attribute__((always_inline)) {
+      const int kc = k < N ? k : N - 1;
+      load_rec<T, R::nP>(sX + kc * R::nP, q.xk);
+      load_rec<T, R::mP>(sU + kc * R::mP, q.uk);
+      load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
+    };
+    auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
+      T ub[m], xn[n];
+      fetch(k + 1, nxt);
 #pragma unroll
       for (int i = 0; i < m; ++i) {
-        T s = T(0);
+        T sacc = T(0);
 #pragma unroll
-        for (int l = 0; l < n; ++l) s += kd[R::oK + i + l * m] * (xb[l] - xk[l]);
-        ub[i] = uk[i] + s + kd[R::oD + i] * alpha;
+        for (int l = 0; l < n; ++l) sacc += cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
+        ub[i] = cur.uk[i] + sacc + cur.kd[R::oD + i] * alpha;
       }
       T* slot = xch + (k & 1) * (nm * kBlock);
 #pragma unroll
@@ -1878,6 +1888,16 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
       lds_barrier();  // barrier k
+    };
+    {
+      Nominal qa, qb;
+      fetch(0, qa);
+      int k = 0;
+      for (; k + 1 < N; k += 2) {
+        knot(k, qa, qb);
+        knot(k + 1, qb, qa);
+      }
+      if (k < N) knot(k, qa, qb);
     }
     // final hand-off: x_N
     T* slot = xch + (N & 1) * (nm * kBlock);
