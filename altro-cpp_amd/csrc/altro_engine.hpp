@@ -894,10 +894,10 @@ class Engine final : public EngineBase {
     // stays one sweep ahead of the device, and sizes each grid with the newest count it knows --
     // counts only shrink, so it is an upper bound -- so tail sweeps launch a handful of workgroups.
     {
-      altro_status rs = ReserveCounters(max_sweeps + 2);
+      altro_status rs = ReserveCounters(max_sweeps + 4);
       if (rs != ALTRO_OK) return rs;
     }
-    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 2) * sizeof(int), stream_));
+    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 4) * sizeof(int), stream_));
 #ifdef ALTRO_X
     if (!A_.dbg) hipMalloc((void**)&A_.dbg, 24 * sizeof(long long));
 #endif
@@ -931,7 +931,7 @@ class Engine final : public EngineBase {
           A.next_list = nullptr;  // nobody comes after this launch
           A.next_count = nullptr;
           hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
-                             mode, 1, d_counter_ + max_sweeps + 1);
+                             mode, 1, d_counter_ + max_sweeps + 2);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
         persistent_launched = true;
@@ -1006,10 +1006,11 @@ class Engine final : public EngineBase {
 #endif
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
     if (persistent_launched) {
-      int extra = 0;
-      ALTRO_HIP_CHECK(hipMemcpy(&extra, d_counter_ + max_sweeps + 1, sizeof(int), hipMemcpyDeviceToHost));
-      timing_.fused_sweeps = extra;
-      sweeps += extra - 1;
+      int extra[2] = {0, 0};
+      ALTRO_HIP_CHECK(hipMemcpy(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      timing_.fused_sweeps = extra[0];
+      timing_.fused_instance_iterations = extra[1];
+      sweeps += extra[0] - 1;
     }
     timing_.sweeps = sweeps;
     if (prof) {

@@ -2184,7 +2184,10 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
     const int k = i / R::KP, e = i - k * R::KP;
     RECP(A.KD, k, R::KP)[e] = sKDf[i];
   }
-  if (sweeps_out && tid == 0) atomicMax(sweeps_out, loops);
+  if (sweeps_out && tid == 0) {
+    atomicMax(sweeps_out, loops);     // longest chain of iterations
+    atomicAdd(sweeps_out + 1, loops);  // (instance, iteration) units processed by this launch
+  }
 }
 
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)

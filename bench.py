@@ -133,24 +133,34 @@ def main():
         tm = solver.get_timing()
         solver.set_options(profiler_enable=0)
         ab = algorithmic_bytes(n, m, N, 4, 3, 8)
+        # Kernels of one solve: the three sweep kernels while thousands of instances iterate, then ONE
+        # persistent launch of k_sweep_fused that runs every remaining iteration of the stragglers
+        # (expansions + backward + forward of one instance per workgroup).
         kern_ms = {"expansions": tm["expansions_ms"], "backward_pass": tm["backward_pass_ms"],
-                   "forward_pass": tm["forward_pass_ms"]}
+                   "forward_pass": tm["forward_pass_ms"], "sweep_fused": tm["fused_ms"]}
         dom = max(kern_ms, key=kern_ms.get)
-        units = tm["instance_iterations"]  # (trajectory, iteration) units processed by the launches
-        launches = tm["sweeps"]
-        avg_launch_ms = kern_ms[dom] / max(launches, 1)
-        achieved = ab[dom] * units / max(launches, 1) / (avg_launch_ms * 1e-3) / 1e9  # GB/s
+        units_total = tm["instance_iterations"]  # (trajectory, iteration) units of the whole solve
+        units_fused = tm["fused_instance_iterations"]
+        if dom == "sweep_fused":
+            launches, units, bytes_per_unit = 1, units_fused, ab["total"]
+        else:
+            launches = tm["sweeps"] - tm["fused_sweeps"]
+            units, bytes_per_unit = units_total - units_fused, ab[dom]
+        launches = max(launches, 1)
+        avg_launch_ms = kern_ms[dom] / launches
+        achieved = bytes_per_unit * units / launches / (avg_launch_ms * 1e-3) / 1e9  # GB/s
         sweep_ms = sum(kern_ms.values())
-        achieved_all = ab["total"] * units / (sweep_ms * 1e-3) / 1e9
+        achieved_all = ab["total"] * units_total / (sweep_ms * 1e-3) / 1e9
         # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
         # same command (FETCH_SIZE / WRITE_SIZE in separate --pmc runs, gfx950 correction applied --
         # see profiles/rNN_traffic.json); bench.py itself cannot run the profiler.
         traffic, traffic_src = None, None
         import glob
+        key = {"expansions": "k_expansions", "backward_pass": "k_backward", "forward_pass": "k_forward",
+               "sweep_fused": "k_sweep_fused"}[dom]
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
             try:
                 tj = json.load(open(f))
-                key = "k_" + dom.replace("_pass", "")
                 if key in tj:
                     traffic = round(tj[key]["traffic_bytes_per_launch"])
                     traffic_src = os.path.relpath(f, ROOT)
@@ -158,16 +168,19 @@ def main():
             except Exception:
                 pass
         roofline = {
-            "bound": "hbm", "kernel": "k_" + dom.replace("_pass", ""), "achieved": round(achieved, 2),
+            "bound": "hbm", "kernel": key, "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(1e3 * avg_launch_ms, 2), "launches": launches,
-            "algorithmic_bytes_per_launch": round(ab[dom] * units / max(launches, 1)),
+            "units_per_launch": round(units / launches, 1),
+            "algorithmic_bytes_per_launch": round(bytes_per_unit * units / launches),
             "all_kernels_achieved": round(achieved_all, 2),
             "all_kernels_frac": round(achieved_all / HBM_PEAK_GBS, 5),
             "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
-            "limiter": "serial dependency chain (N Riccati steps + N RK4 steps per iteration, "
-                       "max iterations over the batch), not HBM",
+            "tail_iterations": tm["fused_sweeps"],
+            "limiter": "serial dependency chain: the dominant launch is the persistent tail kernel, a few dozen "
+                       "straggler instances x ~100 iterations x (101 Riccati steps + 101 RK4 steps), one "
+                       "workgroup each -- latency of one wavefront's instruction stream, not HBM",
         }
         # ---- CPU baseline: the oracle (a port, see oracle/altro_oracle.cpp) on the host cores --------
         cpu = None

@@ -150,6 +150,7 @@ typedef struct altro_timing {
   int fused_sweeps;        /* how many of them were fused                                   */
   int launches;            /* number of kernel launches                                     */
   long long instance_iterations; /* sum over instances of iterations_total                  */
+  long long fused_instance_iterations; /* (instance, iteration) units run by the fused launch */
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

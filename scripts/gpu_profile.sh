@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 python - <<'PY'
 import csv, glob, collections, json
 def short(name):
-    for k, v in (('k_forward', 'k_forward'), ('k_backward', 'k_backward'), ('k_expansions', 'k_expansions'), ('k_rollout', 'k_rollout'), ('k_al_init', 'k_al_init'), ('k_solve_setup', 'k_solve_setup'), ('k_pack_results', 'k_pack_results')):
+    for k, v in (('k_sweep_fused', 'k_sweep_fused'), ('k_forward', 'k_forward'), ('k_backward', 'k_backward'), ('k_expansions', 'k_expansions'), ('k_rollout', 'k_rollout'), ('k_al_init', 'k_al_init'), ('k_solve_setup', 'k_solve_setup'), ('k_pack_results', 'k_pack_results')):
         if k in name: return v
     return name[:40]
 out = {}
@@ -29,8 +29,9 @@ if f:
     for r in csv.DictReader(open(f[0])):
         out.setdefault(short(r['Name']), {})['trace'] = {'calls': int(r['Calls']), 'total_ns': float(r['TotalDurationNs']), 'avg_ns': float(r['AverageNs']), 'pct': float(r['Percentage'])}
 json.dump(out, open('gpurun_out/profile/summary.json', 'w'), indent=1)
-for k in ('k_forward', 'k_backward', 'k_expansions'):
+for k in ('k_sweep_fused', 'k_forward', 'k_backward', 'k_expansions'):
     print(k, json.dumps(out.get(k, {}))[:900])
 PY
 cp gpurun_out/profile/trace/*kernel_stats.csv gpurun_out/profile/kernel_stats.csv 2>/dev/null
+python bench.py --steps 5 --warmup 1 2>&1 | tail -1 > gpurun_out/profile/bench_line.json
 ls gpurun_out/profile
