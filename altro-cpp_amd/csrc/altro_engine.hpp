@@ -899,7 +899,7 @@ class Engine final : public EngineBase {
     }
     ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 4) * sizeof(int), stream_));
 #ifdef ALTRO_X
-    if (!A_.dbg) hipMalloc((void**)&A_.dbg, 24 * sizeof(long long));
+    if (!A_.dbg) hipMalloc((void**)&A_.dbg, 32 * sizeof(long long));
 #endif
     for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
@@ -995,13 +995,15 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipGetLastError());
 #ifdef ALTRO_X
     {
-      long long h[24];
+      long long h[32];
       hipMemcpy(h, A_.dbg, sizeof(h), hipMemcpyDeviceToHost);
       fprintf(stderr, "stamps(cycles rel. to wave0 entry): R:");
       for (int i = 0; i < 5; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
       fprintf(stderr, "  C:");
       for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
-      fprintf(stderr, "  B: %lld %lld\n", h[17] - h[16], h[18] - h[16]);
+      fprintf(stderr, "  B: %lld %lld", h[17] - h[16], h[18] - h[16]);
+      fprintf(stderr, "  FUSED w0[E0 Eend Bend sync]: %lld %lld %lld %lld  w1[Eend Send sync Fend]: %lld %lld %lld %lld\n", h[20] - h[20],
+              h[21] - h[20], h[22] - h[20], h[23] - h[20], h[25] - h[20], h[26] - h[20], h[27] - h[20], h[28] - h[20]);
     }
 #endif
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)

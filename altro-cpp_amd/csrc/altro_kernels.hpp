@@ -13,11 +13,15 @@
 //                    ilqr.hpp:525-545 are independent closed-loop rollouts, so each instance gets 20
 //                    lanes that evaluate alpha = 1, 1/2, ... 2^-19 side by side; a wave ballot picks
 //                    the first trial the serial loop would have accepted.  Inputs are staged in LDS;
-//                    the step is pipelined over a rollout wave and a cost wave; every trial stores
-//                    its candidate trajectory so the winner is copied, not re-integrated; the same
-//                    kernel runs the per-instance state machine: convergence statistics, IsDone,
-//                    dual/penalty update and the AL outer-loop transition (ilqr.hpp:568-619,
-//                    al_solver.hpp:313-401).  k_forward is the single-wave, HBM-reading fallback.
+//                    the step is pipelined over a rollout wave, a cost wave and an auxiliary wave
+//                    (bound checks, gradient measure, candidate stores); every trial stores its
+//                    candidate trajectory so the winner is copied, not re-integrated; the same kernel
+//                    runs the per-instance state machine: convergence statistics, IsDone, dual/penalty
+//                    update and the AL outer-loop transition (ilqr.hpp:568-619, al_solver.hpp:313-401).
+//                    k_forward is the single-wave, HBM-reading fallback.
+//   k_sweep_fused    the tail of a batched solve: one workgroup per straggler instance runs whole
+//                    iterations (expansions, MFMA backward pass, three-wave forward pass) in a loop
+//                    until its instance is finished -- one persistent launch, no host in the loop.
 //
 // Instances are independent; the ones still iterating are kept in a dense list rebuilt every sweep.
 #pragma once
@@ -2123,16 +2127,16 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
   int loops = 0;
 #ifdef ALTRO_X
-#define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
+#define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
 #else
 #define FSTAMP(i)
 #endif
   for (;;) {
-    FSTAMP(wave * 8 + 0);
+    FSTAMP(wave * 4 + 0);
     // ---- E ----
     for (int k = tid; k <= N; k += kFwdWaves * kBlock) expansion_body<T, M>(A, pdg, b, k);
     __syncthreads();  // drains the stores: the records are in L2 for the backward wave
-    FSTAMP(wave * 8 + 1);
+    FSTAMP(wave * 4 + 1);
 
     if (wave == 0) {
       // ---- B ----
@@ -2164,14 +2168,14 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
         fh[0] = J0;
         fh[3] = ic;
       }
-      FSTAMP(8 + 2);
+      FSTAMP(4 + 2);
     }
     __syncthreads();
-    FSTAMP(wave * 8 + 3);
+    FSTAMP(wave * 4 + 3);
 
     // ---- F ----
     forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag);
-    FSTAMP(wave * 8 + 4);
+    if (wave == 1) FSTAMP(8);
     ++loops;
     __syncthreads();
     if (!persistent || *active_flag == 0) break;
