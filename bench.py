@@ -187,7 +187,7 @@ def main():
         if not args.no_cpu_baseline:
             lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
             lib = ctypes.CDLL(lib_path)
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
             # single thread first: calibrates how many repetitions make ~10-30 s of CPU work
             o1 = P.batch_turn90(omake, batch=64, N=N, dtype=A.F64, seed=P.SEED_BASE + 3)
