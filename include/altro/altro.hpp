@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstddef>
 #include <limits>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -567,6 +568,34 @@ class AugmentedLagrangianiLQR {
     altro_timing t;
     detail::Check(h_, altro_get_timing(h_, &t), "altro_get_timing");
     return t;
+  }
+  // Prints the device timing of the last solve (needs SolverOptions::profiler_enable) as a tree in the
+  // layout of the reference's Timer (altro/common/timer.cpp:24-94, profile_entry.cpp:36-66; sample:
+  // perf/profiler_unicycle.out), with the reference's section names.  "sweep_fused" is this build's
+  // persistent tail launch: whole iterations (expansions + backward_pass + forward_pass) of the straggler
+  // instances.  forward_pass includes the reference's cost / rollout / stats / dual_update /
+  // penalty_update / convergence_check work, which the forward kernel performs.
+  void PrintTimings(FILE* f = stdout) {
+    const altro_timing t = GetTiming();
+    const double total = t.total_ms * 1e3;
+    const double ilqr = (t.expansions_ms + t.backward_pass_ms + t.forward_pass_ms + t.fused_ms) * 1e3;
+    auto row = [&](int depth, const char* name, double us, double parent) {
+      char label[64];
+      std::snprintf(label, sizeof(label), "%*s%s", 2 * depth, "", name);
+      std::fprintf(f, "%-28s %9.0f %8.0f %8.0f\n", label, us, total > 0 ? 100.0 * us / total : 0.0,
+                   parent > 0 ? 100.0 * us / parent : 0.0);
+    };
+    std::fprintf(f, "Description                  Time (us)   %%Total  %%Parent\n");
+    std::fprintf(f, "--------------------------------------------------------\n");
+    row(0, "al", total, total);
+    row(1, "ilqr", ilqr, total);
+    row(3, "backward_pass", t.backward_pass_ms * 1e3, ilqr);
+    row(3, "expansions", t.expansions_ms * 1e3, ilqr);
+    row(3, "forward_pass", t.forward_pass_ms * 1e3, ilqr);
+    row(3, "sweep_fused", t.fused_ms * 1e3, ilqr);
+    row(1, "init", t.init_ms * 1e3, total);
+    std::fprintf(f, "sweeps %d (tail iterations in the fused launch: %d), kernel launches %d, instance-iterations %lld\n",
+                 t.sweeps, t.fused_sweeps, t.launches, t.instance_iterations);
   }
 
  private:

@@ -52,6 +52,8 @@ static void SolveBatch(int B, int nruns) {
                 B, iter, t.total_ms, t.init_ms, t.expansions_ms, t.backward_pass_ms, t.forward_pass_ms, t.sweeps,
                 solved, B, solved / (t.total_ms * 1e-3), t.total_ms / t.sweeps);
   }
+  // the reference prints its profiler tree when the solver is destroyed (perf/profiler_unicycle.out)
+  solver.PrintTimings(stdout);
 }
 
 int main(int argc, char* argv[]) {

@@ -22,3 +22,8 @@ def test_benchmark_unicycle_driver():
     # iLQR::Cost() after the solve re-evaluates the AL cost with the updated duals (oracle: 9.437361800688565)
     assert abs(float(m.group(1)) - 9.437361800688565) < 1e-8
     assert re.search(r"batch 256 run 1: .* solved (\d+)/256", r.stdout), r.stdout
+    # profiler tree in the layout of the reference's perf/profiler_unicycle.out
+    assert "Description                  Time (us)   %Total  %Parent" in r.stdout
+    tree = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s*(\w+)\s+(\d+)\s+\d+\s+\d+\s*$", r.stdout, re.M)}
+    assert {"al", "ilqr", "backward_pass", "expansions", "forward_pass", "sweep_fused", "init"} <= set(tree)
+    assert tree["al"] > 0 and tree["ilqr"] > 0 and tree["ilqr"] <= tree["al"] * 1.05
