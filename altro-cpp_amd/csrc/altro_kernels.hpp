@@ -2083,16 +2083,59 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_forward2(DevArrays<T> A,
   forward2_body<T, M, false>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
 }
 
+// iLQR::UpdateExpansions of one instance by `nthreads` threads, reading the trajectory, multipliers and
+// parameters from the LDS block of the forward pass and the problem description from the kernel
+// arguments: the knots of a run share their class, so each run is handed to whole wavefronts
+// (wave-uniform class -> scalar loads) and different runs go to different waves where they fit.  No
+// dependent global load is left on the path; the knot costs also go to sCost[k] (LDS).
+template <class T, class M>
+ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, const CtxL<T>& C, const T* sX,
+                                  const T* sU, T* sCost, int b, int tid, int nthreads) {
+  constexpr int n = M::n, m = M::m;
+  using R = Rec<T, n, m>;
+  const int N = A.N;
+  const unsigned Bp = A.Bp;
+  int toff = 0;
+  for (int r = 0; r < pd->nruns; ++r) {
+    const KnotRun run = pd->runs[r];
+    const KnotClass& kc = pd->cls[run.cls];
+    const int cnt = run.k_end - run.k_begin;
+    int j = tid - toff;
+    if (j < 0) j += nthreads;
+    for (; j < cnt; j += nthreads) {
+      const int k = run.k_begin + j;
+      const int rb = run.rowbase + j * kc.nrows;
+      T xr[R::nP], ur[R::mP];
+      load_rec<T, R::nP>(sX + k * R::nP, xr);
+#pragma unroll
+      for (int i = 0; i < R::mP; ++i) ur[i] = T(0);
+      if (k < N) load_rec<T, R::mP>(sU + k * R::mP, ur);
+      T E[R::EP];
+#pragma unroll
+      for (int e = 0; e < R::EP; ++e) E[e] = T(0);
+      const T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
+                                               E + R::oLuu);
+      A.costs[(unsigned)k * Bp + (unsigned)b] = J;
+      sCost[k] = J;
+      if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
+      store_rec<T, R::EP>(RECP(A.EXP, k, R::EP), E);
+    }
+    toff = (toff + ((cnt + kBlock - 1) / kBlock) * kBlock) % nthreads;
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // One whole iLQR iteration of ONE instance per workgroup (128 threads), for the long tail of a batched
 // solve: a few dozen stragglers iterate ~100 times after everyone else has converged, and each sweep
 // is then a pure latency chain.  Fusing the three kernels removes two kernel boundaries, the staging
 // of the gains (the backward wave writes them straight into the forward pass's LDS block), and hides
 // the rest of the staging and the running-cost sum behind the backward recursion:
-//   E  expansions of the 101 knots over the 128 threads (global memory; visible after the barrier)
-//   B  wave 0: MFMA backward pass (one of the four 4x4 blocks carries the instance)
-//   S  wave 1, meanwhile: X, U, lambda, rho, parameters -> LDS; J0 = sum of the knot costs in order
-//   F  both waves: the two-wave forward pass on the LDS block (forward2_body)
+//   S  X, U, lambda, rho, parameters -> LDS (all threads, one memory round trip)
+//   E  expansions of the 101 knots over the 192 threads from the LDS block (records to global
+//      memory, visible to the workgroup after the barrier; knot costs also to LDS)
+//   B  wave 0: MFMA backward pass (one of the four 4x4 blocks carries the instance), gains -> LDS;
+//      wave 1, meanwhile: J0 = sum of the knot costs in order
+//   F  all waves: the three-wave forward pass on the LDS block (forward2_body)
 // Same device code as the separate kernels, hence the same numbers.  fp64, n = 3, m = 2 only.
 // persistent != 0: instances are independent, so the workgroup simply keeps iterating until ITS
 // instance is finished (the AL state machine of phase 3 says so) -- no further launches, no host in
@@ -2133,30 +2176,26 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
 #endif
   for (;;) {
     FSTAMP(wave * 4 + 0);
-    // ---- E ----
-    for (int k = tid; k <= N; k += kFwdWaves * kBlock) expansion_body<T, M>(A, pdg, b, k);
-    __syncthreads();  // drains the stores: the records are in L2 for the backward wave
+    // ---- S: X, U, lambda, rho, parameters -> LDS (all threads) ----
+    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, false);
+    __syncthreads();
+    // ---- E: expansions from the LDS block ----
+    {
+      const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
+                       sm + L.nX + L.nU + L.nKD + L.rowsP());
+      expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kFwdWaves * kBlock);
+    }
+    __syncthreads();  // drains the stores: the records are in L2 for the backward wave, the costs in LDS
     FSTAMP(wave * 4 + 1);
 
     if (wave == 0) {
       // ---- B ----
       backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
       FSTAMP(2);
-    } else if (wave == 2) {
-      // ---- S (first half) ----
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, lane, 2 * kBlock, false);
-    } else {
-      // ---- S (second half) ----
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, kBlock + lane, 2 * kBlock, false);
-      // running cost in knot order (ilqr.hpp:326-334): fetch side by side, hand over one by one
+    } else if (wave == 1) {
+      // running cost in knot order (ilqr.hpp:326-334)
       double J0 = 0.0;
-      for (int base = 0; base <= N; base += 2 * kBlock) {
-        const int k0 = base + lane, k1 = base + kBlock + lane;
-        const double v0 = A.costs[(unsigned)(k0 <= N ? k0 : N) * Bp + (unsigned)b];
-        const double v1 = A.costs[(unsigned)(k1 <= N ? k1 : N) * Bp + (unsigned)b];
-        for (int j = 0; j < kBlock && base + j <= N; ++j) J0 += __shfl(v0, j);
-        for (int j = 0; j < kBlock && base + kBlock + j <= N; ++j) J0 += __shfl(v1, j);
-      }
+      for (int k = 0; k <= N; ++k) J0 += xch[k];
       if (lane == 0) {
         A.J0[b] = J0;
         double ic = A.initial_cost[b];
