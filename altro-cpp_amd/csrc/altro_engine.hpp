@@ -1004,6 +1004,7 @@ class Engine final : public EngineBase {
       fprintf(stderr, "  B: %lld %lld", h[17] - h[16], h[18] - h[16]);
       fprintf(stderr, "  FUSED w0[E0 Eend Bend sync]: %lld %lld %lld %lld  w1[Eend Send sync Fend]: %lld %lld %lld %lld\n", h[20] - h[20],
               h[21] - h[20], h[22] - h[20], h[23] - h[20], h[25] - h[20], h[26] - h[20], h[27] - h[20], h[28] - h[20]);
+      fprintf(stderr, "   w0: stage issued %lld, staged+sync %lld, E computed+stores issued %lld\n", h[29] - h[20], h[30] - h[20], h[31] - h[20]);
     }
 #endif
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)

@@ -2178,13 +2178,16 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
     FSTAMP(wave * 4 + 0);
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads) ----
     forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, false);
+    FSTAMP(9);
     __syncthreads();
+    FSTAMP(10);
     // ---- E: expansions from the LDS block ----
     {
       const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
                        sm + L.nX + L.nU + L.nKD + L.rowsP());
       expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kFwdWaves * kBlock);
     }
+    FSTAMP(11);
     __syncthreads();  // drains the stores: the records are in L2 for the backward wave, the costs in LDS
     FSTAMP(wave * 4 + 1);
 
