@@ -920,7 +920,7 @@ template <class T, class M>
 ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
                               int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
-                              int* active_out = nullptr) {
+                              int* active_out = nullptr, T* sLamW = nullptr, T* sPenW = nullptr) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -991,7 +991,9 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
           for (int i = 0; i < cd.p; ++i) {
             const unsigned idx = (unsigned)(rb + cd.row_off + i) * Bp + (unsigned)b;
             const T c = A.cval[idx], rho = A.pen[idx];
-            A.lam[idx] = dual_proj(cd.type, A.lam[idx] - rho * c);  // constraint_values.hpp:192-194
+            const T lnew = dual_proj(cd.type, A.lam[idx] - rho * c);  // constraint_values.hpp:192-194
+            A.lam[idx] = lnew;
+            if (sLamW) sLamW[rb + cd.row_off + i] = lnew;  // LDS-resident copy (persistent kernel)
             vpart = max_(vpart, violation(cd.type, c));
             ppart = max_(ppart, rho);
           }
@@ -1012,8 +1014,12 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
           const int rb = A.knot_rowbase[k];
           for (int ci = 0; ci < kc.ncon; ++ci) {
             const T phi = T(A.phi[cls * kMaxConPerKnot + ci]);
-            for (int i = 0; i < kc.con[ci].p; ++i)
-              A.pen[(unsigned)(rb + kc.con[ci].row_off + i) * Bp + (unsigned)b] *= phi;
+            for (int i = 0; i < kc.con[ci].p; ++i) {
+              const unsigned idx = (unsigned)(rb + kc.con[ci].row_off + i) * Bp + (unsigned)b;
+              const T pnew = A.pen[idx] * phi;
+              A.pen[idx] = pnew;
+              if (sPenW) sPenW[rb + kc.con[ci].row_off + i] = pnew;
+            }
           }
         }
         if (t == 0) begin_inner_solve(A, o, b);
@@ -1473,7 +1479,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 // Returns the max violation over those knots.  t_replay < 0: c_ is untouched since the expansion step.
 template <class T, class M, class Ctx>
 ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const Ctx& C, int b, int t_replay, bool accepted,
-                           int k0, int stride) {
+                           int k0, int stride, T* sXw = nullptr, T* sUw = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1515,6 +1521,10 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
           for (int i = 0; i < R::mP; ++i) ur[i] = i < m ? us[j][i < m ? i : 0] : T(0);
           store_rec<T, R::nP>(RECP(A.X, k, R::nP), xr);
           if (k < N) store_rec<T, R::mP>(RECP(A.U, k, R::mP), ur);
+          if (sXw) {  // LDS-resident copy of the trajectory (persistent kernel)
+            store_rec<T, R::nP>(sXw + k * R::nP, xr);
+            if (k < N) store_rec<T, R::mP>(sUw + k * R::mP, ur);
+          }
         }
       }
     }
@@ -1919,7 +1929,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       T viol = T(0);
       if (valid) {
         CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
-        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS);
+        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS,
+                                    FUSED ? sX : nullptr, FUSED ? sU : nullptr);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart[grp] = vm;
@@ -1963,7 +1974,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (valid) {
         CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
         const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
-                                            kFwdWaves * LS);
+                                            kFwdWaves * LS, FUSED ? sX : nullptr, FUSED ? sU : nullptr);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart2[grp] = vm;
@@ -2061,7 +2072,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   __syncthreads();  // barrier S: selection visible, candidate stores of this wave drained
   T viol = T(0);
   if (valid) {
-    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS);
+    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, FUSED ? sX : nullptr,
+                                FUSED ? sU : nullptr);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
@@ -2071,7 +2083,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
   STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
-                       (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr);
+                       (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
+                       FUSED ? sPen : nullptr);
   STAMP(8 + 6);
 }
 
@@ -2176,18 +2189,18 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
 #endif
   for (;;) {
     FSTAMP(wave * 4 + 0);
-    // ---- S: X, U, lambda, rho, parameters -> LDS (all threads) ----
-    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, false);
-    FSTAMP(9);
-    __syncthreads();
-    FSTAMP(10);
+    // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
+    //      forward pass keep the LDS copies current from then on ----
+    if (loops == 0) {
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, false);
+      __syncthreads();
+    }
     // ---- E: expansions from the LDS block ----
     {
       const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
                        sm + L.nX + L.nU + L.nKD + L.rowsP());
       expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kFwdWaves * kBlock);
     }
-    FSTAMP(11);
     __syncthreads();  // drains the stores: the records are in L2 for the backward wave, the costs in LDS
     FSTAMP(wave * 4 + 1);
 
