@@ -124,3 +124,45 @@ def test_valu_backward_matches_mfma(P, hip_make, monkeypatch):
     assert (s1["iterations_total"] == s2["iterations_total"]).all() and (s1["status"] == s2["status"]).all()
     ok = s1["status"] == 0
     assert np.allclose(g1.get_trajectory()[0][ok], g2.get_trajectory()[0][ok], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_randomised_problems_and_options(P, A, oracle_make, hip_make, seed):
+    """Seeded random draws of goals, initial states, obstacle positions and solver options: the GPU must walk
+    the same schedule as the oracle (iteration counts, statuses, penalties) and land on the same trajectories."""
+    rng = np.random.default_rng(20260927 + seed)
+    B = 10
+    circles = np.tile(P.THREE_OBSTACLE_CIRCLES, (B, 1, 1))
+    circles[:, :, :2] += rng.uniform(-0.15, 0.15, (B, 3, 2))
+    opts = dict(
+        max_iterations_inner=int(rng.integers(20, 120)),
+        max_iterations_outer=int(rng.integers(3, 12)),
+        cost_tolerance=float(10.0 ** rng.uniform(-6, -3)),
+        gradient_tolerance=float(10.0 ** rng.uniform(-4, -1)),
+        constraint_tolerance=float(10.0 ** rng.uniform(-6, -3)),
+        initial_penalty=float(rng.choice([0.1, 1.0, 10.0, 100.0])),
+        line_search_max_iterations=int(rng.integers(6, 21)),
+        line_search_decrease_factor=float(rng.choice([1.5, 2.0, 3.0])),
+        bp_reg_initial=float(rng.choice([0.0, 0.0, 1e-4])),
+    )
+    x0 = np.zeros((B, 3))
+    x0[:, :2] = rng.uniform(-0.2, 0.2, (B, 2))
+    x0[:, 2] = rng.uniform(-0.3, 0.3, B)
+    solvers = []
+    for make in (oracle_make, hip_make):
+        s = P.unicycle_three_obstacles(make, batch=B, dtype=A.F64, circles=circles)
+        s.set_initial_state(x0)
+        s.set_penalty_scaling(float([2.0, 10.0, 10.0][seed % 3]))
+        s.set_options(**opts)
+        s.solve()
+        solvers.append(s)
+    o, g = solvers
+    so, sg = o.get_stats(), g.get_stats()
+    for f in ("status", "status_ilqr", "iterations_total", "iterations_outer", "iterations_inner"):
+        assert (so[f] == sg[f]).all(), (f, opts, so[f], sg[f])
+    assert np.allclose(sg["max_penalty"], so["max_penalty"], rtol=1e-12)
+    ok = so["status"] == 0
+    Xo, Uo = o.get_trajectory()
+    Xg, Ug = g.get_trajectory()
+    assert np.allclose(Xg[ok], Xo[ok], rtol=1e-6, atol=1e-7)
+    assert np.allclose(Ug[ok], Uo[ok], rtol=1e-6, atol=1e-7)
