@@ -228,6 +228,18 @@ class BatchSolver:
     def solve(self):            # AugmentedLagrangianiLQR::Solve, al_solver.hpp:304-334
         self._call("solve_al")
 
+    def solve_async(self):
+        """Non-blocking AL solve on a worker thread of the library (MPC pattern); finish with wait()."""
+        self._call("solve_al_async")
+
+    def poll(self):
+        done = C.c_int(0)
+        self._call("solve_poll", C.byref(done))
+        return bool(done.value)
+
+    def wait(self):
+        self._call("wait")
+
     def solve_ilqr(self):       # iLQR::Solve, ilqr.hpp:284-316
         self._call("solve_ilqr")
 

@@ -5,7 +5,9 @@
 // No exception crosses the boundary; there is NO CPU fallback.
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <new>
 #include <string>
 
@@ -20,6 +22,14 @@ struct altro_solver_s {
   bool uploaded = false;
   bool ilqr_mode = false;
   std::string err;
+  // asynchronous solve (altro_solve_al_async): one worker at a time
+  std::thread worker;
+  std::atomic<int> async_done{1};
+  bool async_pending = false;
+  altro_status async_status = ALTRO_OK;
+  ~altro_solver_s() {
+    if (worker.joinable()) worker.join();
+  }
 };
 
 static thread_local std::string g_create_error;
@@ -249,6 +259,36 @@ altro_status altro_solve_al(altro_handle h) {
 altro_status altro_solve_ilqr(altro_handle h) {
   if (h) h->ilqr_mode = true;
   return Forward(h, [&](EngineBase& e) { return e.SolveILQR(h->opts); });
+}
+altro_status altro_solve_al_async(altro_handle h) {
+  if (!h) return ALTRO_INVALID_ARG;
+  if (h->async_pending) {
+    h->err = "an asynchronous solve is already pending (call altro_wait first)";
+    return ALTRO_NOT_READY;
+  }
+  if (h->worker.joinable()) h->worker.join();
+  h->async_pending = true;
+  h->async_done.store(0);
+  h->worker = std::thread([h]() {
+    h->async_status = altro_solve_al(h);
+    h->async_done.store(1, std::memory_order_release);
+  });
+  return ALTRO_OK;
+}
+altro_status altro_solve_poll(altro_handle h, int* done) {
+  if (!h || !done) return ALTRO_INVALID_ARG;
+  *done = h->async_done.load(std::memory_order_acquire);
+  return ALTRO_OK;
+}
+altro_status altro_wait(altro_handle h) {
+  if (!h) return ALTRO_INVALID_ARG;
+  if (!h->async_pending) {
+    h->err = "no asynchronous solve is pending";
+    return ALTRO_NOT_READY;
+  }
+  if (h->worker.joinable()) h->worker.join();
+  h->async_pending = false;
+  return h->async_status;
 }
 altro_status altro_al_init(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.AlInit(h->opts); }); }
 altro_status altro_solve_setup(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.SolveSetup(h->opts); }); }

@@ -564,6 +564,23 @@ class AugmentedLagrangianiLQR {
     if (!lam.empty()) detail::Check(h_, altro_get_duals(h_, lam.data()), "altro_get_duals");
     return lam;
   }
+  // Non-blocking Solve() for the MPC pattern (docs/Overview.dox:48-54): SolveAsync() returns at once, the
+  // caller prepares the next problem, Wait() blocks and refreshes the trajectory and the statistics.
+  void SolveAsync() {
+    ilqr_->MarkTrajectoryDirty();
+    ilqr_->Push();
+    detail::Check(h_, altro_solve_al_async(h_), "altro_solve_al_async");
+  }
+  bool Poll() {
+    int done = 0;
+    detail::Check(h_, altro_solve_poll(h_, &done), "altro_solve_poll");
+    return done != 0;
+  }
+  void Wait() {
+    detail::Check(h_, altro_wait(h_), "altro_wait");
+    ilqr_->Pull(true);
+    status_ = static_cast<SolverStatus>(stats_.instances[0].status);
+  }
   altro_timing GetTiming() {
     altro_timing t;
     detail::Check(h_, altro_get_timing(h_, &t), "altro_get_timing");

@@ -219,6 +219,16 @@ altro_status altro_solve_al(altro_handle h);
 /* iLQR::Solve (ilqr.hpp:284-316) on the AL cost with the current duals/penalties. */
 altro_status altro_solve_ilqr(altro_handle h);
 
+/* Non-blocking variant of altro_solve_al for the MPC pattern the reference is designed for
+ * (docs/Overview.dox:48-54; warm start: al_solver.hpp:292-297): the solve runs on a worker thread of
+ * the library while the caller prepares the next problem.  Between altro_solve_al_async and
+ * altro_wait only altro_solve_poll, altro_wait and altro_last_error may be called on the handle.
+ * altro_solve_poll sets *done to 0/1 without blocking; altro_wait blocks and returns the status the
+ * synchronous call would have returned (ALTRO_NOT_READY if no asynchronous solve is pending). */
+altro_status altro_solve_al_async(altro_handle h);
+altro_status altro_solve_poll(altro_handle h, int* done);
+altro_status altro_wait(altro_handle h);
+
 /* ---- step-level entry points (used by the parity tests the way the reference tests use the
  *      public methods of iLQR / AugmentedLagrangianiLQR) ---------------------------------------- */
 altro_status altro_al_init(altro_handle h);            /* AL Init           al_solver.hpp:287-302 */

@@ -166,3 +166,23 @@ def test_randomised_problems_and_options(P, A, oracle_make, hip_make, seed):
     Xg, Ug = g.get_trajectory()
     assert np.allclose(Xg[ok], Xo[ok], rtol=1e-6, atol=1e-7)
     assert np.allclose(Ug[ok], Uo[ok], rtol=1e-6, atol=1e-7)
+
+
+def test_async_solve_matches_blocking(P, A, hip_make):
+    """altro_solve_al_async / altro_solve_poll / altro_wait: same result as the blocking call."""
+    g1 = P.batch_turn90(hip_make, batch=32)
+    g1.solve()
+    g2 = P.batch_turn90(hip_make, batch=32)
+    with pytest.raises(A.AltroError):
+        g2.wait()  # nothing pending
+    g2.solve_async()
+    with pytest.raises(A.AltroError):
+        g2.solve_async()  # one at a time
+    polls = 0
+    while not g2.poll():
+        polls += 1
+    g2.wait()
+    assert g2.poll()
+    s1, s2 = g1.get_stats(), g2.get_stats()
+    assert (s1["iterations_total"] == s2["iterations_total"]).all() and (s1["status"] == s2["status"]).all()
+    assert np.array_equal(g1.get_trajectory()[0], g2.get_trajectory()[0])
