@@ -381,7 +381,7 @@ class Engine final : public EngineBase {
   bool FusedOk(const DevOpts& d) const {
     if constexpr (!kMfmaBackward) return false;
     return !force_valu_backward_ && !no_fused_ && mfma_offsets_ok_ && fwd_lds_bytes_ > 0 && !A_.record_ctg &&
-           d.line_search_max_iterations <= kLineSearchLanes && fused_lds_bytes_ <= 64 * 1024;
+           d.line_search_max_iterations <= kLineSearchLanes && fused_lds_bytes_ <= 160 * 1024;
   }
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
@@ -836,13 +836,19 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
-      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock + 2) * sizeof(double);
+      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock + 2) * sizeof(double) +
+                         (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
       } else if (fwd_lds_bytes_ > 64 * 1024) {
         ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+      }
+      if constexpr (kMfmaBackward) {
+        if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<M>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
       }
     }
     uploaded_ = true;

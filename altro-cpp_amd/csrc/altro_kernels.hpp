@@ -1479,7 +1479,8 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 // Returns the max violation over those knots.  t_replay < 0: c_ is untouched since the expansion step.
 template <class T, class M, class Ctx>
 ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const Ctx& C, int b, int t_replay, bool accepted,
-                           int k0, int stride, T* sXw = nullptr, T* sUw = nullptr) {
+                           int k0, int stride, const T* cand_base, unsigned cand_off0, T* sXw = nullptr,
+                           T* sUw = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1487,14 +1488,14 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
   const int N = A.N;
   T viol = T(0);
   if (t_replay >= 0) {
-    const unsigned rbo = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t_replay) * (unsigned)nm;
+    const unsigned rbo = cand_off0 + (unsigned)t_replay * (unsigned)nm;
     constexpr int kAhead = 3;  // candidates fetched before the first is used
     for (int kb = k0; kb <= N; kb += kAhead * stride) {
       T xs[kAhead][n], us[kAhead][m];
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) {
         const int k = kb + j * stride;
-        const T* cand = A.trial + (rbo + (unsigned)(k <= N ? k : N) * (unsigned)(LS * nm));
+        const T* cand = cand_base + (rbo + (unsigned)(k <= N ? k : N) * (unsigned)(LS * nm));
 #pragma unroll
         for (int i = 0; i < n; ++i) xs[j][i] = cand[i];
 #pragma unroll
@@ -1587,8 +1588,8 @@ struct RolloutBounds {
 // checks (RolloutBounds), the gradient measure of the trial (ilqr.hpp:574-583 with the trial's controls)
 // and the candidate store.  None of it feeds the cost, so it runs beside the cost wave.
 template <class T, class M>
-ALTRO_DEV void aux_consumer_run(const DevArrays<T>& A, int kbegin, int kend, const T* sKD, const T* xch, int lane,
-                                bool valid, unsigned tb, double& gs, RolloutBounds<T>& bnd) {
+ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, const T* xch, int lane, bool valid, T* candp,
+                                double& gs, RolloutBounds<T>& bnd) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1615,7 +1616,7 @@ ALTRO_DEV void aux_consumer_run(const DevArrays<T>& A, int kbegin, int kend, con
     }
     gs += (double)(gnum / gden);
     if (valid) {  // idle lanes must not touch instance 0's candidates
-      T* cand = A.trial + (tb + (unsigned)k * (unsigned)(LS * nm));
+      T* cand = candp + (unsigned)k * (unsigned)(LS * nm);
 #pragma unroll
       for (int i = 0; i < n; ++i) cand[i] = xb[i];
 #pragma unroll
@@ -1809,7 +1810,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 template <class T, class M, bool FUSED>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
-                             const double* fh, int* active_out = nullptr) {
+                             const double* fh, int* active_out = nullptr, T* sCand = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -1930,6 +1931,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (valid) {
         CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
         viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS,
+                                    FUSED ? sCand : A.trial,
+                                    FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm,
                                     FUSED ? sX : nullptr, FUSED ? sU : nullptr);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
@@ -1940,8 +1943,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     return;
   }
 
-  // candidate scratch, instance-major [b][k][trial][x|u]
-  const unsigned tb = ((unsigned)b * (unsigned)(N + 1) * (unsigned)LS + (unsigned)t) * (unsigned)nm;
+  // candidate scratch [k][trial][x|u]: in global memory (instance-major), or -- FUSED, one instance per
+  // workgroup and per CU -- in LDS, so that the knot loop issues no global store at all
+  T* const cand_base = FUSED ? sCand : A.trial;
+  const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
+  const unsigned tb = cand_off0 + (unsigned)t * (unsigned)nm;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
     double gs = 0.0;
@@ -1949,7 +1955,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     bnd.check = o.check_forwardpass_bounds != 0;
     bnd.smax2 = T(o.state_max) * T(o.state_max);
     bnd.umax2 = T(o.control_max) * T(o.control_max);
-    aux_consumer_run<T, M>(A, 0, N, sKD, xch, lane, valid, tb, gs, bnd);
+    aux_consumer_run<T, M>(0, N, sKD, xch, lane, valid, cand_base + tb, gs, bnd);
     lds_barrier();  // barrier N: terminal state
     {
       const T* slot = xch + (N & 1) * (nm * kBlock);
@@ -1958,7 +1964,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
       bnd.template settle<n>(xN);  // the last step of the rollout
       if (valid) {
-        T* cand = A.trial + (tb + (unsigned)N * (unsigned)(LS * nm));
+        T* cand = cand_base + (tb + (unsigned)N * (unsigned)(LS * nm));
 #pragma unroll
         for (int i = 0; i < n; ++i) cand[i] = xN[i];
       }
@@ -1974,7 +1980,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (valid) {
         CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
         const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
-                                            kFwdWaves * LS, FUSED ? sX : nullptr, FUSED ? sU : nullptr);
+                                            kFwdWaves * LS, cand_base, cand_off0, FUSED ? sX : nullptr,
+                                            FUSED ? sU : nullptr);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart2[grp] = vm;
@@ -2072,8 +2079,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   __syncthreads();  // barrier S: selection visible, candidate stores of this wave drained
   T viol = T(0);
   if (valid) {
-    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, FUSED ? sX : nullptr,
-                                FUSED ? sU : nullptr);
+    viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, cand_base, cand_off0,
+                                FUSED ? sX : nullptr, FUSED ? sU : nullptr);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
@@ -2181,6 +2188,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
   const int fused_junk = (int)((fh + 6) - sKDf);
 
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
+  T* sCand = fh + 6 + kBlock + 2;  // [N+1][20][n+m] line-search candidates (16-byte aligned)
   int loops = 0;
 #ifdef ALTRO_X
 #define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
@@ -2229,7 +2237,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
     FSTAMP(wave * 4 + 3);
 
     // ---- F ----
-    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag);
+    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand);
     if (wave == 1) FSTAMP(8);
     ++loops;
     __syncthreads();
