@@ -1645,6 +1645,20 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   }
   if (kHasB) b_row = kc.con[kBi].row_off;
   const int nrows = kc.nrows;
+  // Jc / (2 rho): the penalty is wave-uniform and hardly ever changes from knot to knot, so its reciprocal
+  // is kept (one IEEE division, ~70 cycles, when it changes) and the quotient comes from Markstein's
+  // correction step, which returns the correctly rounded Jc / (2 rho) -- the same bits -- in 3 operations
+  T inv_rho2 = T(0), inv_for = T(0);
+  auto div_2rho = [&](T num, T rho) __attribute__((always_inline)) -> T {
+    const T den = T(2) * rho;
+    if (den != inv_for) {  // wave-uniform
+      inv_for = den;
+      inv_rho2 = T(1) / den;
+    }
+    const T q = num * inv_rho2;
+    const T r = fma(-den, q, num);
+    return fma(r, inv_rho2, q);
+  };
   for (int k = run.k_begin; k < kend; ++k) {
     lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
     const T* slot = xch + (k & 1) * (nm * kBlock);
@@ -1689,7 +1703,7 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
           bsum += lam * lam;
         }
         T Jc = a - bsum;
-        Jk += Jc / (2 * rho);
+        Jk += div_2rho(Jc, rho);
       };
       auto bound_term = [&]() {
         T a = T(0), bsum = T(0);
@@ -1708,7 +1722,7 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
           bsum += blam[m + j] * blam[m + j];
         }
         T Jc = a - bsum;
-        Jk += Jc / (2 * brho);
+        Jk += div_2rho(Jc, brho);
       };
       if (FK == kFastB) bound_term();
       if (FK == kFastC) circle_term();
@@ -1896,7 +1910,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if constexpr (M::kHasCarriedTrig) {
         // sin / cos of the heading ride along from the previous step (see rk4_fused_sc)
         if ((k % M::kTrigResync) == 0) sincos_(xb[2], &trig_s, &trig_c);
-        M::rk4_fused_sc(xb, ub, hh, xn, trig_s, trig_c);
+        M::template rk4_fused_sc<T, false>(xb, ub, hh, xn, trig_s, trig_c);
       } else {
         rk4_step<T, M>(xb, ub, hh, xn);
       }
