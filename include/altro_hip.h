@@ -145,9 +145,10 @@ typedef struct altro_timing {
   double expansions_ms;    /* sum over sweeps of the expansions kernel (HIP events)         */
   double backward_pass_ms; /* sum over sweeps of the backward-pass kernel                   */
   double forward_pass_ms;  /* sum over sweeps of the forward-pass (+AL update) kernel       */
-  double fused_ms;         /* sum over the tail sweeps that ran as ONE fused kernel         */
-  int sweeps;              /* number of batched iLQR sweeps launched (fused ones included)  */
-  int fused_sweeps;        /* how many of them were fused                                   */
+  double fused_ms;         /* the persistent tail launch (k_sweep_fused): every remaining    */
+                           /* iteration of the straggler instances, one workgroup each      */
+  int sweeps;              /* batched iLQR sweeps = longest chain of iterations             */
+  int fused_sweeps;        /* how many of them ran inside the persistent launch             */
   int launches;            /* number of kernel launches                                     */
   long long instance_iterations; /* sum over instances of iterations_total                  */
   long long fused_instance_iterations; /* (instance, iteration) units run by the fused launch */
