@@ -7,6 +7,8 @@ Tolerances:
   fp32 GPU vs fp64 oracle: final states abs <= 1e-3 * max(1, |x|), cost rel <= 1e-3, violation
   <= tolerance + 1e-4, iteration counts within +-2 for solved instances (distribution printed).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -296,3 +298,29 @@ def test_full_batch_properties(P, A, hip_make):
     assert np.abs(Xr - X1).max() < 1e-12
     # control bounds and goal
     assert (np.abs(U1[ok]).max(axis=(1, 2)) <= 1.5 + 1e-4).all()
+
+
+def test_config3_full_batch_against_oracle(P, A, oracle_make, hip_make, oracle_lib):
+    """BASELINE config 3 at full size (the bench workload): every one of the 4096 instances walks the same
+    schedule on the GPU as in the CPU oracle -- including the ~2 % stragglers that run into the iteration
+    limit -- and the solved ones end on the same trajectories."""
+    import ctypes
+    B = 4096
+    o = P.batch_turn90(oracle_make, batch=B, seed=P.SEED_BASE + 3)
+    oracle_lib.oracle_set_threads(o._h, ctypes.c_int(len(os.sched_getaffinity(0))))
+    o.solve()
+    g = P.batch_turn90(hip_make, batch=B, seed=P.SEED_BASE + 3)
+    g.solve()
+    so, sg = o.get_stats(), g.get_stats()
+    same = (so["iterations_total"] == sg["iterations_total"]) & (so["status"] == sg["status"]) & \
+           (so["iterations_outer"] == sg["iterations_outer"])
+    solved = so["status"] == 0
+    # solved instances: exact schedule.  The 99 stragglers ride a line search down to alpha = 2^-19 for ~100
+    # iterations; today all 4096 instances match (max |dX| 6e-13) -- two may flip before this fails
+    assert same[solved].all(), np.flatnonzero(~same & solved)[:10]
+    assert (~same).sum() <= 2, (~same).sum()
+    Xo, Uo = o.get_trajectory()
+    Xg, Ug = g.get_trajectory()
+    assert np.allclose(Xg[solved], Xo[solved], rtol=1e-7, atol=1e-9)
+    assert np.allclose(Ug[solved], Uo[solved], rtol=1e-6, atol=1e-8)
+    assert np.allclose(sg["cost"][solved], so["cost"][solved], rtol=1e-10)
