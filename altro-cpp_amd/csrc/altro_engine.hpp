@@ -890,8 +890,11 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipGetLastError());
 
     // upper bound on sweeps: every sweep advances every active instance by one inner iteration
-    const int max_sweeps = std::max(1, std::min(o.max_iterations_total,
-                                                o.max_iterations_inner * std::max(1, (mode == kFwdAL) ? o.max_iterations_outer : 1))) + 2;
+    // (64-bit product, clamped: the counters of the sweeps live in a pinned array of this length)
+    const long long inner_outer = (long long)std::max(1, o.max_iterations_inner) *
+                                  (long long)std::max(1, (mode == kFwdAL) ? o.max_iterations_outer : 1);
+    const int max_sweeps =
+        (int)std::max<long long>(1, std::min<long long>({(long long)o.max_iterations_total, inner_outer, 1LL << 20})) + 2;
     int sweeps = 0;
     bool finished = false;
     // Sweep i works on the instances that sweep i-1 left active: a dense list built by the forward
