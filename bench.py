@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="EXTRA measurement, not the headline: keep this many solver handles in flight (asynchronous "
+                         "solves on their own streams), so the latency-bound tail of one batch overlaps the next batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +101,34 @@ def main():
         if world > 1:
             dist.all_gather_into_tensor(gathered, packed)  # RCCL over xGMI: 32 B per instance
 
+    if args.pipeline > 1:
+        # Optional throughput mode (reported separately, never the headline): P handles with the same
+        # problem, each step is still one complete solve, but up to P solves are in flight.
+        pool = [solver] + [P.batch_turn90(make, batch=B, N=N, dtype=A.F64, seed=P.SEED_BASE + 3 + 1000 * rank)
+                           for _ in range(args.pipeline - 1)]
+        for s_ in pool:
+            s_.set_options(profiler_enable=0)
+        pending = [False] * len(pool)
+        counter = [0]
+
+        def step():  # noqa: F811
+            i = counter[0] % len(pool)
+            counter[0] += 1
+            s_ = pool[i]
+            if pending[i]:
+                s_.wait()
+                s_.pack_results_device(packed.data_ptr())
+            s_.reset_trajectory()
+            s_.solve_async()
+            pending[i] = True
+
+        def drain():
+            for i, s_ in enumerate(pool):
+                if pending[i]:
+                    s_.wait()
+                    s_.pack_results_device(packed.data_ptr())
+                    pending[i] = False
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -105,10 +136,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.pipeline > 1:
+        drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if args.pipeline > 1:
+        drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,6 +263,8 @@ def main():
                 "us_per_instance_iter": round(1e3 * ms_per_step / max(float(iters.sum()) / world, 1.0), 4),
                 "mean_iterations": round(float(iters.mean()), 3), "max_iterations": int(iters.max()),
                 "sweeps": tm["sweeps"], "device": name, "cus": cus,
+                **({"pipeline": args.pipeline, "note": "NOT the headline configuration: solves of consecutive steps "
+                    "overlap (asynchronous handles)"} if args.pipeline > 1 else {}),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
