@@ -282,11 +282,6 @@ ALTRO_DEV void rows01(double x, double& from_row0, double& from_row1) {
   from_row0 = __hiloint2double((int)bb[0], (int)a[0]);
   from_row1 = __hiloint2double((int)bb[1], (int)a[1]);
 }
-// lanes 32-63 receive what lanes 0-31 hold (v_permlane32_swap); lanes 0-31 keep their value
-ALTRO_DEV int lower_half(int x) {
-  const auto a = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
-  return (int)a[0];
-}
 
 constexpr int kBwdAhead = 6;    // knots per prefetch block of the MFMA backward pass
 constexpr int kBwdFrontPad = 2 * kBwdAhead;  // records in front of knot 0 that the prefetch may touch
@@ -1833,10 +1828,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const int grp = lane / LS;
   const int t = lane - grp * LS;
   const int b0 = (grp < per_wave) ? instance_of_slot(A, blockIdx.x * per_wave + grp, all) : -1;
-  const unsigned Bp = A.Bp;
   const int N = A.N;
   const bool valid = b0 >= 0;
-  if (__ballot(valid) == 0ull) return;  // both waves take the same decision
+  if (__ballot(valid) == 0ull) return;  // every wave takes the same decision
   const int b = valid ? b0 : 0;
 #ifdef ALTRO_X
   const bool dbg_on = A.dbg && blockIdx.x == 0 && lane == 0 && A.it_total[b] == 60;
