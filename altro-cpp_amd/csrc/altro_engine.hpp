@@ -363,14 +363,15 @@ class Engine final : public EngineBase {
   dim3 GridBK() const { return dim3((B_ + kBlock - 1) / kBlock, N_ + 1); }
   // Backward pass launch: fp64 unicycle-sized problems run on the matrix cores (4 instances per
   // wavefront), everything else on the one-lane-per-instance VALU kernel.
-  static constexpr bool kMfmaBackward = std::is_same<T, double>::value && n == 3 && m == 2;
+  // The MFMA backward pass computes in fp64 whatever the storage type of the engine is
+  static constexpr bool kMfmaBackward = n == 3 && m == 2;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
       if (!force_valu_backward_ && mfma_offsets_ok_) {
         if (A.record_ctg)
-          hipLaunchKernelGGL((k_backward_mfma<M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma<T, M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         else
-          hipLaunchKernelGGL((k_backward_mfma<M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma<T, M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         return;
       }
     }
@@ -836,7 +837,7 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
-      fused_lds_bytes_ = shared_bytes + per_inst + (4 + 2 + kBlock + 2) * sizeof(double) +
+      fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
@@ -847,7 +848,7 @@ class Engine final : public EngineBase {
       }
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
-          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<M>),
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
       }
     }
@@ -939,7 +940,7 @@ class Engine final : public EngineBase {
         if constexpr (kMfmaBackward) {
           A.next_list = nullptr;  // nobody comes after this launch
           A.next_count = nullptr;
-          hipLaunchKernelGGL((k_sweep_fused<M>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
+          hipLaunchKernelGGL((k_sweep_fused<T, M>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
                              mode, 1, d_counter_ + max_sweeps + 2);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);

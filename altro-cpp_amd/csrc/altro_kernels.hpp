@@ -292,12 +292,14 @@ constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bu
 // FUSED (k_sweep_fused): one instance per wavefront (block 0), the gains go straight into the forward
 // pass's LDS block sKDf[k * KP + e] (+ a junk slot at sKDf[fused_junk + lane]) and are also written to
 // A.KD at the end; the running cost J0 is summed by the other wave; dV0 / dV1 are handed over in fh[1..2].
-template <class M, bool CTG, bool FUSED>
-ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, int all, int lane, int slot_base,
-                                  double* sKD, double* sKDf, int fused_junk, double* fh) {
+// T is the STORAGE type of the engine (records, gains, costs); the recursion itself always runs in fp64 on
+// the fp64 matrix cores -- an fp32 engine reads float tiles, converts exactly, and rounds the gains once.
+template <class T, class M, bool CTG, bool FUSED>
+ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int all, int lane, int slot_base,
+                                  double* sKD, T* sKDf, int fused_junk, double* fh) {
   static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
   constexpr int n = 3, m = 2;
-  using R = Rec<double, n, m>;
+  using R = Rec<T, n, m>;
   const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
   const int b0 = (FUSED && blk != 0) ? -1 : instance_of_slot(A, slot_base + blk, all);
   const bool inst_on = b0 >= 0;
@@ -325,17 +327,20 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
   // (kBwdFrontPad records, see the allocation).  Offsets are 32-bit BYTE offsets from the start of the
   // front pad, so a load is one instruction (scalar base + vector offset) and a cursor step one
   // subtraction; the engine only selects this kernel when the array is smaller than 4 GiB.
-  const unsigned strideB = Bp * (unsigned)R::EP * 8u;
+  const unsigned strideB = Bp * (unsigned)R::EP * (unsigned)sizeof(T);
   const unsigned frontB = (unsigned)kBwdFrontPad * strideB;
   const unsigned zoff = frontB + (unsigned)(N + 1) * strideB;
-  const unsigned rec0 = frontB + (unsigned)b * (unsigned)R::EP * 8u;
+  const unsigned rec0 = frontB + (unsigned)b * (unsigned)R::EP * (unsigned)sizeof(T);
   const unsigned sA = offA >= 0 ? strideB : 0u, sB = offB >= 0 ? strideB : 0u, s1 = off1 >= 0 ? strideB : 0u,
                  s2 = off2 >= 0 ? strideB : 0u, s3 = off3 >= 0 ? strideB : 0u;
-  const unsigned bA = offA >= 0 ? rec0 + 8u * offA : zoff, bB = offB >= 0 ? rec0 + 8u * offB : zoff,
-                 b1 = off1 >= 0 ? rec0 + 8u * off1 : zoff, b2 = off2 >= 0 ? rec0 + 8u * off2 : zoff,
-                 b3 = off3 >= 0 ? rec0 + 8u * off3 : zoff;
+  constexpr unsigned kES = (unsigned)sizeof(T);
+  const unsigned bA = offA >= 0 ? rec0 + kES * offA : zoff, bB = offB >= 0 ? rec0 + kES * offB : zoff,
+                 b1 = off1 >= 0 ? rec0 + kES * off1 : zoff, b2 = off2 >= 0 ? rec0 + kES * off2 : zoff,
+                 b3 = off3 >= 0 ? rec0 + kES * off3 : zoff;
   const char* __restrict__ Eb = reinterpret_cast<const char*>(A.EXP) - (size_t)frontB;
-  auto ldE = [&](unsigned off) __attribute__((always_inline)) { return *reinterpret_cast<const double*>(Eb + off); };
+  auto ldE = [&](unsigned off) __attribute__((always_inline)) -> double {
+    return (double)*reinterpret_cast<const T*>(Eb + off);
+  };
 
   struct Tiles {
     double tA, tB, t1, t2, t3;
@@ -393,7 +398,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = base + j * 16 + q;
-        v[j] = A.costs[(unsigned)(k <= N ? k : N) * Bp + (unsigned)b];
+        v[j] = (double)A.costs[(unsigned)(k <= N ? k : N) * Bp + (unsigned)b];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -411,11 +416,11 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
   // The gains are collected in LDS and written out in bulk: a store in the loop would share the memory
   // counter with the prefetched tiles (loads and stores retire out of order with respect to each
   // other), and every wait on a tile would have to drain the whole queue.
-  double* const sink = A.trial + lane;  // CTG build only: junk sink of the lanes that own no element
+  T* const sink = A.trial + lane;  // CTG build only: junk sink of the lanes that own no element
   while (__ballot(need) != 0ull) {
     if (!primed) prime();  // restart after a failed factorisation
     primed = false;
-    if (CTG) *((need && offCT >= 0) ? RECP(A.CTG, N, R::CP) + offCT : sink) = Pp;
+    if (CTG) *((need && offCT >= 0) ? RECP(A.CTG, N, R::CP) + offCT : sink) = (T)Pp;
     bool running = need;
     // write the buffered knots (k_top, k_top - 1, ... in slots 0 .. slot-1) of the four instances out
     int slot = 0, k_top = N - 1;
@@ -424,7 +429,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
         const int e = i % R::KP, ib = (i / R::KP) % 4, sl = i / (4 * R::KP);
         const int bi = __shfl(b, ib * 4);  // instance of block ib (its lane r = 0, c = 0)
         const int on = __shfl(inst_on ? 1 : 0, ib * 4);
-        if (on) A.KD[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)bi) * R::KP + e] = sKD[i];
+        if (on) A.KD[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)bi) * R::KP + e] = (T)sKD[i];
       }
       k_top -= slot;
       slot = 0;
@@ -488,10 +493,10 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
       dV1 = fma(KDc, G, dV1);
       // gains into the LDS block (lanes with nothing to store hit a junk slot)
       if (FUSED)
-        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = KD;
+        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = (T)KD;
       else
         sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
-      if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = Pn;
+      if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
       need = need && !gave_up;
       slot++;
     };
@@ -555,11 +560,11 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<double>& A, const DevOpts& o, 
   }
 }
 
-template <class M, bool CTG>
-__global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<double> A, DevOpts o, int all) {
-  using R = Rec<double, M::n, M::m>;
+template <class T, class M, bool CTG>
+__global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<T> A, DevOpts o, int all) {
+  using R = Rec<T, M::n, M::m>;
   __shared__ double sKD[kBwdChunk * 4 * R::KP + kBlock];  // + one junk slot per lane
-  backward_mfma_body<M, CTG, false>(A, o, all, threadIdx.x, blockIdx.x * 4, sKD, nullptr, 0, nullptr);
+  backward_mfma_body<T, M, CTG, false>(A, o, all, threadIdx.x, blockIdx.x * 4, sKD, nullptr, 0, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2164,16 +2169,15 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 //   B  wave 0: MFMA backward pass (one of the four 4x4 blocks carries the instance), gains -> LDS;
 //      wave 1, meanwhile: J0 = sum of the knot costs in order
 //   F  all waves: the three-wave forward pass on the LDS block (forward2_body)
-// Same device code as the separate kernels, hence the same numbers.  fp64, n = 3, m = 2 only.
+// Same device code as the separate kernels, hence the same numbers.  n = 3, m = 2 (fp64 or fp32 storage).
 // persistent != 0: instances are independent, so the workgroup simply keeps iterating until ITS
 // instance is finished (the AL state machine of phase 3 says so) -- no further launches, no host in
 // the loop; *sweeps_out receives the largest number of iterations any workgroup ran.
 // -------------------------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<double> A, const ProblemDesc* __restrict__ pdg,
+template <class T, class M>
+__global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                             const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
                                                             int* sweeps_out) {
-  using T = double;
   using R = Rec<T, M::n, M::m>;
   constexpr int nm = M::n + M::m;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2193,10 +2197,10 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
   T* xch = sPool + L.padv(pd->npool);
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);
   double* fh = reinterpret_cast<double*>(flags + 2 * kBlock) + kBlock;  // behind the gradient slots
-  const int fused_junk = (int)((fh + 6) - sKDf);
+  const int fused_junk = (int)(reinterpret_cast<T*>(fh + 6) - sKDf);  // one junk slot per lane, in units of T
 
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
-  T* sCand = fh + 6 + kBlock + 2;  // [N+1][20][n+m] line-search candidates (16-byte aligned)
+  T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2);  // [N+1][20][n+m] line-search candidates (16-byte aligned)
   int loops = 0;
 #ifdef ALTRO_X
 #define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
@@ -2222,12 +2226,12 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<do
 
     if (wave == 0) {
       // ---- B ----
-      backward_mfma_body<M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+      backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
       FSTAMP(2);
     } else if (wave == 1) {
       // running cost in knot order (ilqr.hpp:326-334)
       double J0 = 0.0;
-      for (int k = 0; k <= N; ++k) J0 += xch[k];
+      for (int k = 0; k <= N; ++k) J0 += (double)xch[k];
       if (lane == 0) {
         A.J0[b] = J0;
         double ic = A.initial_cost[b];
