@@ -365,6 +365,8 @@ class Engine final : public EngineBase {
   // wavefront), everything else on the one-lane-per-instance VALU kernel.
   // The MFMA backward pass computes in fp64 whatever the storage type of the engine is
   static constexpr bool kMfmaBackward = n == 3 && m == 2;
+  // larger models: one instance per wavefront, matrices in LDS (k_backward_coop)
+  static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
       if (!force_valu_backward_ && mfma_offsets_ok_) {
@@ -372,6 +374,12 @@ class Engine final : public EngineBase {
           hipLaunchKernelGGL((k_backward_mfma<T, M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         else
           hipLaunchKernelGGL((k_backward_mfma<T, M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+        return;
+      }
+    }
+    if constexpr (kCoopBackward) {
+      if (!force_valu_backward_) {
+        hipLaunchKernelGGL((k_backward_coop<T, M>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
         return;
       }
     }

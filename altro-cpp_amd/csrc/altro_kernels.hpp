@@ -220,6 +220,277 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
 }
 
 // -------------------------------------------------------------------------------------------------
+// iLQR::BackwardPass with ONE INSTANCE PER WAVEFRONT, for the larger models (n = 6, n = 12): the
+// one-lane-per-instance kernel above keeps P, the record and the Q-function of an instance in one lane's
+// registers, which for n = 12 is > 1000 values -- it spills to scratch and leaves 1024 instances on 16
+// wavefronts.  Here the 64 lanes of a wave share the matrices of one instance in LDS (~9 KB) and each
+// lane computes every 64th output element of every product; the Cholesky factor of the m x m block is
+// computed redundantly by all lanes, the n + 1 triangular solves go one per lane.  The arithmetic --
+// operation by operation, summation order and arithmetic type included -- is riccati_q / riccati_gains, so
+// the engine returns the same bits as with k_backward; the
+// restart-on-failure schedule is the reference's, trivially: one instance, wave-uniform control flow.
+// -------------------------------------------------------------------------------------------------
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_backward_coop(DevArrays<T> A, DevOpts o, int all) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  using R = Rec<T, n, m>;
+  using S = T;  // arithmetic type of the recursion = storage type (riccati_q / riccati_gains do the same)
+  const int lane = threadIdx.x;
+  const int b = instance_of_slot(A, blockIdx.x, all);
+  if (b < 0) return;  // uniform
+  const int N = A.N;
+  const unsigned Bp = A.Bp;
+  __shared__ S sE[R::EP];                      // expansion record of the current knot
+  __shared__ S sP[n * n], sp[n];               // cost-to-go of knot k + 1, then of knot k
+  __shared__ S sAtP[n * n], sBtP[m * n];       // A^T P, B^T P
+  __shared__ S sQxx[n * n], sQxu[n * m], sQuu[m * m], sQx[n], sQu[m];
+  __shared__ S sK[m * n], sd[m], sKtQuu[n * m];
+  const S* sAm = sE + R::oAB;
+  const S* sBm = sE + R::oAB + n * n;
+  constexpr int kPer = (R::EP + kBlock - 1) / kBlock;  // record elements per lane
+  auto wsync = [&]() __attribute__((always_inline)) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+
+  // running cost in knot order (ilqr.hpp:326-334)
+  double J0 = 0.0;
+  for (int base = 0; base <= N; base += kBlock) {
+    const int kk = base + lane;
+    const double v = (double)A.costs[(unsigned)(kk <= N ? kk : N) * Bp + (unsigned)b];
+    for (int j = 0; j < kBlock && base + j <= N; ++j) J0 += __shfl(v, j);
+  }
+  double rho = A.rho_reg[b], drho = A.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
+  int max_reg_count = 0;
+  int status = A.status[b];
+  bool need = N > 0;
+  auto fetch = [&](int k, S* r) __attribute__((always_inline)) {
+    const T* rec = RECP(A.EXP, k, R::EP);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int e = lane + j * kBlock;
+      r[j] = (S)rec[e < R::EP ? e : R::EP - 1];
+    }
+  };
+  auto put = [&](const S* r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int e = lane + j * kBlock;
+      if (e < R::EP) sE[e] = r[j];
+    }
+  };
+  auto store_ctg = [&](int k) __attribute__((always_inline)) {
+    T* c = RECP(A.CTG, k, R::CP);
+    for (int e = lane; e < n * n; e += kBlock) c[R::oP + e] = (T)sP[e];
+    if (lane < n) c[R::op + lane] = (T)sp[lane];
+  };
+  while (need) {
+    // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138)
+    {
+      const T* rec = RECP(A.EXP, N, R::EP);
+      for (int e = lane; e < n * n; e += kBlock) sP[e] = (S)rec[R::oLxx + e];
+      if (lane < n) sp[lane] = (S)rec[R::oLx + lane];
+    }
+    wsync();
+    if (A.record_ctg) store_ctg(N);
+    bool failed = false;
+    S nxt[kPer];
+    fetch(N - 1, nxt);
+    for (int k = N - 1; k >= 0; --k) {
+      put(nxt);
+      if (k > 0) fetch(k - 1, nxt);  // in flight while this knot is processed
+      wsync();
+      // ---- riccati_q: A^T P, B^T P ----
+      for (int e = lane; e < n * n + m * n; e += kBlock) {
+        if (e < n * n) {
+          const int i = e % n, j = e / n;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sAm[l + i * n] * sP[l + j * n];
+          sAtP[i + j * n] = s;
+        } else {
+          const int f = e - n * n, i = f % m, j = f / m;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sBm[l + i * n] * sP[l + j * n];
+          sBtP[i + j * m] = s;
+        }
+      }
+      wsync();
+      // ---- Qxx, Qxu, Quu, Qx, Qu ----
+      constexpr int c1 = n * n, c2 = c1 + n * m, c3 = c2 + m * m, c4 = c3 + n, c5 = c4 + m;
+      for (int e = lane; e < c5; e += kBlock) {
+        if (e < c1) {
+          const int i = e % n, j = e / n;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sAtP[i + l * n] * sAm[l + j * n];
+          sQxx[e] = sE[R::oLxx + e] + s;
+        } else if (e < c2) {
+          const int f = e - c1, i = f % n, j = f / n;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sAtP[i + l * n] * sBm[l + j * n];
+          sQxu[f] = sE[R::oLxu + f] + s;
+        } else if (e < c3) {
+          const int f = e - c2, i = f % m, j = f / m;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sBtP[i + l * m] * sBm[l + j * n];
+          sQuu[f] = sE[R::oLuu + f] + s;
+        } else if (e < c4) {
+          const int i = e - c3;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sAm[l + i * n] * sp[l];
+          sQx[i] = sE[R::oLx + i] + s;
+        } else {
+          const int i = e - c4;
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < n; ++l) s += sBm[l + i * n] * sp[l];
+          sQu[i] = sE[R::oLu + i] + s;
+        }
+      }
+      wsync();
+      // ---- riccati_gains: Eigen::LLT of Quu + rho I (every lane, redundantly) ----
+      S L[m * m], Linv[m];
+#pragma unroll
+      for (int e = 0; e < m * m; ++e) L[e] = sQuu[e];
+#pragma unroll
+      for (int i = 0; i < m; ++i) L[i + i * m] += S(rho);
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        S xjj = L[j + j * m];
+#pragma unroll
+        for (int l = 0; l < j; ++l) xjj -= L[j + l * m] * L[j + l * m];
+        if (xjj <= S(0)) ok = false;
+        const S ljj = sqrt_(xjj);
+        L[j + j * m] = ljj;
+        Linv[j] = S(1) / ljj;
+#pragma unroll
+        for (int i = j + 1; i < m; ++i) {
+          S s = L[i + j * m];
+#pragma unroll
+          for (int l = 0; l < j; ++l) s -= L[i + l * m] * L[j + l * m];
+          L[i + j * m] = s * Linv[j];
+        }
+      }
+      if (!ok) {  // uniform: ilqr.hpp:409-427, raise the regularisation and restart the sweep
+        increase_reg(o, &rho, &drho);
+        if (rho >= o.bp_reg_max) max_reg_count++;
+        if (max_reg_count >= o.bp_reg_fail_threshold) {
+          status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
+          need = false;
+        }
+        failed = true;
+        break;
+      }
+      // ---- K = -(L L^T)^-1 Qxu^T, d = -(L L^T)^-1 Qu: one right-hand side per lane ----
+      if (lane <= n) {
+        const int j = lane;
+        S col[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) col[i] = (j < n) ? sQxu[(j < n ? j : 0) + i * n] : sQu[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          S s = col[i];
+#pragma unroll
+          for (int l = 0; l < i; ++l) s -= L[i + l * m] * col[l];
+          col[i] = s * Linv[i];
+        }
+#pragma unroll
+        for (int i = m - 1; i >= 0; --i) {
+          S s = col[i];
+#pragma unroll
+          for (int l = i + 1; l < m; ++l) s -= L[l + i * m] * col[l];
+          col[i] = s * Linv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          if (j < n)
+            sK[i + j * m] = -col[i];
+          else
+            sd[i] = -col[i];
+        }
+      }
+      wsync();
+      // ---- K^T Quu ----
+      for (int e = lane; e < n * m; e += kBlock) {
+        const int i = e % n, j = e / n;
+        S s = S(0);
+#pragma unroll
+        for (int l = 0; l < m; ++l) s += sK[l + i * m] * sQuu[l + j * m];
+        sKtQuu[e] = s;
+      }
+      wsync();
+      // ---- cost-to-go with the un-regularised Q (knot_point_function_type.hpp:220-230) ----
+      for (int e = lane; e < n * n + n; e += kBlock) {
+        if (e < n * n) {
+          const int i = e % n, j = e / n;
+          S a = S(0), bq = S(0), c = S(0);
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            a += sKtQuu[i + l * n] * sK[l + j * m];
+            bq += sK[l + i * m] * sQxu[j + l * n];
+            c += sQxu[i + l * n] * sK[l + j * m];
+          }
+          sP[e] = sQxx[e] + a + bq + c;
+        } else {
+          const int i = e - n * n;
+          S a = S(0), bq = S(0), c = S(0);
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            a += sKtQuu[i + l * n] * sd[l];
+            bq += sK[l + i * m] * sQu[l];
+            c += sQxu[i + l * n] * sd[l];
+          }
+          sp[i] = sQx[i] + a + bq + c;
+        }
+      }
+      // ---- expected decrease (every lane), gains out ----
+      {
+        S v0 = S(0), v1 = S(0);
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          v0 += sd[i] * sQu[i];
+          S s = S(0);
+#pragma unroll
+          for (int l = 0; l < m; ++l) s += sQuu[i + l * m] * sd[l];
+          v1 += sd[i] * s;
+        }
+        dV0 += (double)v0;
+        dV1 += (double)(S(0.5) * v1);
+      }
+      {
+        T* kd = RECP(A.KD, k, R::KP);
+        for (int e = lane; e < R::KP; e += kBlock) {
+          S v = S(0);
+          if (e >= R::oK && e < R::oK + m * n) v = sK[e - R::oK];
+          if (e >= R::oD && e < R::oD + m) v = sd[e - R::oD];
+          kd[e] = (T)v;
+        }
+      }
+      wsync();
+      if (A.record_ctg) store_ctg(k);
+    }
+    if (!failed) need = false;  // sweep completed
+  }
+  if (lane != 0) return;
+  A.J0[b] = J0;
+  if (A.need_init_cost[b]) {
+    A.initial_cost[b] = J0;
+    A.need_init_cost[b] = 0;
+  }
+  A.reg_log[b] = rho;  // stats_.Log("reg", rho_)
+  decrease_reg(o, &rho, &drho);
+  A.rho_reg[b] = rho;
+  A.drho[b] = drho;
+  A.dV0[b] = dV0;
+  A.dV1[b] = dV1;
+  A.status[b] = status;
+}
+
+// -------------------------------------------------------------------------------------------------
 // iLQR::BackwardPass on the fp64 matrix cores (n = 3, m = 2: the unicycle of the headline config).
 //
 // v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 blocks per instruction.  Lane layout
