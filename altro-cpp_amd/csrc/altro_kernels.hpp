@@ -6,8 +6,9 @@
 //   k_expansions     grid (instance x knot): cost/AL expansion + RK4 Jacobian + knot cost.
 //                    Embarrassingly parallel (ilqr.hpp:670-677).
 //   k_backward_mfma  backward Riccati recursion on the fp64 4x4x4 matrix cores, 16 lanes per instance,
-//                    4 instances per wavefront (n = 3, m = 2, fp64);  k_backward: one lane per
-//                    instance on the VALU for every other shape.  Both keep the reference's
+//                    4 instances per wavefront (n = 3, m = 2; fp64 arithmetic, fp64 or fp32 storage);
+//                    k_backward_coop: one instance per wavefront, matrices in LDS (n >= 6);
+//                    k_backward: one lane per instance on the VALU (fallback).  All keep the reference's
 //                    restart-on-Cholesky-failure schedule (ilqr.hpp:385-445) with a wave-uniform k.
 //   k_forward2       SPECULATIVE PARALLEL LINE SEARCH: the (up to) 20 backtracking trials of
 //                    ilqr.hpp:525-545 are independent closed-loop rollouts, so each instance gets 20
