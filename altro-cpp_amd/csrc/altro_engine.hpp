@@ -314,6 +314,14 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   altro_status GetTiming(altro_timing* t) override {
+    if (timing_.instance_iterations < 0 && uploaded_) {
+      ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+      std::vector<int> it(Bp_);
+      ALTRO_HIP_CHECK(hipMemcpy(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
+      long long tot = 0;
+      for (int b = 0; b < B_; ++b) tot += it[b];
+      timing_.instance_iterations = tot;
+    }
     *t = timing_;
     return ALTRO_OK;
   }
@@ -1051,13 +1059,7 @@ class Engine final : public EngineBase {
           timing_.forward_pass_ms += ms;
       }
     }
-    {
-      std::vector<int> it(Bp_);
-      ALTRO_HIP_CHECK(hipMemcpy(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
-      long long tot = 0;
-      for (int b = 0; b < B_; ++b) tot += it[b];
-      timing_.instance_iterations = tot;
-    }
+    timing_.instance_iterations = -1;  // summed on demand (GetTiming): keeps a copy out of every solve
     timing_.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return ALTRO_OK;
   }
