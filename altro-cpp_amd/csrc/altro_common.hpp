@@ -97,7 +97,8 @@ struct ProblemDesc {
 // Options in the form the kernels consume (copied from altro_options at every launch).
 struct DevOpts {
   int max_iterations_total, max_iterations_outer, max_iterations_inner;
-  int bp_reg_fail_threshold, check_forwardpass_bounds, line_search_max_iterations, reset_duals, pad;
+  int bp_reg_fail_threshold, check_forwardpass_bounds, line_search_max_iterations, reset_duals;
+  int fast_forward_stalls;  // opt-in (ALTRO_HIP_FAST_FORWARD_STALLS): see k_sweep_fused
   double cost_tolerance, gradient_tolerance;
   double bp_reg_increase_factor, bp_reg_initial, bp_reg_max, bp_reg_min;
   double state_max, control_max;

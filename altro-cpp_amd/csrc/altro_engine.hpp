@@ -853,7 +853,7 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
-      fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2) * sizeof(double) +
+      fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2 + 4) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
@@ -893,7 +893,8 @@ class Engine final : public EngineBase {
   altro_status Solve(const altro_options& o, int mode) {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     const auto t0 = std::chrono::steady_clock::now();
-    const DevOpts d = ToDevOpts(o);
+    DevOpts d = ToDevOpts(o);
+    d.fast_forward_stalls = fast_forward_ ? 1 : 0;
     const bool prof = o.profiler_enable != 0;
     last_mode_ilqr_ = (mode == kFwdILQR);
     std::memset(&timing_, 0, sizeof(timing_));
@@ -1079,6 +1080,7 @@ class Engine final : public EngineBase {
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
+  bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
   int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;

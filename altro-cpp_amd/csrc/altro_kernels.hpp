@@ -1192,7 +1192,8 @@ template <class T, class M>
 ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
                               int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
-                              int* active_out = nullptr, T* sLamW = nullptr, T* sPenW = nullptr) {
+                              int* active_out = nullptr, T* sLamW = nullptr, T* sPenW = nullptr,
+                              double* ff = nullptr) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -1232,6 +1233,11 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
       if (!accepted) increase_reg(o, &rho, &drho);  // ilqr.hpp:550
       A.rho_reg[b] = rho;
       A.drho[b] = drho;
+      if (ff) {  // what the stall detector of the persistent kernel compares between iterations
+        ff[0] = accepted ? 0.0 : 1.0;
+        ff[1] = rho;
+        ff[2] = drho;
+      }
     }
     if (accepted) {
       A.cost_cur[b] = J_sel;  // stats_.Log("cost"/"alpha"/"z")
@@ -1302,6 +1308,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     }
   }
   if (t != 0) return;
+  if (ff) ff[3] = inner_done ? 1.0 : 0.0;
   if (active_out) *active_out = active ? 1 : 0;  // persistent sweep kernel: keep iterating?
   if (!active) {
     A.phase[b] = 0;
@@ -2096,7 +2103,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 template <class T, class M, bool FUSED>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
-                             const double* fh, int* active_out = nullptr, T* sCand = nullptr) {
+                             const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -2376,7 +2383,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
-                       FUSED ? sPen : nullptr);
+                       FUSED ? sPen : nullptr, FUSED ? ff : nullptr);
   STAMP(8 + 6);
 }
 
@@ -2472,7 +2479,10 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
   const int fused_junk = (int)(reinterpret_cast<T*>(fh + 6) - sKDf);  // one junk slot per lane, in units of T
 
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
-  T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2);  // [N+1][20][n+m] line-search candidates (16-byte aligned)
+  double* ff = fh + 6 + kBlock + 2;                          // {rejected, rho, drho, inner_done} of the last iteration
+  T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2 + 4);  // [N+1][20][n+m] line-search candidates (16-byte aligned)
+  bool prev_rej = false;
+  double prev_rho = -1.0, prev_drho = -1.0;
   int loops = 0;
 #ifdef ALTRO_X
 #define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
@@ -2521,11 +2531,37 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     FSTAMP(wave * 4 + 3);
 
     // ---- F ----
-    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand);
+    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
     if (wave == 1) FSTAMP(8);
     ++loops;
     __syncthreads();
     if (!persistent || *active_flag == 0) break;
+    if (o.fast_forward_stalls) {
+      // OPT-IN, off by default.  A rejected line search leaves the trajectory, the multipliers and -- once
+      // the regularisation has settled into its increase/decrease cycle -- the whole state of the instance
+      // unchanged, so the next iteration recomputes exactly the same rejection: the reference (and the default
+      // path here) repeats it until max_iterations_inner.  Two consecutive rejections with bit-identical
+      // regularisation state prove the fixed point; the identical iterations in between are then only
+      // counted (and logged), and the last one is executed normally so that every status decision is taken
+      // by the usual code.
+      const bool rej = ff[0] != 0.0 && ff[3] == 0.0;
+      const bool stalled = rej && prev_rej && ff[1] == prev_rho && ff[2] == prev_drho;
+      prev_rej = rej;
+      prev_rho = ff[1];
+      prev_drho = ff[2];
+      if (stalled && tid == 0) {
+        const int it_in = A.it_inner[b], it_tot = A.it_total[b];
+        int k = o.max_iterations_inner - 1 - it_in;
+        const int k2 = o.max_iterations_total - 1 - it_tot;
+        k = k < k2 ? k : k2;
+        if (k > 0) {
+          A.it_inner[b] = it_in + k;
+          A.it_total[b] = it_tot + k;
+          for (int j = 0; j < k; ++j) hist_push(A, b);
+          loops += k;
+        }
+      }
+    }
     // (waves of a workgroup share the CU's vector L1, which stores write through and keep coherent,
     // so what this iteration wrote -- trajectory, multipliers, records -- is what the next one reads)
     __syncthreads();  // everyone has read the flag before phase 3 of the next iteration rewrites it

@@ -265,6 +265,9 @@ def main():
                 "sweeps": tm["sweeps"], "device": name, "cus": cus,
                 **({"pipeline": args.pipeline, "note": "NOT the headline configuration: solves of consecutive steps "
                     "overlap (asynchronous handles)"} if args.pipeline > 1 else {}),
+                **({"fast_forward_stalls": True, "note_ff": "NOT the headline configuration: ALTRO_HIP_FAST_FORWARD_STALLS "
+                    "counts the bit-identical repetitions of a rejected line search instead of recomputing them"}
+                   if os.environ.get("ALTRO_HIP_FAST_FORWARD_STALLS") else {}),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -46,3 +46,44 @@ def test_fused_tail_matches_separate_kernels_bitwise(tmp_path):
         if k.endswith("_fused"):
             continue
         assert np.array_equal(a[k], b[k]), k
+
+
+_SCRIPT_FF = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+s = P.batch_turn90(make, batch=512, seed=P.SEED_BASE + 3)
+s.set_record_history(301)
+s.solve()
+st = s.get_stats()
+X, U = s.get_trajectory()
+out = {"X": X, "U": U, "K": s.get_gains()[0], "lam": s.get_duals(), "pen": s.get_penalties()}
+for f in st.dtype.names:
+    out["st_" + f] = st[f]
+bad = np.flatnonzero(st["status"] != 0)
+out["bad"] = bad
+for b in bad[:4]:
+    for f in ("cost", "alpha", "gradient", "cost_decrease", "regularization", "violations", "max_penalty", "improvement_ratio"):
+        out["h%%d_%%s" %% (b, f)] = s.get_history(int(b), f)
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_stall_fast_forward_is_bit_identical(tmp_path):
+    """ALTRO_HIP_FAST_FORWARD_STALLS (opt-in): the straggler instances sit at a fixed point -- a rejected line
+    search repeated ~100 times -- and counting those repetitions instead of recomputing them must not change one
+    bit of the statistics, the per-iteration history, the trajectories, the gains or the multipliers."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for tag, env in (("plain", {}), ("ff", {"ALTRO_HIP_FAST_FORWARD_STALLS": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_FF % root, out], check=True, env=dict(os.environ, **env), timeout=600)
+        res.append(np.load(out))
+    a, b = res
+    assert len(a["bad"]) > 0  # there are stragglers in this batch
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
