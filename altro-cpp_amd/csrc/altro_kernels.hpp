@@ -2480,9 +2480,10 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
 
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
   double* ff = fh + 6 + kBlock + 2;                          // {rejected, rho, drho, inner_done} of the last iteration
-  T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2 + 4);  // [N+1][20][n+m] line-search candidates (16-byte aligned)
+  T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2 + 16);  // [N+1][20][n+m] line-search candidates (128-byte phase kept)
   bool prev_rej = false;
   double prev_rho = -1.0, prev_drho = -1.0;
+  int skipped = 0;
   int loops = 0;
 #ifdef ALTRO_X
 #define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
@@ -2558,7 +2559,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
           A.it_inner[b] = it_in + k;
           A.it_total[b] = it_tot + k;
           for (int j = 0; j < k; ++j) hist_push(A, b);
-          loops += k;
+          skipped += k;  // (kept apart from `loops`, which must stay wave-uniform)
         }
       }
     }
@@ -2572,8 +2573,8 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     RECP(A.KD, k, R::KP)[e] = sKDf[i];
   }
   if (sweeps_out && tid == 0) {
-    atomicMax(sweeps_out, loops);     // longest chain of iterations
-    atomicAdd(sweeps_out + 1, loops);  // (instance, iteration) units processed by this launch
+    atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations
+    atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
   }
 }
 
