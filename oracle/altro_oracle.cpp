@@ -35,6 +35,10 @@
 
 namespace {
 
+// Oracle-only dtype code (next to ALTRO_F64 = 0 / ALTRO_F32 = 1 of include/altro_hip.h): fp64 arithmetic with
+// the expansion and gain records rounded to fp32 -- what the product's ALTRO_F32 engine computes.
+constexpr int ORACLE_F64_F32REC = 2;
+
 // ------------------------------------------------------------------------------------------------
 // Continuous-time models.  jac is n x (n+m), column-major, fully written.
 // ------------------------------------------------------------------------------------------------
@@ -194,6 +198,7 @@ struct SolverBase {
   virtual void GetConVals(double* out) = 0;
   virtual void GetStats(altro_stats* s) = 0;
   virtual Stats& RawStats() = 0;
+  virtual void SetRoundRecords(bool on) = 0;
   altro_options opts;
 };
 
@@ -232,6 +237,15 @@ struct Instance final : SolverBase {
   int status_ = ALTRO_UNSOLVED;     // iLQR status_ (ilqr.hpp:798)
   int status_al_ = ALTRO_UNSOLVED;  // AL status_ (al_solver.hpp:222)
   Stats stats;
+  // ORACLE_F64_F32REC (not a reference mode): emulates the product's ALTRO_F32 engine, which computes in
+  // fp64 and keeps only the two bulk per-knot RECORDS -- the expansion ([A|B], lxx, lxu, luu, lx, lu) and the
+  // gains (K, d) -- in fp32.  The fp64 restatement below is unchanged; the stored records are rounded to
+  // float at the points where the device stores them.
+  bool round_records = false;
+  void RoundRec(T* v, int count) const {
+    if (round_records)
+      for (int i = 0; i < count; ++i) v[i] = (T)(float)v[i];
+  }
 
   Instance(int N_, const Model& mdl) : model(mdl), N(N_) {
     h.assign(N + 1, 0.0f);
@@ -258,6 +272,7 @@ struct Instance final : SolverBase {
     opts = o;
   }
   Stats& RawStats() override { return stats; }
+  void SetRoundRecords(bool on) override { round_records = on; }
 
   // ---- problem definition -----------------------------------------------------------------
   void SetLQRCost(int k, const double* Q, const double* R, const double* xref, const double* uref) {
@@ -598,6 +613,14 @@ struct Instance final : SolverBase {
       CostExpansion(k, x, u);
       if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm]);
       costs[k] = KnotCost(k, x, u);
+      if (round_records) {
+        RoundRec(&AB[k * n * nm], n * nm);
+        RoundRec(&lxx[k * n * n], n * n);
+        RoundRec(&lxu[k * n * m], n * m);
+        RoundRec(&luu[k * m * m], m * m);
+        RoundRec(&lx[k * n], n);
+        RoundRec(&lu[k * m], m);
+      }
     }
   }
 
@@ -742,6 +765,9 @@ struct Instance final : SolverBase {
     }
     deltaV[0] += dv0;
     deltaV[1] += T(0.5) * dv1;
+    // the device keeps K, d in registers for the cost-to-go and rounds only the stored gain record
+    RoundRec(Kk, m * n);
+    RoundRec(dk, m);
     return true;
   }
 
@@ -1161,6 +1187,7 @@ altro_status Build(oracle_handle h) {
   for (int b = 0; b < h->desc.batch; ++b) {
     std::unique_ptr<SolverBase> I =
         h->desc.dtype == ALTRO_F32 ? MakeForModel<float>(h, b) : MakeForModel<double>(h, b);
+    if (I && h->desc.dtype == ORACLE_F64_F32REC) I->SetRoundRecords(true);
     if (!I) {
       h->err = "unsupported (model, n, m) combination";
       return ALTRO_UNSUPPORTED;
