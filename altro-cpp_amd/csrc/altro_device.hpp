@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "altro_common.hpp"
 
 namespace altro_hip {
@@ -77,6 +79,56 @@ __device__ __forceinline__ void store_rec(T* p, const T* in) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Record storage type.  An engine is instantiated for (T, M): T is the type of the solver state and of
+// ALL arithmetic (trajectory, multipliers, costs, Riccati recursion, rollouts); M is the model, optionally
+// wrapped in WithRec32<>, which keeps the two BULK per-knot records -- the expansion record and the gain
+// record, 94 of the 127 elements a knot moves per iteration for the unicycle -- in fp32 in HBM.  That is the
+// ALTRO_F32 dtype of the C-ABI: fp32 where the bytes are, fp64 where differences of nearly equal numbers
+// decide the schedule (dJ < 1e-4 on J ~ 1e2, z = (J0 - J) / expected, c of an active constraint).  An
+// all-fp32 solver loses 10-15 points of solved fraction on the obstacle problems and cannot meet the stated
+// 1e-3 state tolerance on the 12-state model; this one reproduces the fp64 schedule (scripts/cpu_fp32_study.py).
+// -------------------------------------------------------------------------------------------------
+template <class M>
+struct WithRec32 : M {
+  using rec_t = float;
+};
+template <class T, class M, class = void>
+struct RecScalar {
+  using type = T;
+};
+template <class T, class M>
+struct RecScalar<T, M, std::void_t<typename M::rec_t>> {
+  using type = typename M::rec_t;
+};
+template <class T, class M>
+using rec_scalar_t = typename RecScalar<T, M>::type;
+
+// A record stored as RS in memory <-> T registers (Rec<T> register layout; the element offsets of Rec<T>
+// and Rec<RS> coincide, only the padding at the end differs).  E = number of meaningful elements.
+template <class T, class RS, int EPT, int EPS, int E>
+__device__ __forceinline__ void load_rec_as(const RS* p, T* out) {
+  if constexpr (std::is_same<T, RS>::value) {
+    load_rec<T, EPT>(p, out);
+  } else {
+    RS tmp[EPS];
+    load_rec<RS, EPS>(p, tmp);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = e < E ? (T)tmp[e < E ? e : 0] : T(0);
+  }
+}
+template <class T, class RS, int EPT, int EPS, int E>
+__device__ __forceinline__ void store_rec_as(RS* p, const T* in) {
+  if constexpr (std::is_same<T, RS>::value) {
+    store_rec<T, EPT>(p, in);
+  } else {
+    RS tmp[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) tmp[e] = e < E ? (RS)in[e < E ? e : 0] : RS(0);
+    store_rec<RS, EPS>(p, tmp);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Device array bundle (passed to kernels by value)
 // -------------------------------------------------------------------------------------------------
 template <class T>
@@ -84,10 +136,11 @@ struct DevArrays {
   int B, Bp, N;
   // trajectory (Z_) records X[k][b][nP], U[k][b][mP]; initial state x0[b][nP]
   T *x0, *X, *U;
-  // expansion records EXP[k][b][EP] (dynamics Jacobian + cost expansion), per-knot cost costs[k][b]
-  T *EXP, *costs;
-  // gain records KD[k][b][KP]; cost-to-go records CTG[k][b][CP] (written only on request)
-  T *KD, *CTG;
+  // expansion records EXP[k][b][EP] (dynamics Jacobian + cost expansion) and gain records KD[k][b][KP],
+  // stored as rec_scalar_t<T, M> (T, or float under WithRec32<M>): typed by the kernels, which know M
+  void *EXP, *KD;
+  // per-knot cost costs[k][b]; cost-to-go records CTG[k][b][CP] (written only on request)
+  T *costs, *CTG;
   // line-search candidates, instance-major [b][k][trial][x|u] (Zbar_ of every speculative trial)
   T* trial;
   // constraint rows [row][b]: duals, penalties, stored constraint values (c_)

@@ -65,6 +65,8 @@ template <class T, class M>
 class Engine final : public EngineBase {
   static constexpr int n = M::n, m = M::m, nm = n + m;
   using R = Rec<T, n, m>;
+  using RS = rec_scalar_t<T, M>;  // storage type of the expansion and gain records (float under WithRec32<>)
+  using RR = Rec<RS, n, m>;
 
  public:
   explicit Engine(const altro_desc& d) : desc_(d) {}
@@ -217,10 +219,10 @@ class Engine final : public EngineBase {
   }
   altro_status GetGains(double* K, double* d) override {
     if (K) {
-      altro_status st = DownloadRec(A_.KD, N_, R::KP, R::oK, m * n, K);
+      altro_status st = DownloadRec((const RS*)A_.KD, N_, RR::KP, RR::oK, m * n, K);
       if (st != ALTRO_OK) return st;
     }
-    if (d) return DownloadRec(A_.KD, N_, R::KP, R::oD, m, d);
+    if (d) return DownloadRec((const RS*)A_.KD, N_, RR::KP, RR::oD, m, d);
     return ALTRO_OK;
   }
   altro_status SetRecordCtg(int enable) override {
@@ -243,12 +245,14 @@ class Engine final : public EngineBase {
                             double* lu) override {
     if (k < 0 || k > N_) return ALTRO_INVALID_ARG;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    std::vector<T> h((size_t)R::EP * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), A_.EXP + (size_t)k * Bp_ * R::EP, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    altro_status sst = Sync();
+    if (sst != ALTRO_OK) return sst;
+    std::vector<RS> h((size_t)RR::EP * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), (const RS*)A_.EXP + (size_t)k * Bp_ * RR::EP, h.size() * sizeof(RS), hipMemcpyDeviceToHost));
     auto take = [&](double* out, int off, int E, bool stage_only) {
       if (!out || (stage_only && k >= N_)) return;
       for (int b = 0; b < B_; ++b)
-        for (int e = 0; e < E; ++e) out[(size_t)b * E + e] = (double)h[(size_t)b * R::EP + off + e];
+        for (int e = 0; e < E; ++e) out[(size_t)b * E + e] = (double)h[(size_t)b * RR::EP + off + e];
     };
     take(AB, R::oAB, n * nm, true);
     take(lxx, R::oLxx, n * n, false);
@@ -417,8 +421,7 @@ class Engine final : public EngineBase {
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     {
       // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)
-      hipLaunchKernelGGL((k_forward<T, M, false>), grid, dim3(kBlock), 0, stream_, A, d_pd_, pd_, d, mode, all,
-                         fwd_per_wave_);
+      hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, stream_, A, d_pd_, d, mode, all, fwd_per_wave_);
     }
   }
   altro_status Sync() {
@@ -449,13 +452,16 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]
-  altro_status DownloadRec(const T* dev, int knots, int EP, int off, int E, double* out) {
+  template <class E_>
+  altro_status DownloadRec(const E_* dev, int knots, int EP, int off, int E, double* out) {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    std::vector<T> h((size_t)knots * EP * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    altro_status sst = Sync();  // the stream is non-blocking: order this null-stream copy after its work
+    if (sst != ALTRO_OK) return sst;
+    std::vector<E_> h((size_t)knots * EP * Bp_);
+    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, h.size() * sizeof(E_), hipMemcpyDeviceToHost));
     for (int k = 0; k < knots; ++k)
       for (int b = 0; b < B_; ++b) {
-        const T* src = &h[((size_t)k * Bp_ + b) * EP + off];
+        const E_* src = &h[((size_t)k * Bp_ + b) * EP + off];
         double* dst = out + ((size_t)b * knots + k) * E;
         for (int e = 0; e < E; ++e) dst[e] = (double)src[e];
       }
@@ -750,7 +756,7 @@ class Engine final : public EngineBase {
     }
     {
       const double lim = 2147483647.0;
-      const double biggest = std::max({(double)(N_ + 1) * R::EP * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
+      const double biggest = std::max({(double)(N_ + 1) * RR::EP * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
                                        (double)std::max(rows, 1) * Bp_});
       if (biggest > lim) {
         err_ = "problem too large for 32-bit device indexing (split the batch over several handles)";
@@ -775,13 +781,18 @@ class Engine final : public EngineBase {
     {
       // k_backward_mfma reads a zeroed pad record behind the last knot and lets its prefetch run up to
       // kBwdFrontPad records below knot 0
-      const size_t front = (size_t)kBwdFrontPad * R::EP * bp;
-      ALTRO_ALLOC(A_.EXP, front + (size_t)(N_ + 1) * R::EP * bp + R::EP);
-      A_.EXP += front;
-      mfma_offsets_ok_ = (front + (size_t)(N_ + 2) * R::EP * bp) * sizeof(T) < (size_t)0xffffffffu;
+      const size_t front = (size_t)kBwdFrontPad * RR::EP * bp;
+      RS* exp = nullptr;
+      ALTRO_ALLOC(exp, front + (size_t)(N_ + 1) * RR::EP * bp + RR::EP);
+      A_.EXP = exp + front;
+      mfma_offsets_ok_ = (front + (size_t)(N_ + 2) * RR::EP * bp) * sizeof(RS) < (size_t)0xffffffffu;
     }
     ALTRO_ALLOC(A_.costs, (size_t)(N_ + 1) * bp);
-    ALTRO_ALLOC(A_.KD, (size_t)N_ * R::KP * bp);
+    {
+      RS* kd = nullptr;
+      ALTRO_ALLOC(kd, (size_t)N_ * RR::KP * bp);
+      A_.KD = kd;
+    }
     ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
     ALTRO_HIP_CHECK(hipMalloc((void**)&A_.trial, (size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T)));
     allocs_.push_back((void*)A_.trial);

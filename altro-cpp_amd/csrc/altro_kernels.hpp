@@ -81,6 +81,8 @@ template <class T, class M>
 ALTRO_DEV T expansion_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pd, int b, int k) {
   constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
+  using RS = rec_scalar_t<T, M>;
+  using RR = Rec<RS, n, m>;
   const int N = A.N;
   const unsigned Bp = A.Bp;
   T xr[R::nP], ur[R::mP];
@@ -98,7 +100,7 @@ ALTRO_DEV T expansion_body(const DevArrays<T>& A, const ProblemDesc* __restrict_
                                            E + R::oLuu);
   A.costs[(unsigned)k * Bp + (unsigned)b] = J;
   if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
-  store_rec<T, R::EP>(RECP(A.EXP, k, R::EP), E);
+  store_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP((RS*)A.EXP, k, RR::EP), E);
   return J;
 }
 // tell the host how many instances this sweep works on (it is polling the mapped word)
@@ -130,12 +132,18 @@ template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, int all) {
   constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
+  using RS = rec_scalar_t<T, M>;
+  using RR = Rec<RS, n, m>;
+  const RS* const EXPp = (const RS*)A.EXP;
   const int b0 = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
   const bool lane_on = b0 >= 0;
   if (__ballot(lane_on) == 0ull) return;
   const int b = lane_on ? b0 : 0;
   const int N = A.N;
   const unsigned Bp = A.Bp;
+  auto load_exp = [&](int k, T* E) __attribute__((always_inline)) {
+    load_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP(EXPp, k, RR::EP), E);
+  };
   // J0 = costs_.sum() of the expansion step (ilqr.hpp:516); it is also the inner solve's
   // initial_cost on its first iteration (ilqr.hpp:298: same trajectory, same duals/penalties).
   double J0 = 0.0;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
   T E[R::EP];
   while (__ballot(need) != 0ull) {
     // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138)
-    load_rec<T, R::EP>(RECP(A.EXP, N, R::EP), E);
+    load_exp(N, E);
 #pragma unroll
     for (int e = 0; e < n * n; ++e) P[e] = E[R::oLxx + e];
 #pragma unroll
@@ -166,14 +174,14 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
       store_rec<T, R::CP>(RECP(A.CTG, N, R::CP), c);
     }
     bool running = need;
-    load_rec<T, R::EP>(RECP(A.EXP, N - 1, R::EP), E);
+    load_exp(N - 1, E);
     for (int k = N - 1; k >= 0; --k) {
       // Q-function assembly consumes the expansion registers ...
       QExp<T, n, m> Q;
       riccati_q<T, n, m>(E + R::oAB, E + R::oLxx, E + R::oLxu, E + R::oLuu, E + R::oLx, E + R::oLu, P, p, Q);
       // ... which are immediately refilled with the next knot's record: the loads fly while the
       // Cholesky / gains / cost-to-go half of this knot executes (no second register buffer)
-      if (k > 0) load_rec<T, R::EP>(RECP(A.EXP, k - 1, R::EP), E);
+      if (k > 0) load_exp(k - 1, E);
       if (running) {
         T KD[R::KP];
 #pragma unroll
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
           }
           running = false;
         } else {
-          store_rec<T, R::KP>(RECP(A.KD, k, R::KP), KD);
+          store_rec_as<T, RS, R::KP, RR::KP, m * n + m>(RECP((RS*)A.KD, k, RR::KP), KD);
           if (A.record_ctg) {
             T c[R::CP];
 #pragma unroll
@@ -233,9 +241,12 @@ __global__ __launch_bounds__(kBlock) void k_backward(DevArrays<T> A, DevOpts o, 
 // -------------------------------------------------------------------------------------------------
 template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_backward_coop(DevArrays<T> A, DevOpts o, int all) {
-  constexpr int n = M::n, m = M::m, nm = n + m;
+  constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
-  using S = T;  // arithmetic type of the recursion = storage type (riccati_q / riccati_gains do the same)
+  using RS = rec_scalar_t<T, M>;  // storage type of the expansion / gain records
+  using RR = Rec<RS, n, m>;
+  using S = T;  // arithmetic type of the recursion (riccati_q / riccati_gains do the same)
+  const RS* const EXPp = (const RS*)A.EXP;
   const int lane = threadIdx.x;
   const int b = instance_of_slot(A, blockIdx.x, all);
   if (b < 0) return;  // uniform
@@ -264,11 +275,11 @@ __global__ __launch_bounds__(kBlock) void k_backward_coop(DevArrays<T> A, DevOpt
   int status = A.status[b];
   bool need = N > 0;
   auto fetch = [&](int k, S* r) __attribute__((always_inline)) {
-    const T* rec = RECP(A.EXP, k, R::EP);
+    const RS* rec = RECP(EXPp, k, RR::EP);
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
       const int e = lane + j * kBlock;
-      r[j] = (S)rec[e < R::EP ? e : R::EP - 1];
+      r[j] = (S)rec[e < R::eE ? e : R::eE - 1];
     }
   };
   auto put = [&](const S* r) __attribute__((always_inline)) {
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_backward_coop(DevArrays<T> A, DevOpt
   while (need) {
     // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138)
     {
-      const T* rec = RECP(A.EXP, N, R::EP);
+      const RS* rec = RECP(EXPp, N, RR::EP);
       for (int e = lane; e < n * n; e += kBlock) sP[e] = (S)rec[R::oLxx + e];
       if (lane < n) sp[lane] = (S)rec[R::oLx + lane];
     }
@@ -463,12 +474,12 @@ __global__ __launch_bounds__(kBlock) void k_backward_coop(DevArrays<T> A, DevOpt
         dV1 += (double)(S(0.5) * v1);
       }
       {
-        T* kd = RECP(A.KD, k, R::KP);
-        for (int e = lane; e < R::KP; e += kBlock) {
+        RS* kd = RECP((RS*)A.KD, k, RR::KP);
+        for (int e = lane; e < RR::KP; e += kBlock) {
           S v = S(0);
           if (e >= R::oK && e < R::oK + m * n) v = sK[e - R::oK];
           if (e >= R::oD && e < R::oD + m) v = sd[e - R::oD];
-          kd[e] = (T)v;
+          kd[e] = (RS)v;
         }
       }
       wsync();
@@ -572,6 +583,9 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
   constexpr int n = 3, m = 2;
   using R = Rec<T, n, m>;
+  using RS = rec_scalar_t<T, M>;  // storage type of the expansion / gain records in HBM
+  using RR = Rec<RS, n, m>;
+  static_assert(RR::KP == R::KP, "the gain chunk in LDS is laid out like the stored record");
   const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
   const int b0 = (FUSED && blk != 0) ? -1 : instance_of_slot(A, slot_base + blk, all);
   const bool inst_on = b0 >= 0;
@@ -599,19 +613,19 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   // (kBwdFrontPad records, see the allocation).  Offsets are 32-bit BYTE offsets from the start of the
   // front pad, so a load is one instruction (scalar base + vector offset) and a cursor step one
   // subtraction; the engine only selects this kernel when the array is smaller than 4 GiB.
-  const unsigned strideB = Bp * (unsigned)R::EP * (unsigned)sizeof(T);
+  const unsigned strideB = Bp * (unsigned)RR::EP * (unsigned)sizeof(RS);
   const unsigned frontB = (unsigned)kBwdFrontPad * strideB;
   const unsigned zoff = frontB + (unsigned)(N + 1) * strideB;
-  const unsigned rec0 = frontB + (unsigned)b * (unsigned)R::EP * (unsigned)sizeof(T);
+  const unsigned rec0 = frontB + (unsigned)b * (unsigned)RR::EP * (unsigned)sizeof(RS);
   const unsigned sA = offA >= 0 ? strideB : 0u, sB = offB >= 0 ? strideB : 0u, s1 = off1 >= 0 ? strideB : 0u,
                  s2 = off2 >= 0 ? strideB : 0u, s3 = off3 >= 0 ? strideB : 0u;
-  constexpr unsigned kES = (unsigned)sizeof(T);
+  constexpr unsigned kES = (unsigned)sizeof(RS);
   const unsigned bA = offA >= 0 ? rec0 + kES * offA : zoff, bB = offB >= 0 ? rec0 + kES * offB : zoff,
                  b1 = off1 >= 0 ? rec0 + kES * off1 : zoff, b2 = off2 >= 0 ? rec0 + kES * off2 : zoff,
                  b3 = off3 >= 0 ? rec0 + kES * off3 : zoff;
   const char* __restrict__ Eb = reinterpret_cast<const char*>(A.EXP) - (size_t)frontB;
   auto ldE = [&](unsigned off) __attribute__((always_inline)) -> double {
-    return (double)*reinterpret_cast<const T*>(Eb + off);
+    return (double)*reinterpret_cast<const RS*>(Eb + off);
   };
 
   struct Tiles {
@@ -701,7 +715,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
         const int e = i % R::KP, ib = (i / R::KP) % 4, sl = i / (4 * R::KP);
         const int bi = __shfl(b, ib * 4);  // instance of block ib (its lane r = 0, c = 0)
         const int on = __shfl(inst_on ? 1 : 0, ib * 4);
-        if (on) A.KD[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)bi) * R::KP + e] = (T)sKD[i];
+        if (on) ((RS*)A.KD)[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)bi) * RR::KP + e] = (RS)sKD[i];
       }
       k_top -= slot;
       slot = 0;
@@ -765,7 +779,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       dV1 = fma(KDc, G, dV1);
       // gains into the LDS block (lanes with nothing to store hit a junk slot)
       if (FUSED)
-        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = (T)KD;
+        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = (T)(RS)KD;  // as stored
       else
         sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
@@ -1119,7 +1133,9 @@ __global__ __launch_bounds__(kBlock) void k_conv_stats(DevArrays<T> A, const Pro
   for (int k = 0; k < A.N; ++k) {
     T u[R::mP], kd[R::KP];
     load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
-    load_rec<T, R::KP>(RECP(A.KD, k, R::KP), kd);
+    using RS = rec_scalar_t<T, M>;
+    using RR = Rec<RS, n, m>;
+    load_rec_as<T, RS, R::KP, RR::KP, m * n + m>(RECP((const RS*)A.KD, k, RR::KP), kd);
     T mx = T(0);
 #pragma unroll
     for (int i = 0; i < m; ++i) mx = max_(mx, abs_(kd[R::oD + i]) / (abs_(u[i]) + T(1)));
@@ -1214,7 +1230,9 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
         T mx = T(0);
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-          const T dv = sKD ? sKD[k * R::KP + R::oD + i] : RECP(A.KD, k, R::KP)[R::oD + i];
+          using RS = rec_scalar_t<T, M>;
+          const T dv = sKD ? sKD[k * R::KP + R::oD + i]
+                           : (T)RECP((const RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[R::oD + i];
           const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
           mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
         }
@@ -1354,9 +1372,11 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
       load_rec<T, R::mP>(sU + k * R::mP, uk);
       load_rec<T, R::KP>(sKD + k * R::KP, kd);
     } else {
+      using RS = rec_scalar_t<T, M>;
+      using RR = Rec<RS, n, m>;
       load_rec<T, R::nP>(RECP(A.X, k, R::nP), xk);
       load_rec<T, R::mP>(RECP(A.U, k, R::mP), uk);
-      load_rec<T, R::KP>(RECP(A.KD, k, R::KP), kd);
+      load_rec_as<T, RS, R::KP, RR::KP, m * n + m>(RECP((const RS*)A.KD, k, RR::KP), kd);
     }
     const T* K = kd + R::oK;
     const T* d = kd + R::oD;
@@ -1487,14 +1507,13 @@ struct FwdLds {  // element counts of one instance's staged block (16-byte align
   ALTRO_DEV int total() const { return nX + nU + nKD + 2 * padv(nR) + padv(nS); }
 };
 
-template <class T, class M, bool LDS>
-__global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const ProblemDesc* __restrict__ pd_global,
-                                                    const ProblemDesc pd_arg, DevOpts o, int mode, int all,
-                                                    int per_wave) {
-  // LDS variant: the problem description comes from the kernel arguments (scalar loads that the
-  // compiler can keep in SGPRs across the serial loop)
-  const ProblemDesc* pd = LDS ? &pd_arg : pd_global;
-  using Ctx = typename std::conditional<LDS, CtxL<T>, CtxG<T>>::type;
+// Single-wave forward pass that reads everything from global memory: the fallback when the staged block of
+// one instance exceeds the LDS, or line_search_max_iterations > 20 (rounds of 20 trials).
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const ProblemDesc* __restrict__ pd, DevOpts o,
+                                                    int mode, int all, int per_wave) {
+  using Ctx = CtxG<T>;
+  constexpr bool LDS = false;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1508,76 +1527,9 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   if (__ballot(valid) == 0ull) return;  // nothing to do for this wave (finished instances)
   const int b = valid ? b0 : 0;         // idle lanes shadow instance 0's loads but never store
 
-  // ---- phase 0: stage the shared pool and the instance's read-only inputs in LDS ----------------
   using R = Rec<T, n, m>;
-  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, Rec<T, n, m>::V};
-  T* sm = reinterpret_cast<T*>(smem_raw) + (grp < per_wave ? grp : 0) * L.total();
-  T* sX = sm;
-  T* sU = sX + L.nX;
-  T* sKD = sU + L.nU;
-  T* sLam = sKD + L.nKD;
-  T* sPen = sLam + L.rowsP();
-  T* sIp = sPen + L.rowsP();
-  T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
-  if (LDS) {
-    for (int i = lane; i < pd->npool; i += kBlock) sPool[i] = A.pool[i];
-    if (valid) {
-      using V = typename VecOf<T>::type;
-      constexpr int VN = R::V;
-      // records: 16-byte vector copies, 8 in flight per lane before the first LDS write
-      auto stage_rec = [&](T* dst, const T* src, int knots, int EP) {
-        const int per = EP / VN;
-        const int total = knots * per;
-        constexpr int kDepth = 8;
-        for (int i0 = t; i0 < total; i0 += LS * kDepth) {
-          V v[kDepth];
-#pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            int vi = i0 + j * LS;
-            vi = vi < total ? vi : total - 1;  // clamp: the load is unconditional, the store is not
-            const int k = vi / per, w = vi - k * per;
-            v[j] = *reinterpret_cast<const V*>(RECP(src, k, EP) + w * VN);
-          }
-#pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int vi = i0 + j * LS;
-            if (vi < total) *reinterpret_cast<V*>(dst + vi * VN) = v[j];
-          }
-        }
-      };
-      // rows / parameter slots: [row][b] scalars, 16 in flight per lane
-      auto stage_soa = [&](T* dst, const T* src, int cnt) {
-        constexpr int kDepth = 16;
-        for (int i0 = t; i0 < cnt; i0 += LS * kDepth) {
-          T v[kDepth];
-#pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int i = i0 + j * LS;
-            v[j] = (i < cnt) ? src[(unsigned)i * Bp + (unsigned)b] : T(0);
-          }
-#pragma unroll
-          for (int j = 0; j < kDepth; ++j) {
-            const int i = i0 + j * LS;
-            if (i < cnt) dst[i] = v[j];
-          }
-        }
-      };
-      stage_rec(sX, A.X, N + 1, R::nP);
-      stage_rec(sU, A.U, N, R::mP);
-      stage_rec(sKD, A.KD, N, R::KP);
-      stage_soa(sLam, A.lam, L.nR);
-      stage_soa(sPen, A.pen, L.nR);
-      stage_soa(sIp, A.ipool, L.nS);
-    }
-    __syncthreads();
-  }
-  Ctx C = [&]() {
-    if constexpr (LDS) {
-      return CtxL<T>(A, b, sPool, sIp, sLam, sPen);
-    } else {
-      return CtxG<T>(A, b);
-    }
-  }();
+  const T *sX = nullptr, *sU = nullptr, *sKD = nullptr;  // this variant reads from global memory
+  const CtxG<T> C(A, b);
   const T hh = T(pd->hstep);
 
   const double J0 = A.J0[b];
@@ -1730,7 +1682,7 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
   {
     const InstPre pre = load_inst_pre(A, b);
     forward_phase3<T, M>(A, pd, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
-                       (double)viol, LDS ? sKD : (const T*)nullptr, LDS ? sU : (const T*)nullptr, pre);
+                       (double)viol, (const T*)nullptr, (const T*)nullptr, pre);
   }
 }
 
@@ -2063,7 +2015,16 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
           const int i = i0 + j * kStride;
           vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
           vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
-          if (with_kd) vk[g][j] = ldrec(A.KD, perK, cK, R::KP, i);
+          if (with_kd) {
+            // gain record: stored as RS, staged as T (element offsets coincide, see load_rec_as)
+            using RS = rec_scalar_t<T, M>;
+            int vi = i < cK ? i : cK - 1;
+            const int k = vi / perK, w = vi - k * perK;
+            const RS* src = RECP((const RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP)) + w * VN;
+            T* e = reinterpret_cast<T*>(&vk[g][j]);
+#pragma unroll
+            for (int q = 0; q < VN; ++q) e[q] = (T)src[q];
+          }
           sl[g][j] = cR > 0 ? SOA(A.lam, i < cR ? i : cR - 1) : T(0);
           sp[g][j] = cR > 0 ? SOA(A.pen, i < cR ? i : cR - 1) : T(0);
           si[g][j] = cS > 0 ? SOA(A.ipool, i < cS ? i : cS - 1) : T(0);
@@ -2430,7 +2391,9 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
       A.costs[(unsigned)k * Bp + (unsigned)b] = J;
       sCost[k] = J;
       if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
-      store_rec<T, R::EP>(RECP(A.EXP, k, R::EP), E);
+      using RS = rec_scalar_t<T, M>;
+      using RR = Rec<RS, n, m>;
+      store_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP((RS*)A.EXP, k, RR::EP), E);
     }
     toff = (toff + ((cnt + kBlock - 1) / kBlock) * kBlock) % nthreads;
   }
@@ -2570,7 +2533,8 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
   // the gains for the getters (nothing inside the sweep reads them from global memory)
   for (int i = tid; i < N * R::KP; i += kFwdWaves * kBlock) {
     const int k = i / R::KP, e = i - k * R::KP;
-    RECP(A.KD, k, R::KP)[e] = sKDf[i];
+    using RS = rec_scalar_t<T, M>;
+    if (e < (Rec<RS, M::n, M::m>::KP)) RECP((RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[e] = (RS)sKDf[i];
   }
   if (sweeps_out && tid == 0) {
     atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations
