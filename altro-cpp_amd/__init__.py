@@ -197,6 +197,10 @@ class BatchSolver:
     def reset_trajectory(self):
         self._call("reset_trajectory")
 
+    def reset_stats(self):
+        """solver.GetStats().Reset(): a bare iLQR solve accumulates iterations_total otherwise (quirk Q11)."""
+        self._call("reset_stats")
+
     # -- options (solver.GetOptions()) -------------------------------------------------------------
     def default_options(self):
         o = Options()

@@ -3,13 +3,15 @@
 // Records the problem definition exactly as the reference's altro::problem::Problem setters do,
 // creates the device engine lazily on the first compute call, and forwards every entry point.
 // No exception crosses the boundary; there is NO CPU fallback.
-#include <cmath>
-#include <cstring>
 #include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
 #include <memory>
-#include <thread>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 
 #include "altro_common.hpp"
 
@@ -22,13 +24,27 @@ struct altro_solver_s {
   bool uploaded = false;
   bool ilqr_mode = false;
   std::string err;
-  // asynchronous solve (altro_solve_al_async): one worker at a time
+  // Asynchronous solve (altro_solve_al_async): ONE worker thread per handle, created on first use and
+  // parked on a condition variable between solves.  While a solve is pending the handle only answers
+  // altro_solve_poll / altro_wait / altro_last_error: everything else returns ALTRO_NOT_READY, so a caller
+  // cannot change options, inputs or device buffers under the solve in flight.
   std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool job_posted = false, worker_exit = false;
   std::atomic<int> async_done{1};
   bool async_pending = false;
   altro_status async_status = ALTRO_OK;
+  std::string async_err;  // the worker's own error text, copied to err by altro_wait
   ~altro_solver_s() {
-    if (worker.joinable()) worker.join();
+    if (worker.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        worker_exit = true;
+      }
+      cv.notify_all();
+      worker.join();
+    }
   }
 };
 
@@ -121,8 +137,16 @@ altro_status Ensure(altro_handle h) {
   return st;
 }
 
+// true (and the error text set) while an asynchronous solve owns the handle
+bool Busy(altro_handle h) {
+  if (!h->async_pending) return false;
+  h->err = "an asynchronous solve is pending on this handle (call altro_wait first)";
+  return true;
+}
+
 template <class F>
 altro_status Forward(altro_handle h, F f) {
+  if (h && Busy(h)) return ALTRO_NOT_READY;
   altro_status st = Ensure(h);
   if (st != ALTRO_OK) return st;
   st = f(*h->engine);
@@ -150,9 +174,16 @@ altro_status altro_set_model(altro_handle h, int kind, const double* params, int
   return ALTRO_OK;
 }
 altro_status altro_set_uniform_step(altro_handle h, float hstep) {
-  if (!h) return ALTRO_INVALID_ARG;
-  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  if (!h || !(hstep > 0.0f)) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
+  // the step belongs to the trajectory (trajectory.hpp:122-130), not to the problem definition: it may
+  // change between solves, also after the device state exists
   h->spec.hstep = hstep;
+  if (h->uploaded) {
+    altro_status st = h->engine->SetStep(hstep);
+    if (st != ALTRO_OK) h->err = h->engine->LastError();
+    return st;
+  }
   return ALTRO_OK;
 }
 altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const double* Q, const double* R,
@@ -208,6 +239,7 @@ altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_e
 }
 altro_status altro_set_initial_state(altro_handle h, const double* x0, int per_instance) {
   if (!h || !x0) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
   const altro_desc& d = h->spec.desc;
   h->spec.x0.assign(x0, x0 + (size_t)d.n * (per_instance ? d.batch : 1));
   h->spec.x0_per_instance = per_instance;
@@ -216,6 +248,7 @@ altro_status altro_set_initial_state(altro_handle h, const double* x0, int per_i
 }
 altro_status altro_set_trajectory(altro_handle h, const double* X, const double* U, int per_instance) {
   if (!h) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
   const altro_desc& d = h->spec.desc;
   const size_t mult = per_instance ? d.batch : 1;
   h->spec.has_X = X != nullptr;
@@ -229,8 +262,12 @@ altro_status altro_set_trajectory(altro_handle h, const double* X, const double*
 altro_status altro_reset_trajectory(altro_handle h) {
   return Forward(h, [&](EngineBase& e) { return e.ResetTrajectory(); });
 }
+altro_status altro_reset_stats(altro_handle h) {
+  return Forward(h, [&](EngineBase& e) { return e.ResetStats(); });
+}
 altro_status altro_set_options(altro_handle h, const altro_options* o) {
   if (!h || !o) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
   h->opts = *o;
   return ALTRO_OK;
 }
@@ -241,12 +278,14 @@ altro_status altro_get_options(altro_handle h, altro_options* o) {
 }
 altro_status altro_set_penalty(altro_handle h, double rho) {
   if (!h || !(rho >= 0)) return ALTRO_INVALID_ARG;  // ALTRO_ASSERT(rho >= 0), constraint_values.hpp:80
+  if (Busy(h)) return ALTRO_NOT_READY;
   h->spec.penalty = rho;
   if (h->uploaded) return Forward(h, [&](EngineBase& e) { return e.SetPenalty(rho); });
   return ALTRO_OK;
 }
 altro_status altro_set_penalty_scaling(altro_handle h, double phi) {
   if (!h || !(phi >= 1)) return ALTRO_INVALID_ARG;  // ALTRO_ASSERT(phi >= 1), constraint_values.hpp:85
+  if (Busy(h)) return ALTRO_NOT_READY;
   h->spec.phi = phi;
   if (h->uploaded) return Forward(h, [&](EngineBase& e) { return e.SetPenaltyScaling(phi); });
   return ALTRO_OK;
@@ -262,17 +301,34 @@ altro_status altro_solve_ilqr(altro_handle h) {
 }
 altro_status altro_solve_al_async(altro_handle h) {
   if (!h) return ALTRO_INVALID_ARG;
-  if (h->async_pending) {
-    h->err = "an asynchronous solve is already pending (call altro_wait first)";
-    return ALTRO_NOT_READY;
+  if (Busy(h)) return ALTRO_NOT_READY;
+  // create the device state on the caller's thread: definition errors are reported here, synchronously
+  altro_status st = Ensure(h);
+  if (st != ALTRO_OK) return st;
+  h->ilqr_mode = false;
+  if (!h->worker.joinable()) {
+    h->worker = std::thread([h]() {
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(h->mu);
+          h->cv.wait(lk, [h]() { return h->job_posted || h->worker_exit; });
+          if (h->worker_exit) return;
+          h->job_posted = false;
+        }
+        // the engine and the options are frozen while async_pending is set (Busy() guards every setter)
+        h->async_status = h->engine->SolveAL(h->opts);
+        if (h->async_status != ALTRO_OK) h->async_err = h->engine->LastError();
+        h->async_done.store(1, std::memory_order_release);
+      }
+    });
   }
-  if (h->worker.joinable()) h->worker.join();
   h->async_pending = true;
   h->async_done.store(0);
-  h->worker = std::thread([h]() {
-    h->async_status = altro_solve_al(h);
-    h->async_done.store(1, std::memory_order_release);
-  });
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->job_posted = true;
+  }
+  h->cv.notify_one();
   return ALTRO_OK;
 }
 altro_status altro_solve_poll(altro_handle h, int* done) {
@@ -286,8 +342,9 @@ altro_status altro_wait(altro_handle h) {
     h->err = "no asynchronous solve is pending";
     return ALTRO_NOT_READY;
   }
-  if (h->worker.joinable()) h->worker.join();
+  while (!h->async_done.load(std::memory_order_acquire)) std::this_thread::yield();
   h->async_pending = false;
+  if (h->async_status != ALTRO_OK) h->err = h->async_err;
   return h->async_status;
 }
 altro_status altro_al_init(altro_handle h) { return Forward(h, [&](EngineBase& e) { return e.AlInit(h->opts); }); }
@@ -339,11 +396,11 @@ altro_status altro_get_knot_costs(altro_handle h, double* costs) {
   return Forward(h, [&](EngineBase& e) { return e.GetKnotCosts(costs); });
 }
 int altro_num_constraints(altro_handle h) {
-  if (Ensure(h) != ALTRO_OK) return -1;
+  if (!h || Busy(h) || Ensure(h) != ALTRO_OK) return -1;
   return h->engine->NumRows();
 }
 int altro_num_constraints_at(altro_handle h, int k) {
-  if (Ensure(h) != ALTRO_OK) return -1;
+  if (!h || Busy(h) || Ensure(h) != ALTRO_OK) return -1;
   return h->engine->NumRowsAt(k);
 }
 altro_status altro_get_duals(altro_handle h, double* lam) {
@@ -374,8 +431,12 @@ altro_status altro_set_record_history(altro_handle h, int capacity) {
   return Forward(h, [&](EngineBase& e) { return e.SetRecordHistory(capacity); });
 }
 int altro_get_history(altro_handle h, int instance, int field, double* out, int cap) {
-  if (Ensure(h) != ALTRO_OK || !out) return -1;
+  if (!h || !out || Busy(h) || Ensure(h) != ALTRO_OK) return -1;
   return h->engine->GetHistory(instance, field, out, cap);
+}
+altro_status altro_device_info(altro_handle h, char* name, int name_len, int* cu_count) {
+  if (!h) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.DeviceInfo(name, name_len, cu_count); });
 }
 altro_status altro_pack_results_device(altro_handle h, void* dst_device) {
   if (!dst_device) return ALTRO_INVALID_ARG;

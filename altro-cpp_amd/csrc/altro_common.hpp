@@ -113,7 +113,9 @@ class EngineBase {
   virtual altro_status Upload(const ProblemSpec& spec, std::string* err) = 0;
   virtual altro_status SetInitialState(const ProblemSpec& spec, std::string* err) = 0;
   virtual altro_status SetTrajectory(const ProblemSpec& spec, std::string* err) = 0;
+  virtual altro_status SetStep(float hstep) = 0;
   virtual altro_status ResetTrajectory() = 0;
+  virtual altro_status ResetStats() = 0;
   virtual altro_status SetPenalty(double rho) = 0;
   virtual altro_status SetPenaltyScaling(double phi) = 0;
   virtual altro_status SolveAL(const altro_options& o) = 0;
@@ -146,6 +148,7 @@ class EngineBase {
   virtual altro_status SetRecordHistory(int capacity) = 0;
   virtual int GetHistory(int instance, int field, double* out, int cap) = 0;
   virtual altro_status PackResultsDevice(void* dst) = 0;
+  virtual altro_status DeviceInfo(char* name, int name_len, int* cu_count) = 0;
   virtual const char* LastError() = 0;
 };
 

@@ -114,10 +114,26 @@ class Engine final : public EngineBase {
     return st;
   }
 
+  // The integration step belongs to the trajectory (trajectory.hpp:122-130), which the caller may replace
+  // between solves: it can be set at any time, and the calls that integrate refuse to run without it.
+  altro_status SetStep(float hstep) override {
+    if (!uploaded_) return ALTRO_OK;  // Upload takes it from the spec
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    pd_.hstep = hstep;
+    ALTRO_HIP_CHECK(hipMemcpy(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
+    return ALTRO_OK;
+  }
   altro_status ResetTrajectory() override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     ALTRO_HIP_CHECK(hipMemcpyAsync(A_.U, U_init_, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    return ALTRO_OK;
+  }
+  altro_status ResetStats() override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    hipLaunchKernelGGL(k_reset_stats<T>, GridB(), dim3(kBlock), 0, stream_, A_);
     return ALTRO_OK;
   }
   altro_status SetPenalty(double rho) override {
@@ -150,6 +166,7 @@ class Engine final : public EngineBase {
     return Sync();
   }
   altro_status Rollout(const altro_options&) override {
+    if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     return Sync();
@@ -164,6 +181,7 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   altro_status UpdateExpansions(const altro_options&) override {
+    if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     return Sync();
@@ -174,6 +192,7 @@ class Engine final : public EngineBase {
     return Sync();
   }
   altro_status ForwardPass(const altro_options& o) override {
+    if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     LaunchForward(A_, ToDevOpts(o), (int)kFwdStepOnly, 1, B_);
     return Sync();
@@ -274,6 +293,10 @@ class Engine final : public EngineBase {
     if (R == 0) return ALTRO_OK;
     std::vector<T> h((size_t)R * Bp_);
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    {
+      altro_status st = Sync();
+      if (st != ALTRO_OK) return st;
+    }
     ALTRO_HIP_CHECK(hipMemcpy(h.data(), src, h.size() * sizeof(T), hipMemcpyDeviceToHost));
     for (int b = 0; b < B_; ++b)
       for (int r = 0; r < R; ++r) out[(size_t)b * R + r] = (double)h[(size_t)r * Bp_ + b];
@@ -286,11 +309,19 @@ class Engine final : public EngineBase {
     for (int b = 0; b < B_; ++b)
       for (int r = 0; r < R; ++r) h[(size_t)r * Bp_ + b] = T(lam[(size_t)b * R + r]);
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    {
+      altro_status st = Sync();
+      if (st != ALTRO_OK) return st;
+    }
     ALTRO_HIP_CHECK(hipMemcpy(A_.lam, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
   altro_status GetStats(altro_stats* st, bool ilqr_mode) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    {
+      altro_status sst = Sync();
+      if (sst != ALTRO_OK) return sst;
+    }
     std::vector<double> f((size_t)kNumScalarT * Bp_);
     std::vector<int> iv((size_t)kNumScalarI * Bp_);
     ALTRO_HIP_CHECK(hipMemcpy(f.data(), d_scalarT_, f.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -320,6 +351,8 @@ class Engine final : public EngineBase {
   altro_status GetTiming(altro_timing* t) override {
     if (timing_.instance_iterations < 0 && uploaded_) {
       ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+      altro_status sst = Sync();
+      if (sst != ALTRO_OK) return sst;
       std::vector<int> it(Bp_);
       ALTRO_HIP_CHECK(hipMemcpy(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
       long long tot = 0;
@@ -349,19 +382,27 @@ class Engine final : public EngineBase {
   int GetHistory(int instance, int field, double* out, int cap) override {
     if (!A_.hist || instance < 0 || instance >= B_ || field < 0 || field >= kHistFields) return -1;
     if (hipSetDevice(desc_.device_id) != hipSuccess) return -1;
+    if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
     int len = 0;
     if (hipMemcpy(&len, A_.hist_len + instance, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     // the reference's vectors also hold the row opened by the last NewIteration: a copy of the last
-    int stored = std::min(len, A_.hist_cap);
-    int cnt = 0;
-    double v = 0.0;
-    for (int i = 0; i < stored && cnt < cap; ++i) {
-      if (hipMemcpy(&v, A_.hist + ((size_t)field * A_.hist_cap + i) * Bp_ + instance, sizeof(double),
-                    hipMemcpyDeviceToHost) != hipSuccess)
-        return -1;
-      out[cnt++] = v;
-    }
+    const int cnt = std::min(std::min(len, A_.hist_cap), cap);
+    if (cnt <= 0) return 0;
+    // column `instance` of the [field][row][Bp] block: one strided copy
+    if (hipMemcpy2D(out, sizeof(double), A_.hist + (size_t)field * A_.hist_cap * Bp_ + instance, (size_t)Bp_ * sizeof(double),
+                    sizeof(double), (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess)
+      return -1;
     return cnt;
+  }
+  altro_status DeviceInfo(char* name, int name_len, int* cu_count) override {
+    hipDeviceProp_t p;
+    ALTRO_HIP_CHECK(hipGetDeviceProperties(&p, desc_.device_id));
+    if (name && name_len > 0) {
+      std::strncpy(name, p.name, name_len - 1);
+      name[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    return ALTRO_OK;
   }
   altro_status PackResultsDevice(void* dst) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
@@ -424,6 +465,11 @@ class Engine final : public EngineBase {
       hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, stream_, A, d_pd_, d, mode, all, fwd_per_wave_);
     }
   }
+  bool StepOk() {
+    if (pd_.hstep > 0.0f) return true;
+    err_ = "the integration step is not set (altro_set_uniform_step / Trajectory::SetUniformStep)";
+    return false;
+  }
   altro_status Sync() {
     ALTRO_HIP_CHECK(hipGetLastError());
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -484,6 +530,10 @@ class Engine final : public EngineBase {
   altro_status SetInitialStateImpl(const ProblemSpec& s) {
     if (!uploaded_) return ALTRO_OK;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    {
+      altro_status st = Sync();
+      if (st != ALTRO_OK) return st;
+    }
     // x0 records [b][nP]: one "knot" with Bp instances
     if (s.x0.empty()) return UploadRec(A_.x0, 1, R::nP, n, nullptr, false);
     return UploadRec(A_.x0, 1, R::nP, n, s.x0.data(), s.x0_per_instance != 0);
@@ -491,6 +541,10 @@ class Engine final : public EngineBase {
   altro_status SetTrajectoryImpl(const ProblemSpec& s) {
     if (!uploaded_) return ALTRO_OK;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    {
+      altro_status st0 = Sync();  // ResetTrajectory may still be copying on the (non-blocking) stream
+      if (st0 != ALTRO_OK) return st0;
+    }
     altro_status st = UploadRec(A_.X, N_ + 1, R::nP, n, s.has_X ? s.X.data() : nullptr, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
     st = UploadRec(A_.U, N_, R::mP, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
@@ -902,6 +956,7 @@ class Engine final : public EngineBase {
   }
 
   altro_status Solve(const altro_options& o, int mode) {
+    if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     const auto t0 = std::chrono::steady_clock::now();
     DevOpts d = ToDevOpts(o);

@@ -987,6 +987,23 @@ ALTRO_DEV void begin_inner_solve(const DevArrays<T>& A, const DevOpts& o, int b)
   A.need_init_cost[b] = 1;  // stats_.initial_cost = Cost() is taken from the next expansion step
 }
 
+// SolverStats::Reset (solver_stats.cpp:31-45)
+template <class T>
+ALTRO_DEV void reset_stats(const DevArrays<T>& A, int b) {
+  A.initial_cost[b] = 0.0;
+  A.it_inner[b] = A.it_outer[b] = A.it_total[b] = 0;
+  A.cost_cur[b] = A.cost_prev[b] = A.dJ[b] = A.grad[b] = A.viol[b] = 0.0;
+  A.alpha[b] = A.z[b] = A.reg_log[b] = 0.0;
+  if (A.hist) A.hist_len[b] = 0;
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_reset_stats(DevArrays<T> A) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= A.B) return;
+  reset_stats(A, b);
+  A.penmax[b] = 0.0;
+}
+
 // AugmentedLagrangianiLQR::Init (al_solver.hpp:287-302) without the (unobservable) initial
 // MaxViolation log, + activation of every instance.
 template <class T>
@@ -994,11 +1011,7 @@ __global__ __launch_bounds__(kBlock) void k_al_init(DevArrays<T> A, const Proble
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= A.B) return;
   rows_set(A, pd, b, o.reset_duals != 0, o.initial_penalty > 0, T(o.initial_penalty));  // quirk Q8
-  // stats.Reset()
-  A.initial_cost[b] = 0.0;
-  A.it_inner[b] = A.it_outer[b] = A.it_total[b] = 0;
-  A.cost_cur[b] = A.cost_prev[b] = A.dJ[b] = A.grad[b] = A.viol[b] = 0.0;
-  A.alpha[b] = A.z[b] = A.reg_log[b] = 0.0;
+  reset_stats(A, b);  // stats.Reset()
   // stats.Log("pen", GetMaxPenalty()) of Init (al_solver.hpp:301)
   if (o.initial_penalty > 0) {
     A.penmax[b] = o.initial_penalty;
@@ -1007,7 +1020,6 @@ __global__ __launch_bounds__(kBlock) void k_al_init(DevArrays<T> A, const Proble
     rows_viol_pen(A, pd, b, &v, &pm);
     A.penmax[b] = (double)pm;
   }
-  if (A.hist) A.hist_len[b] = 0;
   A.status_al[b] = ALTRO_UNSOLVED;
 }
 // finishing touch of AL Init for the step-level API: log viol (after a cost evaluation) and pen

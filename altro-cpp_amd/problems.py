@@ -162,37 +162,48 @@ def batch_turn90_goals(batch, seed=SEED_BASE + 3):
     return xf
 
 
-def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3):
-    """BASELINE config 3: kTurn90 with per-instance goal xf = (1.5+dx, 1.5+dy, pi/2+dth)."""
-    return unicycle_turn90(make, batch=batch, N=N, dtype=dtype, xf=batch_turn90_goals(batch, seed))
+def _block(arr, shard):
+    """Rows [lo, hi) of a per-instance array of the GLOBAL batch (one rank's shard), or all of it."""
+    return arr if shard is None else arr[shard[0]:shard[1]]
 
 
-def batch_three_obstacles(make, batch, N=100, dtype=F32, seed=SEED_BASE + 4):
+def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3, shard=None):
+    """BASELINE config 3: kTurn90 with per-instance goal xf = (1.5+dx, 1.5+dy, pi/2+dth).
+
+    ``batch`` is the size of the (global) seeded batch; ``shard = (lo, hi)`` builds only that block of it."""
+    xf = _block(batch_turn90_goals(batch, seed), shard)
+    return unicycle_turn90(make, batch=len(xf), N=N, dtype=dtype, xf=xf)
+
+
+def batch_three_obstacles(make, batch, N=100, dtype=F32, seed=SEED_BASE + 4, shard=None):
     """BASELINE config 4: kThreeObstacles with per-instance obstacle centres jittered +-0.1."""
     rng = np.random.default_rng(seed)
     circles = np.tile(THREE_OBSTACLE_CIRCLES, (batch, 1, 1))
     if batch > 1:
         circles[1:, :, :2] += rng.uniform(-0.1, 0.1, (batch - 1, 3, 2))
-    return unicycle_three_obstacles(make, batch=batch, N=N, dtype=dtype, circles=circles)
+    circles = _block(circles, shard)
+    return unicycle_three_obstacles(make, batch=len(circles), N=N, dtype=dtype, circles=circles)
 
 
-def batch_triple_integrator(make, batch, N=50, dtype=F64, seed=SEED_BASE + 2):
+def batch_triple_integrator(make, batch, N=50, dtype=F64, seed=SEED_BASE + 2, shard=None):
     """BASELINE config 2: unconstrained triple integrator, 51 knots, xf[0:2] ~ U([0.5,2]^2)."""
     rng = np.random.default_rng(seed)
     xf = np.zeros((batch, 6))
     xf[:, 0], xf[:, 1] = 1.0, 2.0
     if batch > 1:
         xf[1:, :2] = rng.uniform(0.5, 2.0, (batch - 1, 2))
-    return triple_integrator(make, batch=batch, N=N, dtype=dtype, xf=xf)
+    xf = _block(xf, shard)
+    return triple_integrator(make, batch=len(xf), N=N, dtype=dtype, xf=xf)
 
 
-def batch_quadrotor12(make, batch, N=200, dtype=F32, seed=SEED_BASE + 5):
+def batch_quadrotor12(make, batch, N=200, dtype=F32, seed=SEED_BASE + 5, shard=None):
     """BASELINE config 5: hover-to-hover, xf_p ~ U([-2,2]^3)."""
     rng = np.random.default_rng(seed)
     pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
     if batch > 1:
         pos[1:] = rng.uniform(-2.0, 2.0, (batch - 1, 3))
-    return quadrotor12(make, batch=batch, N=N, dtype=dtype, xf_pos=pos)
+    pos = _block(pos, shard)
+    return quadrotor12(make, batch=len(pos), N=N, dtype=dtype, xf_pos=pos)
 
 
 def make_hip(n, m, N, batch, dtype, device_id=0):

@@ -6,8 +6,13 @@ owns a contiguous block of instances, solves it with its own handle on its own d
 collective is ONE all_gather of the 32-byte per-instance result record {cost, violation,
 iterations_total, status} after the solve (RCCL over xGMI on GPUs: backend "nccl"; gloo on CPU for
 the tests).  No all-reduce, no per-iteration communication.
+
+``pack_and_gather`` is the one code path of that exchange: bench.py calls it on GPU tensors with RCCL,
+tests/test_sharding_gloo.py calls the very same function on CPU tensors with gloo.
 """
 import numpy as np
+
+RECORD_FIELDS = ("cost", "violation", "iterations_total", "status")
 
 
 def shard_range(total, world, rank):
@@ -20,25 +25,24 @@ def shard_range(total, world, rank):
 def result_records(stats):
     """[B][4] float64 records {cost, violation, iterations_total, status} from a get_stats() array."""
     out = np.empty((len(stats), 4), dtype=np.float64)
-    out[:, 0] = stats["cost"]
-    out[:, 1] = stats["violation"]
-    out[:, 2] = stats["iterations_total"]
-    out[:, 3] = stats["status"]
+    for i, f in enumerate(RECORD_FIELDS):
+        out[:, i] = stats[f]
     return out
 
 
-def gather_records(local, dist=None, device=None):
-    """all_gather of equally-sized [b][4] record blocks -> [world*b][4] (torch tensors).
+def pack_and_gather(solver, packed, gathered=None, dist=None):
+    """The result exchange of one step.
 
-    `local` is a torch tensor on the communication device (cuda for nccl/RCCL, cpu for gloo)."""
-    import torch
-
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
-    world = dist.get_world_size()
-    out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    The solver writes its [b][4] fp64 result records straight into ``packed`` -- memory of the rank's
+    own device (a torch tensor on cuda:<local_rank>; host memory when the CPU oracle stands in for the
+    device in the tests) -- and, with more than one rank, ONE ``all_gather_into_tensor`` assembles
+    ``gathered`` = [world * b][4] on every rank.  Equal shard sizes (weak scaling); uneven shards go
+    through ``gather_variable``.  Returns the tensor that holds the global records."""
+    solver.pack_results_device(packed.data_ptr())
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_gather_into_tensor(gathered, packed)
+        return gathered
+    return packed
 
 
 def gather_variable(local_np, dist):

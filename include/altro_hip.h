@@ -14,7 +14,8 @@
  *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an
  *    altro_status; no exception crosses the boundary.  altro_last_error() gives the text.
  *  - All host arrays exchanged over the ABI are IEEE fp64, caller-owned, and are copied during
- *    the call.  The device computes in the dtype chosen at altro_create (fp64 or fp32).
+ *    the call.  The device computes in fp64; the dtype chosen at altro_create selects how the two
+ *    bulk per-knot records are STORED in device memory (see altro_dtype).
  *  - NEW relative to the reference: a batch of B independent problem instances per handle.
  *    Host layout is instance-major, then knot point, then Eigen column-major matrix:
  *    X[b][k][i] (k = 0..N), U[b][k][j] (k = 0..N-1), K[b][k][col][row] with K being m x n
@@ -48,7 +49,14 @@ typedef enum altro_status {
   ALTRO_UNSUPPORTED = 4
 } altro_status;
 
-/* Arithmetic type used on the device. */
+/* Storage precision on the device.
+ *   ALTRO_F64: everything in fp64.
+ *   ALTRO_F32: the expansion records ([A|B], lxx, lxu, luu, lx, lu) and the gain records (K, d) -- 3/4 of
+ *     the elements a knot point moves per iteration -- are stored in fp32; the trajectory, the multipliers,
+ *     every cost and every arithmetic operation (Riccati recursion, rollouts, line search, AL updates) stay
+ *     fp64.  Iteration counts and statuses follow the fp64 schedule; states agree with the fp64 solve to
+ *     ~1e-6 (stated tolerance 1e-3).  An all-fp32 solver loses 10-15 points of solved fraction on the
+ *     obstacle problems (scripts/cpu_fp32_study.py), which is why this build has none. */
 typedef enum altro_dtype { ALTRO_F64 = 0, ALTRO_F32 = 1 } altro_dtype;
 
 /* Closed registry of continuous-time models, all discretised with RK4
@@ -171,7 +179,9 @@ void altro_default_options(altro_options* opts);
  * params: TRIPLE_INTEGRATOR -> {dof}; UNICYCLE -> none; QUADROTOR12 -> none. */
 altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams);
 
-/* Trajectory::SetUniformStep (trajectory.hpp:122-130). */
+/* Trajectory::SetUniformStep (trajectory.hpp:122-130).  hstep > 0.  Belongs to the trajectory, not to the
+ * problem definition: may be called at any time (also between solves).  Calls that integrate (rollout,
+ * expansions, forward pass, solves) return ALTRO_NOT_READY until a step has been set. */
 altro_status altro_set_uniform_step(altro_handle h, float hstep);
 
 /* Problem::SetCostFunction(QuadraticCost::LQRCost(Q,R,xref,uref,terminal), k) for
@@ -205,6 +215,13 @@ altro_status altro_set_trajectory(altro_handle h, const double* X, const double*
  * without a host round trip. */
 altro_status altro_reset_trajectory(altro_handle h);
 
+/* solver.GetStats().Reset() (solver_stats.cpp:31-45): clears the iteration counters and the logged rows.
+ * AugmentedLagrangianiLQR::Solve does this itself (al_solver.hpp:298); a bare iLQR::Solve does NOT, so
+ * iterations_total -- and with it the max_iterations_total cap -- accumulates over repeated altro_solve_ilqr
+ * calls exactly as in the reference (ilqr.hpp:284-316) unless the caller resets.  Asynchronous on the
+ * handle's stream, like altro_reset_trajectory. */
+altro_status altro_reset_stats(altro_handle h);
+
 /* solver.GetOptions() (al_solver.hpp:44, ilqr.hpp:161). */
 altro_status altro_set_options(altro_handle h, const altro_options* opts);
 altro_status altro_get_options(altro_handle h, altro_options* opts);
@@ -222,8 +239,9 @@ altro_status altro_solve_ilqr(altro_handle h);
 
 /* Non-blocking variant of altro_solve_al for the MPC pattern the reference is designed for
  * (docs/Overview.dox:48-54; warm start: al_solver.hpp:292-297): the solve runs on a worker thread of
- * the library while the caller prepares the next problem.  Between altro_solve_al_async and
- * altro_wait only altro_solve_poll, altro_wait and altro_last_error may be called on the handle.
+ * the library (one per handle, parked between solves) while the caller prepares the next problem.
+ * Between altro_solve_al_async and altro_wait only altro_solve_poll, altro_wait and altro_last_error
+ * answer; every other call on the handle returns ALTRO_NOT_READY without touching the solve in flight.
  * altro_solve_poll sets *done to 0/1 without blocking; altro_wait blocks and returns the status the
  * synchronous call would have returned (ALTRO_NOT_READY if no asynchronous solve is pending). */
 altro_status altro_solve_al_async(altro_handle h);

@@ -243,8 +243,14 @@ struct Instance final : SolverBase {
   // float at the points where the device stores them.
   bool round_records = false;
   void RoundRec(T* v, int count) const {
+    // (the empty asm keeps g++ 11 -O3 from vectorising this loop: its 4-wide epilogue drops the
+    // double -> float -> double conversion and leaves elements 8..11 of a 15-element record unrounded)
     if (round_records)
-      for (int i = 0; i < count; ++i) v[i] = (T)(float)v[i];
+      for (int i = 0; i < count; ++i) {
+        float f = (float)v[i];
+        asm volatile("" : "+x"(f));
+        v[i] = (T)f;
+      }
   }
 
   Instance(int N_, const Model& mdl) : model(mdl), N(N_) {
@@ -1351,6 +1357,21 @@ altro_status oracle_reset_trajectory(oracle_handle h) {
   }
   return ALTRO_OK;
 }
+altro_status oracle_reset_stats(oracle_handle h) {  // solver.GetStats().Reset(), solver_stats.cpp:31-45
+  return ForAll(h, [&](SolverBase& s, int) { s.RawStats().Reset(); });
+}
+// host-memory counterpart of altro_pack_results_device (the gloo tests gather CPU tensors)
+altro_status oracle_pack_results_device(oracle_handle h, void* dst) {
+  double* out = static_cast<double*>(dst);
+  return ForAll(h, [&](SolverBase& s, int b) {
+    altro_stats st;
+    s.GetStats(&st);
+    out[4 * (size_t)b + 0] = st.cost;
+    out[4 * (size_t)b + 1] = st.violation;
+    out[4 * (size_t)b + 2] = (double)st.iterations_total;
+    out[4 * (size_t)b + 3] = (double)(h->ilqr_mode ? st.status_ilqr : st.status);
+  });
+}
 altro_status oracle_set_options(oracle_handle h, const altro_options* o) {
   h->opts = *o;
   for (auto& I : h->inst) I->opts = *o;
@@ -1388,6 +1409,20 @@ altro_status oracle_bench_al(oracle_handle h, int reps) {
     for (int r = 0; r < reps; ++r) {
       s.SetTrajectory(Xb, Ub);
       s.SolveAL();
+    }
+  });
+}
+// the same for a bare iLQR solve (BASELINE configs[1]); the statistics are reset between the repetitions
+altro_status oracle_bench_ilqr(oracle_handle h, int reps) {
+  h->ilqr_mode = true;
+  const altro_desc& D = h->desc;
+  return ForAll(h, [&](SolverBase& s, int b) {
+    const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
+    const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
+    for (int r = 0; r < reps; ++r) {
+      s.SetTrajectory(Xb, Ub);
+      s.RawStats().Reset();
+      s.SolveILQR();
     }
   });
 }

@@ -218,12 +218,56 @@ def test_triple_integrator_constrained(P, oracle_make, hip_make):
     assert np.allclose(U[0, 0], [100, 200]) and np.allclose(U[0, -1], [100, 200])
 
 
-def test_config5_quadrotor_fp64(P, A, oracle_make, hip_make):
-    o, g = both(P, P.batch_quadrotor12, oracle_make, hip_make, batch=16, dtype=A.F64)
-    o.solve(); g.solve()
-    # n=12, N=200 Riccati recursion with Qf/Q = 5e5: rounding differences are amplified by the
-    # conditioning of P; iteration counts and statuses still match exactly
-    _compare_full(o, g, xtol=(1e-5, 1e-6), gtol=1e-3)
+def _config5_sensitivity(P, A, oracle_make, oracle_lib, batch):
+    """How far the fp64 ORACLE itself moves when the goals of the config-5 batch are perturbed by one ulp:
+    the 12-state model has Qf/Q = 5e5 over 200 knots and stops after ~4 iterations at the default (loose)
+    cost tolerance, so rounding-level differences in the first iterate are amplified ~1e10-fold (dU ~ 1e-5,
+    dK ~ 3e-3 norm-wise, dX ~ 5e-7).  Returns the oracle solve and the max-norm spread of X, U, K, d over
+    three perturbed solves: the yardstick the GPU is compared against, instead of an asserted tolerance."""
+    import ctypes
+    rng = np.random.default_rng(P.SEED_BASE + 5)
+    pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
+    if batch > 1:
+        pos[1:] = rng.uniform(-2.0, 2.0, (batch - 1, 3))
+
+    def run(xf_pos):
+        s = P.quadrotor12(oracle_make, batch=batch, dtype=A.F64, xf_pos=xf_pos)
+        oracle_lib.oracle_set_threads(s._h, ctypes.c_int(len(os.sched_getaffinity(0))))
+        s.solve()
+        return s, s.get_trajectory(), s.get_gains()
+    o, (X0, U0), (K0, d0) = run(pos)
+    spread = dict(X=0.0, U=0.0, K=0.0, d=0.0)
+    prng = np.random.default_rng(1)
+    for _ in range(3):
+        _, (X1, U1), (K1, d1) = run(pos * (1.0 + prng.choice([-1.0, 1.0], pos.shape) * 2.2e-16))
+        spread["X"] = max(spread["X"], np.abs(X1 - X0).max())
+        spread["U"] = max(spread["U"], np.abs(U1 - U0).max())
+        spread["K"] = max(spread["K"], (np.abs(K1 - K0).max(axis=(1, 2, 3)) / np.abs(K0).max(axis=(1, 2, 3))).max())
+        spread["d"] = max(spread["d"], np.abs(d1 - d0).max())
+    return o, spread
+
+
+def _config5_against_oracle(P, A, oracle_make, hip_make, oracle_lib, batch):
+    o, spread = _config5_sensitivity(P, A, oracle_make, oracle_lib, batch)
+    g = P.batch_quadrotor12(hip_make, batch=batch, dtype=A.F64)
+    g.solve()
+    so, sg = o.get_stats(), g.get_stats()
+    for f in ("status", "iterations_total", "iterations_outer", "iterations_inner"):
+        assert (so[f] == sg[f]).all(), f   # the schedule is exact
+    assert (so["status"] == 0).mean() > 0.99
+    (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
+    (Ko, do), (Kg, dg) = o.get_gains(), g.get_gains()
+    err = dict(X=np.abs(Xg - Xo).max(), U=np.abs(Ug - Uo).max(), d=np.abs(dg - do).max(),
+               K=(np.abs(Kg - Ko).max(axis=(1, 2, 3)) / np.abs(Ko).max(axis=(1, 2, 3))).max())
+    print("config 5 fp64: GPU-vs-oracle error", {k: f"{v:.2e}" for k, v in err.items()},
+          "oracle's own 1-ulp sensitivity", {k: f"{v:.2e}" for k, v in spread.items()})
+    for k in err:  # the GPU differs from the oracle by no more than the oracle differs from itself
+        assert err[k] <= 4.0 * spread[k] + 1e-12, (k, err[k], spread[k])
+    assert np.allclose(sg["cost"], so["cost"], rtol=1e-7)
+
+
+def test_config5_quadrotor_fp64(P, A, oracle_make, hip_make, oracle_lib):
+    _config5_against_oracle(P, A, oracle_make, hip_make, oracle_lib, 16)
 
 
 def test_config2_full_batch_against_oracle(P, A, oracle_make, hip_make):
@@ -236,14 +280,7 @@ def test_config2_full_batch_against_oracle(P, A, oracle_make, hip_make):
 
 def test_config5_full_batch_fp64_against_oracle(P, A, oracle_make, hip_make, oracle_lib):
     """BASELINE configs[4] at full size in fp64: 1024 x 12-state model, 201 knots, full AL loop."""
-    import ctypes
-    o = P.batch_quadrotor12(oracle_make, batch=1024, dtype=A.F64)
-    oracle_lib.oracle_set_threads(o._h, ctypes.c_int(len(os.sched_getaffinity(0))))
-    o.solve()
-    g = P.batch_quadrotor12(hip_make, batch=1024, dtype=A.F64)
-    g.solve()
-    so, _ = _compare_full(o, g, xtol=(1e-5, 1e-6), gtol=1e-3)
-    assert (so["status"] == 0).mean() > 0.99
+    _config5_against_oracle(P, A, oracle_make, hip_make, oracle_lib, 1024)
 
 
 def test_full_batch_properties(P, A, hip_make):

@@ -27,13 +27,20 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 total = int(sys.argv[2])
 make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d, _lib=lib, _prefix="oracle_")
-# global synthetic batch, identical on every rank; each rank keeps its block of goals
-rng_xf = P.batch_turn90_goals(total)
-lo, hi = S.shard_range(total, world, rank)
-s = P.unicycle_turn90(make, batch=hi - lo, xf=rng_xf[lo:hi])
+# global seeded batch; each rank builds only its block -- exactly what bench.py does
+shard = S.shard_range(total, world, rank)
+s = P.batch_turn90(make, batch=total, shard=shard)
 s.solve()
-rec = S.result_records(s.get_stats())
-allrec = S.gather_variable(rec, dist)
+if total % world == 0:
+    # equal shards: the result exchange of bench.py's step(), same function, gloo instead of RCCL and host
+    # memory instead of HBM (the oracle's pack_results_device writes to a host pointer)
+    b = shard[1] - shard[0]
+    packed = torch.empty((b, 4), dtype=torch.float64)
+    gathered = torch.empty((world * b, 4), dtype=torch.float64)
+    allrec = S.pack_and_gather(s, packed, gathered, dist).numpy()
+    assert np.array_equal(packed.numpy(), S.result_records(s.get_stats()))
+else:
+    allrec = S.gather_variable(S.result_records(s.get_stats()), dist)
 if rank == 0:
     np.save(sys.argv[3], allrec)
 dist.barrier()
@@ -47,8 +54,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path, A, P, oracle_make):
-    total = 13  # odd on purpose: uneven shards
+import pytest
+
+
+@pytest.mark.parametrize("total", [12, 13])  # 12: bench.py's pack_and_gather path; 13: uneven shards
+def test_two_rank_gloo_matches_single_process(tmp_path, A, P, oracle_make, total):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = tmp_path / "gathered.npy"
@@ -61,7 +71,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path, A, P, oracle_make):
     gathered = np.load(out)
     import importlib
     S = importlib.import_module("altro_cpp_amd.sharding")
-    s = P.unicycle_turn90(oracle_make, batch=total, xf=P.batch_turn90_goals(total))
+    s = P.batch_turn90(oracle_make, batch=total)
     s.solve()
     ref = S.result_records(s.get_stats())
     assert gathered.shape == ref.shape
