@@ -77,7 +77,7 @@ def _survey_tolerances(o64, g, ctol=1e-4):
 @pytest.mark.parametrize("name,batch,xtol,gtol", [
     ("batch_turn90", 96, 1e-6, 1e-4),
     ("batch_three_obstacles", 96, 1e-5, 1e-3),
-    ("batch_quadrotor12", 16, 1e-5, 1e-3),
+    ("batch_quadrotor12", 16, 1e-5, 5e-3),  # gains of this model move 3e-3 under a 1-ulp input change (test_parity_gpu)
 ])
 def test_f32_engine_against_record_rounding_oracle(P, A, oracle_make, hip_make, oracle_lib, name, batch, xtol, gtol):
     o = getattr(P, name)(oracle_make, batch=batch, dtype=REC32)
