@@ -149,17 +149,104 @@ def quadrotor12(make, batch=1, N=200, dtype=F32, xf_pos=None, **kw):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Seeded synthetic batches; instance 0 = the exact reference problem
+# Seeded synthetic batches; instance 0 = the exact reference problem.
+# The generator is std::mt19937_64 (the C++ facade, include/altro/problems.hpp, draws the same numbers from
+# the standard library's engine), uniform doubles as a + (b - a) * (x >> 11) * 2^-53, one instance after the
+# other: the Python binding, bench.py and the C++ drivers solve the SAME batches.
 # ---------------------------------------------------------------------------------------------------
+class Mt19937_64:
+    """std::mt19937_64 (Matsumoto & Nishimura's 64-bit Mersenne Twister), bit-exact."""
+    NN, MM = 312, 156
+    MATRIX_A, UM, LM = 0xB5026F5AA96619E9, 0xFFFFFFFF80000000, 0x7FFFFFFF
+    MASK = (1 << 64) - 1
+
+    def __init__(self, seed=5489):
+        mt = [0] * self.NN
+        mt[0] = seed & self.MASK
+        for i in range(1, self.NN):
+            mt[i] = (6364136223846793005 * (mt[i - 1] ^ (mt[i - 1] >> 62)) + i) & self.MASK
+        self.mt, self.mti = mt, self.NN
+
+    def _twist(self):
+        mt, NN, MM = self.mt, self.NN, self.MM
+        for i in range(NN):
+            x = (mt[i] & self.UM) | (mt[(i + 1) % NN] & self.LM)
+            mt[i] = mt[(i + MM) % NN] ^ (x >> 1) ^ (self.MATRIX_A if x & 1 else 0)
+        self.mti = 0
+
+    def next(self):
+        if self.mti >= self.NN:
+            self._twist()
+        x = self.mt[self.mti]
+        self.mti += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        return x & self.MASK
+
+    def uniform(self, a, b):
+        return a + (b - a) * ((self.next() >> 11) * (1.0 / 9007199254740992.0))
+
+
+_batch_cache = {}
+
+
+def _cached(key, build):
+    if key not in _batch_cache:
+        _batch_cache[key] = build()
+    return _batch_cache[key].copy()
+
+
 def batch_turn90_goals(batch, seed=SEED_BASE + 3):
     """Per-instance goals of BASELINE config 3: xf = (1.5+dx, 1.5+dy, pi/2+dth), instance 0 exact."""
-    rng = np.random.default_rng(seed)
-    xf = np.tile(np.array([1.5, 1.5, np.pi / 2]), (batch, 1))
-    if batch > 1:
-        xf[1:, 0] += rng.uniform(-0.5, 0.5, batch - 1)
-        xf[1:, 1] += rng.uniform(-0.5, 0.5, batch - 1)
-        xf[1:, 2] += rng.uniform(-0.3, 0.3, batch - 1)
-    return xf
+    def build():
+        g = Mt19937_64(seed)
+        xf = np.tile(np.array([1.5, 1.5, np.pi / 2]), (batch, 1))
+        for b in range(1, batch):
+            xf[b, 0] = 1.5 + g.uniform(-0.5, 0.5)
+            xf[b, 1] = 1.5 + g.uniform(-0.5, 0.5)
+            xf[b, 2] = np.pi / 2 + g.uniform(-0.3, 0.3)
+        return xf
+    return _cached(("turn90", batch, seed), build)
+
+
+def batch_obstacle_circles(batch, seed=SEED_BASE + 4):
+    """Per-instance obstacles of BASELINE config 4: the three reference circles, centres jittered +-0.1."""
+    def build():
+        g = Mt19937_64(seed)
+        circles = np.tile(THREE_OBSTACLE_CIRCLES, (batch, 1, 1))
+        for b in range(1, batch):
+            for i in range(3):
+                circles[b, i, 0] += g.uniform(-0.1, 0.1)
+                circles[b, i, 1] += g.uniform(-0.1, 0.1)
+        return circles
+    return _cached(("obstacles", batch, seed), build)
+
+
+def batch_triple_integrator_goals(batch, seed=SEED_BASE + 2):
+    """Per-instance goals of BASELINE config 2: xf[0:2] ~ U([0.5, 2]^2), instance 0 = (1, 2)."""
+    def build():
+        g = Mt19937_64(seed)
+        xf = np.zeros((batch, 6))
+        xf[:, 0], xf[:, 1] = 1.0, 2.0
+        for b in range(1, batch):
+            xf[b, 0] = g.uniform(0.5, 2.0)
+            xf[b, 1] = g.uniform(0.5, 2.0)
+        return xf
+    return _cached(("tripleint", batch, seed), build)
+
+
+def batch_quadrotor12_goals(batch, seed=SEED_BASE + 5):
+    """Per-instance hover goals of BASELINE config 5: xf_p ~ U([-2, 2]^3), instance 0 = (1, -1, 0.5)."""
+    def build():
+        g = Mt19937_64(seed)
+        pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
+        for b in range(1, batch):
+            for i in range(3):
+                pos[b, i] = g.uniform(-2.0, 2.0)
+        return pos
+    return _cached(("quad12", batch, seed), build)
 
 
 def _block(arr, shard):
@@ -177,32 +264,19 @@ def batch_turn90(make, batch, N=100, dtype=F64, seed=SEED_BASE + 3, shard=None):
 
 def batch_three_obstacles(make, batch, N=100, dtype=F32, seed=SEED_BASE + 4, shard=None):
     """BASELINE config 4: kThreeObstacles with per-instance obstacle centres jittered +-0.1."""
-    rng = np.random.default_rng(seed)
-    circles = np.tile(THREE_OBSTACLE_CIRCLES, (batch, 1, 1))
-    if batch > 1:
-        circles[1:, :, :2] += rng.uniform(-0.1, 0.1, (batch - 1, 3, 2))
-    circles = _block(circles, shard)
+    circles = _block(batch_obstacle_circles(batch, seed), shard)
     return unicycle_three_obstacles(make, batch=len(circles), N=N, dtype=dtype, circles=circles)
 
 
 def batch_triple_integrator(make, batch, N=50, dtype=F64, seed=SEED_BASE + 2, shard=None):
     """BASELINE config 2: unconstrained triple integrator, 51 knots, xf[0:2] ~ U([0.5,2]^2)."""
-    rng = np.random.default_rng(seed)
-    xf = np.zeros((batch, 6))
-    xf[:, 0], xf[:, 1] = 1.0, 2.0
-    if batch > 1:
-        xf[1:, :2] = rng.uniform(0.5, 2.0, (batch - 1, 2))
-    xf = _block(xf, shard)
+    xf = _block(batch_triple_integrator_goals(batch, seed), shard)
     return triple_integrator(make, batch=len(xf), N=N, dtype=dtype, xf=xf)
 
 
 def batch_quadrotor12(make, batch, N=200, dtype=F32, seed=SEED_BASE + 5, shard=None):
     """BASELINE config 5: hover-to-hover, xf_p ~ U([-2,2]^3)."""
-    rng = np.random.default_rng(seed)
-    pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
-    if batch > 1:
-        pos[1:] = rng.uniform(-2.0, 2.0, (batch - 1, 3))
-    pos = _block(pos, shard)
+    pos = _block(batch_quadrotor12_goals(batch, seed), shard)
     return quadrotor12(make, batch=len(pos), N=N, dtype=dtype, xf_pos=pos)
 
 

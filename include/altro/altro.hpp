@@ -22,6 +22,7 @@
 // SolverStatus.  Solver objects are non-copyable and not thread-safe (altro/ilqr/ilqr.hpp:56-71).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <limits>
@@ -106,8 +107,12 @@ struct SolverOptions {
   }
 };
 
-// altro/common/solver_stats.hpp:44-63.  Scalars and `.back()` values of instance 0 after a solve;
-// AllInstances() gives the per-instance records of the batch.
+// altro/common/solver_stats.hpp:44-63.  The counters and the per-iteration vectors of ONE instance
+// (instance 0 unless SelectInstance() was called).  The vectors hold one row per logged iteration plus the
+// row opened by the last NewIteration -- the reference's layout (solver_stats.cpp:54-66), so alpha[0] is the
+// first accepted step and .back() the latest value -- when the solver records the history (the default for
+// batches of up to kHistoryBatchLimit instances; SetRecordHistory() otherwise); without recording they hold
+// the latest row only.  AllInstances() gives the final per-instance records of the whole batch.
 struct SolverStats {
   double initial_cost = 0.0;
   int iterations_inner = 0;
@@ -117,7 +122,37 @@ struct SolverStats {
       max_penalty;
   std::vector<altro_stats> instances;
   const std::vector<altro_stats>& AllInstances() const { return instances; }
+  void Reset() {  // solver_stats.cpp:31-45 (host mirror; iLQR::ResetStats() also clears the device counters)
+    initial_cost = 0.0;
+    iterations_inner = iterations_outer = iterations_total = 0;
+    for (auto* v : {&cost, &alpha, &improvement_ratio, &gradient, &cost_decrease, &regularization, &violations, &max_penalty})
+      v->clear();
+  }
 };
+
+namespace constraints {
+// altro/constraints/constraint.hpp:134-141
+struct ConstraintInfo {
+  std::string label;
+  int index = 0;
+  std::vector<double> violation;  // c - Pi_K(c): c for equalities, max(c, 0) for inequalities
+  std::string type;
+  double MaxViolation() const {
+    double v = 0.0;
+    for (double x : violation) v = std::max(v, std::abs(x));
+    return v;
+  }
+  std::string ToString(int precision = 4) const {  // constraint.cpp:12-15
+    std::string out = label + " at index " + std::to_string(index) + ": [";
+    char buf[64];
+    for (size_t i = 0; i < violation.size(); ++i) {
+      std::snprintf(buf, sizeof(buf), "%.*g", precision, violation[i]);
+      out += (i ? ", " : "") + std::string(buf);
+    }
+    return out + "]";
+  }
+};
+}  // namespace constraints
 
 namespace detail {
 inline void Check(altro_handle h, altro_status st, const char* what) {
@@ -206,6 +241,17 @@ struct ConstraintDesc {
   int nparams = 0;             // length of one instance's block
   std::string label;
   bool operator==(const ConstraintDesc& o) const { return kind == o.kind && params == o.params && nparams == o.nparams; }
+  bool IsEquality() const { return kind == ALTRO_CON_GOAL; }
+  // Constraint<ConType>::GetConstraintType, altro/constraints/constraint.hpp:193-201
+  std::string GetConstraintType() const { return IsEquality() ? "Equality Constraint" : "Inequality Constraint"; }
+  int OutputDimension() const {
+    if (kind == ALTRO_CON_GOAL) return nparams;
+    if (kind == ALTRO_CON_CIRCLE) return nparams / 3;
+    int p = 0;  // CONTROL_BOUND: one row per finite bound (basic_constraints.hpp:138-145)
+    for (int i = 0; i < nparams; ++i)
+      if (std::abs(params[i]) < std::numeric_limits<double>::max()) ++p;
+    return p;
+  }
 };
 // examples/basic_constraints.hpp:15-40
 struct GoalConstraint : ConstraintDesc {
@@ -287,9 +333,16 @@ class Problem {
     Range(k);
     cons_[k].push_back(con);
   }
+  // the constraints of knot k in the order the solver stacks them: equalities first, then inequalities,
+  // insertion order within each (al_cost.hpp:267-272)
+  std::vector<examples::ConstraintDesc> Constraints(int k) const {
+    std::vector<examples::ConstraintDesc> v = cons_[k];
+    std::stable_partition(v.begin(), v.end(), [](const examples::ConstraintDesc& c) { return c.IsEquality(); });
+    return v;
+  }
   int NumConstraints(int k) const {
     int p = 0;
-    for (const auto& c : cons_[k]) p += Rows(c);
+    for (const auto& c : cons_[k]) p += c.OutputDimension();
     return p;
   }
   int NumConstraints() const {
@@ -303,9 +356,14 @@ class Problem {
     return !x0_.empty();
   }
 
+  // BuildAugLagProblem (al_problem.hpp:29-51) marks the copy whose constraints a solver folds into the cost;
+  // a plain iLQR built from an unmarked problem ignores the constraints (ilqr.hpp:117-119, quirk Q10).
+  void MarkAugLag(bool on) { auglag_ = on; }
+  bool IsAugLag() const { return auglag_; }
+
   // Replay the definition through the C-ABI (consecutive knots with identical descriptors become
   // one [k_begin, k_end) call).
-  void Apply(altro_handle h) const {
+  void Apply(altro_handle h, bool with_constraints = true) const {
     using detail::Check;
     Check(h, altro_set_model(h, model_kind_, model_params_.empty() ? nullptr : model_params_.data(),
                              (int)model_params_.size()), "altro_set_model");
@@ -320,7 +378,8 @@ class Problem {
     }
     // insertion order within a knot is what matters (al_cost.hpp:267-272): emit constraint j of each knot
     size_t maxc = 0;
-    for (const auto& v : cons_) maxc = std::max(maxc, v.size());
+    if (with_constraints)
+      for (const auto& v : cons_) maxc = std::max(maxc, v.size());
     for (size_t j = 0; j < maxc; ++j)
       for (int k = 0; k <= N_;) {
         if (cons_[k].size() <= j) {
@@ -343,15 +402,8 @@ class Problem {
   void Range(int k) const {
     if (k < 0 || k > N_) throw std::runtime_error("Invalid knot point index.");
   }
-  static int Rows(const examples::ConstraintDesc& c) {
-    if (c.kind == ALTRO_CON_GOAL) return c.nparams;
-    if (c.kind == ALTRO_CON_CIRCLE) return c.nparams / 3;
-    int p = 0;
-    for (int i = 0; i < c.nparams; ++i)
-      if (std::abs(c.params[i]) < std::numeric_limits<double>::max()) ++p;
-    return p;
-  }
   int N_, batch_ = 1, n_ = 0, m_ = 0, model_kind_ = 0;
+  bool auglag_ = false;
   std::vector<double> model_params_, x0_;
   std::vector<examples::QuadraticCost> costs_;
   std::vector<bool> has_cost_;
@@ -360,142 +412,325 @@ class Problem {
 };
 }  // namespace problem
 
+namespace augmented_lagrangian {
+// BuildAugLagProblem (altro/augmented_lagrangian/al_problem.hpp:29-51): the copy of the problem whose
+// constraints are folded into ALCost functions.  On this facade the device evaluates the AL terms itself, so
+// the copy only carries the mark that tells a solver to register the constraints.
+template <int n, int m>
+problem::Problem BuildAugLagProblem(const problem::Problem& prob) {
+  problem::Problem al = prob;
+  al.MarkAugLag(true);
+  return al;
+}
+}  // namespace augmented_lagrangian
+
 namespace ilqr {
-// altro/ilqr/knot_point_function_type.hpp:243-268: read-only view of one knot of one instance.
+
+constexpr int kHistoryBatchLimit = 64;   // batches up to this size record the per-iteration history by default
+constexpr int kHistoryCapacity = 302;    // rows kept per instance (max_iterations_total + the initial row)
+
+namespace detail_ilqr {
+// State shared by an iLQR solver, the AL solver built on it and the knot-point views: the C-ABI handle, the
+// options / statistics objects of the reference, the caller's trajectory, and a cache of downloaded arrays
+// that is invalidated by every compute call (`epoch`).
+template <int n, int m>
+struct Core {
+  altro_handle h = nullptr;
+  int N = 0, B = 1;
+  SolverOptions opts;
+  SolverStats stats;
+  std::shared_ptr<Trajectory<n, m>> traj;
+  bool pushed = false;
+  bool record_history = false;
+  int stats_instance = 0;
+  unsigned epoch = 0;
+  std::vector<std::vector<examples::ConstraintDesc>> cons;  // per knot, solver order (empty without AL)
+  // cache
+  unsigned gains_epoch = ~0u, ctg_epoch = ~0u;
+  std::vector<double> K, d, P, p;
+  ~Core() {
+    if (h) altro_destroy(h);
+  }
+  Core() = default;
+  Core(const Core&) = delete;
+  Core& operator=(const Core&) = delete;
+};
+
+// CostExpansion (altro/ilqr/cost_expansion.hpp:24-116): the blocks of the quadratic cost expansion of one knot
+struct CostExpansion {
+  std::vector<double> xx, xu, uu, x, u;  // column-major n x n, n x m, m x m; n; m
+  const std::vector<double>& dxdx() const { return xx; }
+  const std::vector<double>& dxdu() const { return xu; }
+  const std::vector<double>& dudu() const { return uu; }
+  const std::vector<double>& dx() const { return x; }
+  const std::vector<double>& du() const { return u; }
+};
+}  // namespace detail_ilqr
+
+// altro/ilqr/knot_point_function_type.hpp:243-268: read-only view of one knot of one instance.  The gain and
+// cost-to-go arrays are downloaded once per compute call and shared by all views (a loop over knots costs one
+// device copy, not one per knot).
 template <int n, int m>
 class KnotPointFunctions {
+  using Core = detail_ilqr::Core<n, m>;
+
  public:
-  KnotPointFunctions(altro_handle h, int N, int batch, int k, int b) : h_(h), N_(N), B_(batch), k_(k), b_(b) {}
+  KnotPointFunctions(std::shared_ptr<Core> c, int k, int b) : c_(std::move(c)), k_(k), b_(b) {}
   std::vector<double> GetFeedbackGain() const {  // m x n, column-major
-    std::vector<double> K((size_t)B_ * N_ * m * n);
-    detail::Check(h_, altro_get_gains(h_, K.data(), nullptr), "altro_get_gains");
-    return Slice(K, ((size_t)b_ * N_ + k_) * m * n, m * n);
+    Gains();
+    return Slice(c_->K, ((size_t)b_ * c_->N + k_) * m * n, m * n);
   }
   std::vector<double> GetFeedforwardGain() const {
-    std::vector<double> d((size_t)B_ * N_ * m);
-    detail::Check(h_, altro_get_gains(h_, nullptr, d.data()), "altro_get_gains");
-    return Slice(d, ((size_t)b_ * N_ + k_) * m, m);
+    Gains();
+    return Slice(c_->d, ((size_t)b_ * c_->N + k_) * m, m);
   }
   std::vector<double> GetCostToGoHessian() const {
-    std::vector<double> P((size_t)B_ * (N_ + 1) * n * n);
-    detail::Check(h_, altro_get_ctg(h_, P.data(), nullptr), "altro_get_ctg");
-    return Slice(P, ((size_t)b_ * (N_ + 1) + k_) * n * n, n * n);
+    Ctg();
+    return Slice(c_->P, ((size_t)b_ * (c_->N + 1) + k_) * n * n, n * n);
   }
   std::vector<double> GetCostToGoGradient() const {
-    std::vector<double> p((size_t)B_ * (N_ + 1) * n);
-    detail::Check(h_, altro_get_ctg(h_, nullptr, p.data()), "altro_get_ctg");
-    return Slice(p, ((size_t)b_ * (N_ + 1) + k_) * n, n);
+    Ctg();
+    return Slice(c_->p, ((size_t)b_ * (c_->N + 1) + k_) * n, n);
   }
   std::vector<double> GetDynamicsExpansion() const {  // [A|B], n x (n+m), column-major
-    std::vector<double> AB((size_t)B_ * n * (n + m));
-    detail::Check(h_, altro_get_expansion(h_, k_, AB.data(), nullptr, nullptr, nullptr, nullptr, nullptr),
+    std::vector<double> AB((size_t)c_->B * n * (n + m));
+    detail::Check(c_->h, altro_get_expansion(c_->h, k_, AB.data(), nullptr, nullptr, nullptr, nullptr, nullptr),
                   "altro_get_expansion");
     return Slice(AB, (size_t)b_ * n * (n + m), n * (n + m));
   }
+  detail_ilqr::CostExpansion GetCostExpansion() const {  // knot_point_function_type.hpp:249
+    const size_t B = c_->B;
+    std::vector<double> xx(B * n * n), xu(B * n * m), uu(B * m * m), x(B * n), u(B * m);
+    const bool stage = k_ < c_->N;
+    detail::Check(c_->h, altro_get_expansion(c_->h, k_, nullptr, xx.data(), stage ? xu.data() : nullptr,
+                                             stage ? uu.data() : nullptr, x.data(), stage ? u.data() : nullptr),
+                  "altro_get_expansion");
+    detail_ilqr::CostExpansion e;
+    e.xx = Slice(xx, (size_t)b_ * n * n, n * n);
+    e.xu = stage ? Slice(xu, (size_t)b_ * n * m, n * m) : std::vector<double>((size_t)n * m, 0.0);
+    e.uu = stage ? Slice(uu, (size_t)b_ * m * m, m * m) : std::vector<double>((size_t)m * m, 0.0);
+    e.x = Slice(x, (size_t)b_ * n, n);
+    e.u = stage ? Slice(u, (size_t)b_ * m, m) : std::vector<double>((size_t)m, 0.0);
+    return e;
+  }
 
  private:
+  void Gains() const {
+    if (c_->gains_epoch == c_->epoch) return;
+    c_->K.resize((size_t)c_->B * c_->N * m * n);
+    c_->d.resize((size_t)c_->B * c_->N * m);
+    detail::Check(c_->h, altro_get_gains(c_->h, c_->K.data(), c_->d.data()), "altro_get_gains");
+    c_->gains_epoch = c_->epoch;
+  }
+  void Ctg() const {
+    if (c_->ctg_epoch == c_->epoch) return;
+    c_->P.resize((size_t)c_->B * (c_->N + 1) * n * n);
+    c_->p.resize((size_t)c_->B * (c_->N + 1) * n);
+    detail::Check(c_->h, altro_get_ctg(c_->h, c_->P.data(), c_->p.data()), "altro_get_ctg");
+    c_->ctg_epoch = c_->epoch;
+  }
   static std::vector<double> Slice(const std::vector<double>& v, size_t off, size_t len) {
     return std::vector<double>(v.begin() + off, v.begin() + off + len);
   }
-  altro_handle h_;
-  int N_, B_, k_, b_;
+  std::shared_ptr<Core> c_;
+  int k_, b_;
 };
 
 // altro/ilqr/ilqr.hpp:47-813 (the algorithm methods; thread-pool and logging members omitted)
 template <int n, int m>
 class iLQR {
+  using Core = detail_ilqr::Core<n, m>;
+
  public:
-  iLQR(altro_handle h, int N, int batch, SolverOptions* opts, SolverStats* stats,
-       std::shared_ptr<Trajectory<n, m>>* traj)
-      : h_(h), N_(N), B_(batch), opts_(opts), stats_(stats), traj_(traj) {}
-  int NumSegments() const { return N_; }
-  SolverOptions& GetOptions() { return *opts_; }
-  SolverStats& GetStats() { return *stats_; }
+  explicit iLQR(int N) : c_(std::make_shared<Core>()) { c_->N = N; }  // ilqr.hpp:50
+  explicit iLQR(const problem::Problem& prob, int dtype = ALTRO_F64, int device_id = 0)  // ilqr.hpp:51-54
+      : c_(std::make_shared<Core>()) {
+    c_->N = prob.NumSegments();
+    InitializeFromProblem(prob, dtype, device_id);
+  }
+  iLQR(const iLQR&) = delete;
+  iLQR& operator=(const iLQR&) = delete;
+  iLQR(iLQR&&) noexcept = default;
+
+  // ilqr.hpp:98-134.  A problem marked by BuildAugLagProblem brings its constraints (AL cost); a plain problem
+  // contributes costs and dynamics only, like the reference (ilqr.hpp:117-119).
+  void InitializeFromProblem(const problem::Problem& prob, int dtype = ALTRO_F64, int device_id = 0) {
+    if (prob.NumSegments() != c_->N) throw std::runtime_error("Number of segments in problem isn't consistent with solver.");
+    if (prob.StateDimension() != n || prob.ControlDimension() != m)
+      throw std::runtime_error("Inconsistent state / control dimension.");
+    if (!prob.IsFullyDefined()) throw std::runtime_error("Expected problem to be fully defined.");
+    if (c_->h) throw std::runtime_error("The solver has already been initialized from a problem.");
+    c_->B = prob.BatchSize();
+    altro_desc d{n, m, c_->N, c_->B, dtype, device_id};
+    altro_status st = altro_create(&d, &c_->h);
+    if (st != ALTRO_OK) throw std::runtime_error(std::string("altro_create failed: ") + altro_last_error(nullptr));
+    prob.Apply(c_->h, prob.IsAugLag());
+    c_->cons.assign(c_->N + 1, {});
+    if (prob.IsAugLag())
+      for (int k = 0; k <= c_->N; ++k) c_->cons[k] = prob.Constraints(k);
+    SetRecordHistory(c_->B <= kHistoryBatchLimit);
+    SetRecordCostToGo(c_->B <= kHistoryBatchLimit);
+  }
+  bool IsInitialized() const { return c_->h != nullptr; }
+
+  int NumSegments() const { return c_->N; }
+  int BatchSize() const { return c_->B; }
+  SolverOptions& GetOptions() { return c_->opts; }
+  SolverStats& GetStats() { return c_->stats; }
   SolverStatus GetStatus() const { return status_; }
-  std::shared_ptr<Trajectory<n, m>> GetTrajectory() { return *traj_; }
-  KnotPointFunctions<n, m> GetKnotPointFunction(int k, int b = 0) {
-    detail::Check(h_, altro_set_record_ctg(h_, 1), "altro_set_record_ctg");
-    return KnotPointFunctions<n, m>(h_, N_, B_, k, b);
-  }
-  void Solve() {
-    Push();
-    detail::Check(h_, altro_solve_ilqr(h_), "altro_solve_ilqr");
-    Pull(true);
-  }
-  void Rollout() {
-    Push();
-    detail::Check(h_, altro_rollout(h_), "altro_rollout");
-    Pull(false);
-  }
-  double Cost(int b = 0) {
-    std::vector<double> J(B_);
-    Push();
-    detail::Check(h_, altro_cost(h_, J.data()), "altro_cost");
-    return J[b];
-  }
-  void UpdateExpansions() {
-    Push();
-    detail::Check(h_, altro_update_expansions(h_), "altro_update_expansions");
-  }
-  void BackwardPass() {
-    detail::Check(h_, altro_set_options(h_, &(o_ = opts_->ToC())), "altro_set_options");
-    detail::Check(h_, altro_backward_pass(h_), "altro_backward_pass");
-  }
-  void ForwardPass() {
-    detail::Check(h_, altro_forward_pass(h_), "altro_forward_pass");
-    Pull(false);
-  }
-  // make the device see the caller's trajectory / options (the trajectory object is shared, so the
-  // caller may have edited it since the last call: ilqr.hpp:223-235)
-  void Push() {
-    detail::Check(h_, altro_set_options(h_, &(o_ = opts_->ToC())), "altro_set_options");
-    if (*traj_ && !pushed_) {
-      auto& Z = **traj_;
-      if (!step_set_) {  // the step is part of the problem definition: fixed after the first push
-        detail::Check(h_, altro_set_uniform_step(h_, Z.GetStep(0)), "altro_set_uniform_step");
-        step_set_ = true;
-      }
-      detail::Check(h_, altro_set_trajectory(h_, Z.States().data(), Z.Controls().data(), 1), "altro_set_trajectory");
-      pushed_ = true;
-    }
-  }
-  void MarkTrajectoryDirty() { pushed_ = false; }
-  void Pull(bool with_stats) {
-    if (*traj_) {
-      auto& Z = **traj_;
-      detail::Check(h_, altro_get_trajectory(h_, Z.States().data(), Z.Controls().data()), "altro_get_trajectory");
-    }
-    if (with_stats) {
-      stats_->instances.resize(B_);
-      detail::Check(h_, altro_get_stats(h_, stats_->instances.data()), "altro_get_stats");
-      const altro_stats& s = stats_->instances[0];
-      status_ = static_cast<SolverStatus>(s.status_ilqr);
-      stats_->initial_cost = s.initial_cost;
-      stats_->iterations_inner = s.iterations_inner;
-      stats_->iterations_outer = s.iterations_outer;
-      stats_->iterations_total = s.iterations_total;
-      auto put = [](std::vector<double>& v, double x) { v.assign(1, x); };
-      put(stats_->cost, s.cost);
-      put(stats_->alpha, s.alpha);
-      put(stats_->improvement_ratio, s.improvement_ratio);
-      put(stats_->gradient, s.gradient);
-      put(stats_->cost_decrease, s.cost_decrease);
-      put(stats_->regularization, s.regularization);
-      put(stats_->violations, s.violation);
-      put(stats_->max_penalty, s.max_penalty);
-    }
+  double GetRegularization() const { return c_->stats.instances.empty() ? 0.0 : c_->stats.instances[c_->stats_instance].regularization; }
+  altro_handle Handle() const { return Need(); }
+  // the instance whose counters / vectors GetStats() shows (default 0); takes effect at the next compute call
+  void SelectInstance(int b) { c_->stats_instance = b; }
+  // per-iteration vectors of SolverStats (solver_stats.hpp:56-63) need the device to log every iteration
+  void SetRecordHistory(bool on) {
+    detail::Check(Need(), altro_set_record_history(c_->h, on ? kHistoryCapacity : 0), "altro_set_record_history");
+    c_->record_history = on;
   }
 
+  // KnotPointFunctions::GetCostToGoHessian / Gradient need the backward pass to store P, p of every knot
+  // (the solve itself only needs them in registers).  On by default for batches of up to kHistoryBatchLimit
+  // instances; switch it off for timing runs: the persistent tail kernel only runs without it.
+  void SetRecordCostToGo(bool on) {
+    detail::Check(Need(), altro_set_record_ctg(c_->h, on ? 1 : 0), "altro_set_record_ctg");
+    record_ctg_ = on;
+  }
+
+  std::shared_ptr<Trajectory<n, m>> GetTrajectory() { return c_->traj; }
+  void SetTrajectory(std::shared_ptr<Trajectory<n, m>> traj) {  // ilqr.hpp:231-235
+    c_->traj = std::move(traj);
+    c_->pushed = false;
+  }
+  std::shared_ptr<Trajectory<n, m>> MakeTrajectory(float dt) {  // ilqr.hpp:216-221
+    auto Z = std::make_shared<Trajectory<n, m>>(c_->N, c_->B);
+    Z->SetUniformStep(dt);
+    SetTrajectory(Z);
+    return Z;
+  }
+  KnotPointFunctions<n, m> GetKnotPointFunction(int k, int b = 0) {
+    Need();
+    return KnotPointFunctions<n, m>(c_, k, b);
+  }
+
+  void Solve() {  // ilqr.hpp:284-316
+    Push();
+    detail::Check(c_->h, altro_solve_ilqr(c_->h), "altro_solve_ilqr");
+    Pull(true, true);
+  }
+  void SolveSetup() {  // ilqr.hpp:629-645
+    Push();
+    detail::Check(c_->h, altro_solve_setup(c_->h), "altro_solve_setup");
+    ++c_->epoch;
+  }
+  void Rollout() {  // ilqr.hpp:453-459
+    Push();
+    detail::Check(c_->h, altro_rollout(c_->h), "altro_rollout");
+    Pull(true, false);
+  }
+  double Cost(int b = 0) {  // ilqr.hpp:326-334
+    std::vector<double> J(c_->B);
+    Push();
+    detail::Check(c_->h, altro_cost(c_->h, J.data()), "altro_cost");
+    return J[b];
+  }
+  void UpdateExpansions() {  // ilqr.hpp:350-358
+    Push();
+    detail::Check(c_->h, altro_update_expansions(c_->h), "altro_update_expansions");
+    ++c_->epoch;
+  }
+  void BackwardPass() {  // ilqr.hpp:385-445
+    PushOptions();
+    detail::Check(c_->h, altro_backward_pass(c_->h), "altro_backward_pass");
+    ++c_->epoch;
+    PullStats();
+  }
+  void ForwardPass() {  // ilqr.hpp:512-558
+    PushOptions();
+    detail::Check(c_->h, altro_forward_pass(c_->h), "altro_forward_pass");
+    Pull(true, true);
+  }
+  void UpdateConvergenceStatistics() {  // ilqr.hpp:568-587
+    PushOptions();
+    detail::Check(c_->h, altro_update_convergence_statistics(c_->h), "altro_update_convergence_statistics");
+    PullStats();
+  }
+  // solver.GetStats().Reset() of the reference (solver_stats.cpp:31-45), on the host mirror and on the device
+  void ResetStats() {
+    detail::Check(Need(), altro_reset_stats(c_->h), "altro_reset_stats");
+    c_->stats.Reset();
+  }
+  // the reference's task decomposition of UpdateExpansions (ilqr.hpp:183-214) has no counterpart: every
+  // (instance, knot) pair is its own GPU thread
+  int NumThreads() const { return 1; }
+  int NumTasks() const { return 1; }
+
+  // ---- plumbing shared with AugmentedLagrangianiLQR ---------------------------------------------------
+  void PushOptions() {
+    o_ = c_->opts.ToC();
+    detail::Check(Need(), altro_set_options(c_->h, &o_), "altro_set_options");
+  }
+  // make the device see the caller's options and trajectory (the trajectory object is shared, so the caller
+  // may have edited or replaced it since the last call: ilqr.hpp:223-235)
+  void Push() {
+    PushOptions();
+    if (c_->traj && !c_->pushed) {
+      auto& Z = *c_->traj;
+      if (Z.BatchSize() != c_->B || Z.NumSegments() != c_->N) throw std::runtime_error("Trajectory size isn't consistent with the solver.");
+      if (Z.GetStep(0) > 0.0f) detail::Check(c_->h, altro_set_uniform_step(c_->h, Z.GetStep(0)), "altro_set_uniform_step");
+      detail::Check(c_->h, altro_set_trajectory(c_->h, Z.States().data(), Z.Controls().data(), 1), "altro_set_trajectory");
+      c_->pushed = true;
+    }
+  }
+  void MarkTrajectoryDirty() { c_->pushed = false; }
+  void Pull(bool with_traj, bool with_stats) {
+    ++c_->epoch;
+    if (with_traj && c_->traj) {
+      auto& Z = *c_->traj;
+      detail::Check(c_->h, altro_get_trajectory(c_->h, Z.States().data(), Z.Controls().data()), "altro_get_trajectory");
+    }
+    if (with_stats) PullStats();
+  }
+  void PullStats() {
+    SolverStats& S = c_->stats;
+    S.instances.resize(c_->B);
+    detail::Check(c_->h, altro_get_stats(c_->h, S.instances.data()), "altro_get_stats");
+    const int b = std::min(std::max(c_->stats_instance, 0), c_->B - 1);
+    const altro_stats& s = S.instances[b];
+    status_ = static_cast<SolverStatus>(s.status_ilqr);
+    status_al_ = static_cast<SolverStatus>(s.status);
+    S.initial_cost = s.initial_cost;
+    S.iterations_inner = s.iterations_inner;
+    S.iterations_outer = s.iterations_outer;
+    S.iterations_total = s.iterations_total;
+    // field order of altro_get_history: cost, alpha, improvement_ratio, gradient, cost_decrease, regularization,
+    // violations, max_penalty.  History rows = the rows closed by NewIteration; the latest row is the open one.
+    std::vector<double>* vec[8] = {&S.cost, &S.alpha, &S.improvement_ratio, &S.gradient, &S.cost_decrease,
+                                   &S.regularization, &S.violations, &S.max_penalty};
+    const double last[8] = {s.cost, s.alpha, s.improvement_ratio, s.gradient, s.cost_decrease, s.regularization,
+                            s.violation, s.max_penalty};
+    std::vector<double> buf(kHistoryCapacity);
+    for (int f = 0; f < 8; ++f) {
+      vec[f]->clear();
+      if (c_->record_history) {
+        const int cnt = altro_get_history(c_->h, b, f, buf.data(), kHistoryCapacity);
+        if (cnt > 0) vec[f]->assign(buf.begin(), buf.begin() + cnt);
+      }
+      vec[f]->push_back(last[f]);
+    }
+  }
+  SolverStatus StatusAL() const { return status_al_; }
+  std::shared_ptr<Core> CorePtr() { return c_; }
+
  private:
-  altro_handle h_;
-  int N_, B_;
-  SolverOptions* opts_;
-  SolverStats* stats_;
-  std::shared_ptr<Trajectory<n, m>>* traj_;
+  altro_handle Need() const {
+    if (!c_->h) throw std::runtime_error("The solver has not been initialized with a problem.");
+    return c_->h;
+  }
+  std::shared_ptr<Core> c_;
   SolverStatus status_ = SolverStatus::kUnsolved;
+  SolverStatus status_al_ = SolverStatus::kUnsolved;
   altro_options o_{};
-  bool pushed_ = false;
-  bool step_set_ = false;
+  bool record_ctg_ = false;
 };
 }  // namespace ilqr
 
@@ -504,86 +739,115 @@ namespace augmented_lagrangian {
 template <int n, int m>
 class AugmentedLagrangianiLQR {
  public:
+  explicit AugmentedLagrangianiLQR(int N) : ilqr_solver_(N) {}  // al_solver.hpp:35
   explicit AugmentedLagrangianiLQR(const problem::Problem& prob, int dtype = ALTRO_F64, int device_id = 0)
-      : N_(prob.NumSegments()), B_(prob.BatchSize()) {
-    if (prob.StateDimension() != n || prob.ControlDimension() != m)
-      throw std::runtime_error("Inconsistent state / control dimension.");
-    if (!prob.IsFullyDefined()) throw std::runtime_error("Expected problem to be fully defined.");
-    altro_desc d{n, m, N_, B_, dtype, device_id};
-    altro_status st = altro_create(&d, &h_);
-    if (st != ALTRO_OK) throw std::runtime_error(std::string("altro_create failed: ") + altro_last_error(nullptr));
-    prob.Apply(h_);
-    ilqr_.reset(new ilqr::iLQR<n, m>(h_, N_, B_, &opts_, &stats_, &traj_));
+      : ilqr_solver_(prob.NumSegments()) {  // al_solver.hpp:231-237
+    InitializeFromProblem(prob, dtype, device_id);
   }
-  ~AugmentedLagrangianiLQR() { altro_destroy(h_); }
   AugmentedLagrangianiLQR(const AugmentedLagrangianiLQR&) = delete;
   AugmentedLagrangianiLQR& operator=(const AugmentedLagrangianiLQR&) = delete;
 
-  SolverStats& GetStats() { return stats_; }
-  SolverOptions& GetOptions() { return opts_; }
-  SolverStatus GetStatus() const { return status_; }
-  ilqr::iLQR<n, m>& GetiLQRSolver() { return *ilqr_; }
-  int NumSegments() const { return N_; }
-  int NumConstraints() const { return altro_num_constraints(h_); }
-  int NumConstraints(int k) const { return altro_num_constraints_at(h_, k); }
-  altro_handle Handle() { return h_; }
-
-  void SetTrajectory(std::shared_ptr<Trajectory<n, m>> traj) {
-    traj_ = std::move(traj);
-    ilqr_->MarkTrajectoryDirty();
+  void InitializeFromProblem(const problem::Problem& prob, int dtype = ALTRO_F64, int device_id = 0) {  // al_solver.hpp:239-251
+    ilqr_solver_.InitializeFromProblem(BuildAugLagProblem<n, m>(prob), dtype, device_id);
   }
-  void SetPenalty(double rho) { detail::Check(h_, altro_set_penalty(h_, rho), "altro_set_penalty"); }
-  void SetPenaltyScaling(double phi) { detail::Check(h_, altro_set_penalty_scaling(h_, phi), "altro_set_penalty_scaling"); }
+
+  SolverStats& GetStats() { return ilqr_solver_.GetStats(); }
+  SolverOptions& GetOptions() { return ilqr_solver_.GetOptions(); }
+  SolverStatus GetStatus() const { return status_; }
+  ilqr::iLQR<n, m>& GetiLQRSolver() { return ilqr_solver_; }
+  int NumSegments() const { return ilqr_solver_.NumSegments(); }
+  int BatchSize() const { return ilqr_solver_.BatchSize(); }
+  altro_handle Handle() { return ilqr_solver_.Handle(); }
+  // al_solver.hpp:253-271 ("Cannot query the number of constraints before initializing the solver with a problem.")
+  int NumConstraints() const { return altro_num_constraints(ilqr_solver_.Handle()); }
+  int NumConstraints(int k) const { return altro_num_constraints_at(ilqr_solver_.Handle(), k); }
+
+  void SetTrajectory(std::shared_ptr<Trajectory<n, m>> traj) { ilqr_solver_.SetTrajectory(std::move(traj)); }
+  void SetPenalty(double rho) { detail::Check(Handle(), altro_set_penalty(Handle(), rho), "altro_set_penalty"); }
+  void SetPenaltyScaling(double phi) { detail::Check(Handle(), altro_set_penalty_scaling(Handle(), phi), "altro_set_penalty_scaling"); }
 
   void Solve() {  // al_solver.hpp:304-334
-    ilqr_->MarkTrajectoryDirty();
-    ilqr_->Push();
-    detail::Check(h_, altro_solve_al(h_), "altro_solve_al");
-    ilqr_->Pull(true);
-    status_ = static_cast<SolverStatus>(stats_.instances[0].status);
+    ilqr_solver_.MarkTrajectoryDirty();  // the caller may have refilled the shared trajectory (auglag_test.cpp:366)
+    ilqr_solver_.Push();
+    detail::Check(Handle(), altro_solve_al(Handle()), "altro_solve_al");
+    ilqr_solver_.Pull(true, true);
+    status_ = ilqr_solver_.StatusAL();
   }
-  void UpdateDuals() { detail::Check(h_, altro_update_duals(h_), "altro_update_duals"); }
-  void UpdatePenalties() { detail::Check(h_, altro_update_penalties(h_), "altro_update_penalties"); }
-  double MaxViolation(int b = 0) {
-    std::vector<double> v(B_);
-    detail::Check(h_, altro_max_violation(h_, v.data()), "altro_max_violation");
+  void UpdateDuals() { detail::Check(Handle(), altro_update_duals(Handle()), "altro_update_duals"); }
+  void UpdatePenalties() { detail::Check(Handle(), altro_update_penalties(Handle()), "altro_update_penalties"); }
+  double MaxViolation(int b = 0) {  // al_solver.hpp:403-408: evaluates the cost first
+    ilqr_solver_.Push();
+    std::vector<double> v(BatchSize());
+    detail::Check(Handle(), altro_max_violation(Handle(), v.data()), "altro_max_violation");
     return v[b];
   }
   double GetMaxViolation(int b = 0) {
-    std::vector<double> v(B_);
-    detail::Check(h_, altro_get_max_violation(h_, v.data()), "altro_get_max_violation");
+    std::vector<double> v(BatchSize());
+    detail::Check(Handle(), altro_get_max_violation(Handle(), v.data()), "altro_get_max_violation");
     return v[b];
   }
   double GetMaxPenalty(int b = 0) {
-    std::vector<double> v(B_);
-    detail::Check(h_, altro_get_max_penalty(h_, v.data()), "altro_get_max_penalty");
+    std::vector<double> v(BatchSize());
+    detail::Check(Handle(), altro_get_max_penalty(Handle(), v.data()), "altro_get_max_penalty");
     return v[b];
   }
   std::vector<double> GetDuals() {
-    std::vector<double> lam((size_t)B_ * NumConstraints());
-    if (!lam.empty()) detail::Check(h_, altro_get_duals(h_, lam.data()), "altro_get_duals");
+    std::vector<double> lam((size_t)BatchSize() * NumConstraints());
+    if (!lam.empty()) detail::Check(Handle(), altro_get_duals(Handle(), lam.data()), "altro_get_duals");
     return lam;
   }
+
+  // al_solver.hpp:83-104: label, knot index and violation vector c - Pi_K(c) of every constraint of instance b,
+  // from the constraint values the last evaluation left on the device; optionally sorted by max violation.
+  std::vector<constraints::ConstraintInfo> GetConstraintInfo(bool should_sort = false, int b = 0) {
+    const int R = NumConstraints();
+    std::vector<double> c((size_t)BatchSize() * R);
+    if (!c.empty()) detail::Check(Handle(), altro_get_constraint_values(Handle(), c.data()), "altro_get_constraint_values");
+    std::vector<constraints::ConstraintInfo> coninfo;
+    const auto& cons = ilqr_solver_.CorePtr()->cons;
+    size_t row = (size_t)b * R;
+    for (int k = 0; k <= NumSegments(); ++k)
+      for (const examples::ConstraintDesc& cd : cons[k]) {
+        constraints::ConstraintInfo info;
+        info.label = cd.label;
+        info.index = k;
+        info.type = cd.GetConstraintType();
+        const int p = cd.OutputDimension();
+        for (int i = 0; i < p; ++i, ++row) info.violation.push_back(cd.IsEquality() ? c[row] : std::max(c[row], 0.0));
+        coninfo.push_back(std::move(info));
+      }
+    if (should_sort)
+      std::stable_sort(coninfo.begin(), coninfo.end(), [](const constraints::ConstraintInfo& a, const constraints::ConstraintInfo& b2) {
+        return a.MaxViolation() > b2.MaxViolation();
+      });
+    return coninfo;
+  }
+  void PrintViolations(bool should_sort = false, int precision = 4, FILE* f = stdout) {  // al_solver.hpp:68-81
+    const std::vector<constraints::ConstraintInfo> coninfo = GetConstraintInfo(should_sort);
+    std::fprintf(f, "Got %zu constraints\n", coninfo.size());
+    for (const constraints::ConstraintInfo& info : coninfo) std::fprintf(f, "%s\n", info.ToString(precision).c_str());
+  }
+
   // Non-blocking Solve() for the MPC pattern (docs/Overview.dox:48-54): SolveAsync() returns at once, the
   // caller prepares the next problem, Wait() blocks and refreshes the trajectory and the statistics.
   void SolveAsync() {
-    ilqr_->MarkTrajectoryDirty();
-    ilqr_->Push();
-    detail::Check(h_, altro_solve_al_async(h_), "altro_solve_al_async");
+    ilqr_solver_.MarkTrajectoryDirty();
+    ilqr_solver_.Push();
+    detail::Check(Handle(), altro_solve_al_async(Handle()), "altro_solve_al_async");
   }
   bool Poll() {
     int done = 0;
-    detail::Check(h_, altro_solve_poll(h_, &done), "altro_solve_poll");
+    detail::Check(Handle(), altro_solve_poll(Handle(), &done), "altro_solve_poll");
     return done != 0;
   }
   void Wait() {
-    detail::Check(h_, altro_wait(h_), "altro_wait");
-    ilqr_->Pull(true);
-    status_ = static_cast<SolverStatus>(stats_.instances[0].status);
+    detail::Check(Handle(), altro_wait(Handle()), "altro_wait");
+    ilqr_solver_.Pull(true, true);
+    status_ = ilqr_solver_.StatusAL();
   }
   altro_timing GetTiming() {
     altro_timing t;
-    detail::Check(h_, altro_get_timing(h_, &t), "altro_get_timing");
+    detail::Check(Handle(), altro_get_timing(Handle(), &t), "altro_get_timing");
     return t;
   }
   // Prints the device timing of the last solve (needs SolverOptions::profiler_enable) as a tree in the
@@ -616,13 +880,8 @@ class AugmentedLagrangianiLQR {
   }
 
  private:
-  int N_, B_;
-  altro_handle h_ = nullptr;
-  SolverOptions opts_;
-  SolverStats stats_;
+  ilqr::iLQR<n, m> ilqr_solver_;
   SolverStatus status_ = SolverStatus::kUnsolved;
-  std::shared_ptr<Trajectory<n, m>> traj_;
-  std::unique_ptr<ilqr::iLQR<n, m>> ilqr_;
 };
 }  // namespace augmented_lagrangian
 

@@ -1,5 +1,6 @@
 // altro/problems.hpp — C++ problem factories, counterparts of the reference's
-// examples/problems/unicycle.{hpp,cpp} and examples/problems/triple_integrator.hpp, on the facade.
+// examples/problems/unicycle.{hpp,cpp} and examples/problems/triple_integrator.hpp, on the facade, plus the
+// seeded synthetic batches of the BASELINE configs.
 #pragma once
 
 #include <cmath>
@@ -12,11 +13,25 @@
 namespace altro {
 namespace problems {
 
+constexpr unsigned long long kSeedBase = 20260927ULL;  // + BASELINE config number (1-based), SURVEY.md section 8(d)
+
 inline std::vector<double> Diag(int n, double v) {
   std::vector<double> M((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) M[i + (size_t)i * n] = v;
   return M;
 }
+
+// Uniform doubles from std::mt19937_64, a + (b - a) * (x >> 11) * 2^-53: the standard fixes the engine's
+// sequence but not the distributions, so the mapping is spelled out; altro-cpp_amd/problems.py draws the same
+// numbers (class Mt19937_64), and the Python binding, bench.py and these drivers solve the same batches.
+class SeededUniform {
+ public:
+  explicit SeededUniform(unsigned long long seed) : gen_(seed) {}
+  double operator()(double a, double b) { return a + (b - a) * (static_cast<double>(gen_() >> 11) * 0x1p-53); }
+
+ private:
+  std::mt19937_64 gen_;
+};
 
 // examples/problems/unicycle.hpp:22-81, unicycle.cpp:11-89
 class UnicycleProblem {
@@ -68,11 +83,11 @@ class UnicycleProblem {
       }
       lb = {0, -3};
       ub = {3, +3};
-      if (add_constraints) {  // obstacles first: first in the inequality list (unicycle.cpp:55-59)
-        examples::CircleConstraint obs;
-        obs.SetBatchObstacles(circles, 9);
-        for (int k = 1; k < N; ++k) prob.SetConstraint(obs, k);
-      }
+      // the obstacles are registered whatever add_constraints says, and before the bounds: first in the
+      // inequality list (unicycle.cpp:55-59); a plain iLQR ignores them (ilqr.hpp:117-119)
+      examples::CircleConstraint obs;
+      obs.SetBatchObstacles(circles, 9);
+      for (int k = 1; k < N; ++k) prob.SetConstraint(obs, k);
     }
     const std::vector<double> uref = {0, 0};
     for (int k = 0; k < N; ++k) prob.SetCostFunction(examples::QuadraticCost::LQRCost(Q, R, xf, uref), k);
@@ -98,17 +113,50 @@ class UnicycleProblem {
     return Z;
   }
 
-  // Seeded synthetic batch of BASELINE config 3 (instance 0 = the reference problem)
-  void MakeTurn90Batch(int B, unsigned long long seed = 20260930ULL) {
+  // unicycle.hpp:94-109: an iLQR solver on the plain costs, or (alcost) on the AL cost with rho = 1, lambda = 0;
+  // the trajectory is installed and rolled out
+  ilqr::iLQR<3, 2> MakeSolver(bool alcost = false) {
+    problem::Problem prob = MakeProblem();
+    if (alcost) prob = augmented_lagrangian::BuildAugLagProblem<3, 2>(prob);
+    ilqr::iLQR<3, 2> solver(prob);
+    solver.SetTrajectory(InitialTrajectory());
+    solver.Rollout();
+    return solver;
+  }
+  // unicycle.hpp:111-121
+  std::unique_ptr<augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>> MakeALSolver() {
+    problem::Problem prob = MakeProblem(true);
+    auto solver = std::make_unique<augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>>(prob);
+    solver->SetTrajectory(InitialTrajectory());
+    solver->GetiLQRSolver().Rollout();
+    return solver;
+  }
+
+  // Seeded synthetic batch of BASELINE configs[2] (instance 0 = the reference problem): per-instance goals
+  void MakeTurn90Batch(int B, unsigned long long seed = kSeedBase + 3) {
+    SetScenario(kTurn90);
     batch = B;
-    std::mt19937_64 gen(seed);
-    std::uniform_real_distribution<double> dxy(-0.5, 0.5), dth(-0.3, 0.3);
+    SeededUniform U(seed);
     xf.assign((size_t)B * 3, 0.0);
     for (int b = 0; b < B; ++b) {
-      xf[3 * b + 0] = 1.5 + (b ? dxy(gen) : 0.0);
-      xf[3 * b + 1] = 1.5 + (b ? dxy(gen) : 0.0);
-      xf[3 * b + 2] = M_PI / 2 + (b ? dth(gen) : 0.0);
+      xf[3 * b + 0] = 1.5 + (b ? U(-0.5, 0.5) : 0.0);
+      xf[3 * b + 1] = 1.5 + (b ? U(-0.5, 0.5) : 0.0);
+      xf[3 * b + 2] = M_PI / 2 + (b ? U(-0.3, 0.3) : 0.0);
     }
+  }
+  // BASELINE configs[3]: the three reference circles with centres jittered by +-0.1 per instance
+  void MakeThreeObstaclesBatch(int B, unsigned long long seed = kSeedBase + 4) {
+    SetScenario(kThreeObstacles);
+    batch = B;
+    SeededUniform U(seed);
+    circles.assign((size_t)B * 9, 0.0);
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < 3; ++i) {
+        const double c = 0.25 * (i + 1) * 3.0;
+        circles[9 * b + 3 * i + 0] = c + (b ? U(-0.1, 0.1) : 0.0);
+        circles[9 * b + 3 * i + 1] = c + (b ? U(-0.1, 0.1) : 0.0);
+        circles[9 * b + 3 * i + 2] = 0.425;
+      }
   }
 
  private:
@@ -122,11 +170,13 @@ class TripleIntegratorProblem {
   static constexpr int NStates = 6;
   static constexpr int NControls = 2;
   int N = 10;
+  int batch = 1;
   float h = 0.1f;
-  std::vector<double> xf = {1, 2, 0, 0, 0, 0};
-  std::vector<double> x0 = {-1, -2, 0, 0, 0, 0};
+  std::vector<double> xf = {1, 2, 0, 0, 0, 0};   // [6] or [batch][6]
+  std::vector<double> x0 = {-1, -2, 0, 0, 0, 0};  // [6] or [batch][6]
   problem::Problem MakeProblem(bool add_constraints = false) {
     problem::Problem prob(N);
+    prob.SetBatch(batch);
     const std::vector<double> uref = {0, 0};
     for (int k = 0; k < N; ++k)
       prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(6, 1.0), Diag(2, 1e-3), xf, uref), k);
@@ -141,9 +191,63 @@ class TripleIntegratorProblem {
     return prob;
   }
   std::shared_ptr<Trajectory<6, 2>> InitialTrajectory() const {
-    auto Z = std::make_shared<Trajectory<6, 2>>(N, 1);
+    auto Z = std::make_shared<Trajectory<6, 2>>(N, batch);
     Z->SetUniformStep(h);
     return Z;
+  }
+  // BASELINE configs[1]: 51 knots, xf[0:2] ~ U([0.5, 2]^2), x0 = -xf, instance 0 = the reference problem
+  void MakeBatch(int B, unsigned long long seed = kSeedBase + 2) {
+    N = 50;
+    batch = B;
+    SeededUniform U(seed);
+    xf.assign((size_t)B * 6, 0.0);
+    x0.assign((size_t)B * 6, 0.0);
+    for (int b = 0; b < B; ++b) {
+      xf[6 * b + 0] = b ? U(0.5, 2.0) : 1.0;
+      xf[6 * b + 1] = b ? U(0.5, 2.0) : 2.0;
+      for (int i = 0; i < 6; ++i) x0[6 * b + i] = -xf[6 * b + i];
+    }
+  }
+};
+
+// BASELINE configs[4]: the build-defined 12-state / 4-control model (no reference counterpart), hover to hover
+class Quadrotor12Problem {
+ public:
+  static constexpr int NStates = 12;
+  static constexpr int NControls = 4;
+  int N = 200;
+  int batch = 1;
+  float h = 0.02f;
+  std::vector<double> xf_pos = {1.0, -1.0, 0.5};  // [3] or [batch][3]
+  problem::Problem MakeProblem() {
+    problem::Problem prob(N);
+    prob.SetBatch(batch);
+    std::vector<double> xf((size_t)batch * 12, 0.0);
+    for (int b = 0; b < batch; ++b)
+      for (int i = 0; i < 3; ++i) xf[12 * b + i] = xf_pos[3 * (xf_pos.size() > 3 ? b : 0) + i];
+    const std::vector<double> uref(4, 0.0);
+    for (int k = 0; k < N; ++k)
+      prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(12, 1e-2 * h), Diag(4, 1e-2 * h), xf, uref), k);
+    prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(12, 100.0), Diag(4, 0.0), xf, uref, true), N);
+    const problem::DiscretizedModel<examples::Quadrotor12> model{examples::Quadrotor12()};
+    for (int k = 0; k < N; ++k) prob.SetDynamics(model, k);
+    for (int k = 0; k < N; ++k) prob.SetConstraint(examples::ControlBound({-5, -3, -3, -3}, {5, 3, 3, 3}), k);
+    prob.SetConstraint(examples::GoalConstraint(xf, 12), N);
+    prob.SetInitialState(std::vector<double>(12, 0.0));
+    return prob;
+  }
+  std::shared_ptr<Trajectory<12, 4>> InitialTrajectory() const {
+    auto Z = std::make_shared<Trajectory<12, 4>>(N, batch);
+    Z->SetUniformStep(h);
+    return Z;
+  }
+  void MakeBatch(int B, unsigned long long seed = kSeedBase + 5) {
+    batch = B;
+    SeededUniform U(seed);
+    xf_pos.assign((size_t)B * 3, 0.0);
+    const double first[3] = {1.0, -1.0, 0.5};
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < 3; ++i) xf_pos[3 * b + i] = b ? U(-2.0, 2.0) : first[i];
   }
 };
 

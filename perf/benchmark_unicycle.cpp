@@ -15,6 +15,7 @@ static double SolveUnicycleLoop(int nruns) {  // perf/benchmark_unicycle.cpp:46-
   def.SetScenario(problems::UnicycleProblem::kThreeObstacles);
   problem::Problem prob = def.MakeProblem(true);
   augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> solver(prob);
+  solver.GetiLQRSolver().SetRecordCostToGo(false);  // timing run: lets the persistent tail kernel take the solve
   auto traj = def.InitialTrajectory();
   solver.SetTrajectory(traj);
   double best = 1e30;

@@ -1,0 +1,267 @@
+// tests/cpp/facade_reference_tests.cpp — the reference's own gtest cases for the hot path, replayed through
+// the C++ facade (include/altro/) on the MI355X solver.  Each CASE cites the test it replays; the expected
+// values are the reference's constants (tests/golden/reference_constants.json holds the same data).
+//   build: make -C tests/cpp        run: tests/cpp/facade_reference_tests   (needs a GPU; exit code = failures)
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "altro/problems.hpp"
+
+using namespace altro;
+
+static int g_failed = 0, g_checks = 0;
+#define EXPECT(cond)                                                                   \
+  do {                                                                                 \
+    ++g_checks;                                                                        \
+    if (!(cond)) {                                                                     \
+      ++g_failed;                                                                      \
+      std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);                  \
+    }                                                                                  \
+  } while (0)
+#define CASE(name) std::printf("[ RUN ] %s\n", name)
+
+static bool IsApprox(const std::vector<double>& a, const std::vector<double>& b, double prec) {
+  // Eigen::isApprox: ||a - b|| <= prec * min(||a||, ||b||)
+  double d = 0, na = 0, nb = 0;
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); ++i) {
+    d += (a[i] - b[i]) * (a[i] - b[i]);
+    na += a[i] * a[i];
+    nb += b[i] * b[i];
+  }
+  return std::sqrt(d) <= prec * std::sqrt(std::min(na, nb));
+}
+
+// ---- test/ilqr/unicycle_ilqr_test.cpp ----------------------------------------------------------------------
+static void UnicycleiLQRTest() {
+  problems::UnicycleProblem def;
+  CASE("UnicycleiLQRTest.BuildProblem (unicycle_ilqr_test.cpp:27-30)");
+  EXPECT(def.MakeProblem().IsFullyDefined());
+
+  CASE("UnicycleiLQRTest.Initialization (:32-37)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver();
+    solver.Rollout();
+    EXPECT(std::abs(solver.Cost() - 259.27636137767087) < 1e-5);
+  }
+  CASE("UnicycleiLQRTest.BackwardPass (:39-54)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver();
+    solver.Rollout();
+    solver.UpdateExpansions();
+    solver.BackwardPass();
+    EXPECT(IsApprox(solver.GetKnotPointFunction(0).GetCostToGoGradient(),
+                    {0.024904637422419617, -0.46496022574032614, -0.0573096310550007}, 1e-5));
+    EXPECT(IsApprox(solver.GetKnotPointFunction(0).GetFeedforwardGain(), {-2.565783457444465, 5.514158930898376}, 1e-5));
+    // KnotPointFunctions::GetCostExpansion (knot_point_function_type.hpp:249): lxx of a stage knot is Q = 1e-2 h I
+    const auto ce = solver.GetKnotPointFunction(3).GetCostExpansion();
+    const double q = 1e-2 * (double)def.GetTimeStep();
+    EXPECT(std::abs(ce.dxdx()[0] - q) < 1e-15 && std::abs(ce.dxdx()[4] - q) < 1e-15 && ce.dxdx()[1] == 0.0);
+    EXPECT(ce.dudu().size() == 4 && std::abs(ce.dudu()[3] - q) < 1e-15 && ce.dx().size() == 3 && ce.du().size() == 2);
+  }
+  CASE("UnicycleiLQRTest.ForwardPass (:56-65)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver();
+    solver.Rollout();
+    solver.UpdateExpansions();
+    solver.BackwardPass();
+    const double J0 = solver.Cost();
+    solver.ForwardPass();
+    EXPECT(solver.Cost() < J0);
+    EXPECT(solver.GetStats().alpha[0] == 0.0625);
+  }
+  CASE("UnicycleiLQRTest.TwoSteps (:67-88)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver();
+    solver.Rollout();
+    solver.UpdateExpansions();
+    solver.BackwardPass();
+    solver.ForwardPass();
+    solver.UpdateExpansions();
+    solver.BackwardPass();
+    EXPECT(IsApprox(solver.GetKnotPointFunction(0).GetCostToGoGradient(),
+                    {-0.0015143873973949232, -0.07854630832127288, -0.017945283678268698}, 1e-5));
+    EXPECT(IsApprox(solver.GetKnotPointFunction(0).GetFeedforwardGain(), {0.21887571453613042, 1.3097976615154625}, 1e-5));
+    solver.ForwardPass();
+    EXPECT(solver.Cost() - 62.773696055304384 < 1e-5);
+  }
+  CASE("UnicycleiLQRTest.FullSolve (:90-100)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver();
+    solver.Solve();
+    EXPECT(solver.GetStats().iterations_inner == 9);
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved);
+    EXPECT(std::abs(solver.Cost() - 0.0387016567) < 1e-5);
+    EXPECT(solver.GetStats().gradient.back() < solver.GetOptions().gradient_tolerance);
+    // the vectors hold one row per iteration plus the row NewIteration opened (solver_stats.cpp:54-66)
+    EXPECT(solver.GetStats().alpha.size() == 10 && solver.GetStats().cost.size() == 10);
+    EXPECT(solver.GetStats().alpha[0] == 0.0625);
+  }
+  CASE("UnicycleiLQRTest.AugLagForwardPass (:102-113)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver(true);
+    solver.Rollout();
+    solver.UpdateExpansions();
+    solver.BackwardPass();
+    const double J0 = solver.Cost();
+    solver.ForwardPass();
+    EXPECT(solver.Cost() < J0);
+    EXPECT(solver.GetStats().alpha[0] == 0.0625);
+  }
+  CASE("UnicycleiLQRTest.AugLagFullSolve (:115-144)");
+  {
+    ilqr::iLQR<3, 2> solver = def.MakeSolver(true);
+    solver.Solve();
+    EXPECT(solver.GetStats().iterations_inner == 10);
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved);
+    EXPECT(std::abs(solver.Cost() - 0.03893427133384412) / 0.03893427133384412 < 1e-6);
+  }
+}
+
+// ---- test/augmented_lagrangian/auglag_test.cpp ---------------------------------------------------------------
+static void AugLagTest() {
+  problems::UnicycleProblem def;
+  const int N = def.N;
+  CASE("AugLagTest.InitializeAndSolve (auglag_test.cpp:325-351)");
+  {
+    problem::Problem prob = def.MakeProblem();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> alsolver(N);
+    bool threw = false;
+    try {
+      alsolver.NumConstraints();  // "Cannot query the number of constraints before initializing the solver ..."
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    alsolver.InitializeFromProblem(prob);
+    EXPECT(alsolver.NumConstraints() == 4 * N + 3 && alsolver.NumConstraints(0) == 4 && alsolver.NumConstraints(N) == 3);
+    auto Z = def.InitialTrajectory();
+    alsolver.SetTrajectory(Z);
+    alsolver.GetOptions().constraint_tolerance = 1e-6;
+    alsolver.Solve();
+    EXPECT(alsolver.GetStats().iterations_total == 14);
+    EXPECT(alsolver.GetStats().iterations_outer == 5);
+    EXPECT(std::abs(alsolver.GetiLQRSolver().Cost() - 0.03893465058924039) < 1e-12);
+    EXPECT(alsolver.GetStatus() == SolverStatus::kSolved);
+    EXPECT(alsolver.GetMaxViolation() < alsolver.GetOptions().constraint_tolerance);
+    // SolverStats vectors: one row per inner iteration + the open row; violations / max_penalty per AL iteration
+    EXPECT(alsolver.GetStats().cost.size() == 15);
+    EXPECT(alsolver.GetStats().max_penalty.back() == 1e4);
+  }
+  CASE("AugLagTest.SolveTwice (:353-380)");
+  {
+    problem::Problem prob = def.MakeProblem();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> alsolver(N);
+    alsolver.InitializeFromProblem(prob);
+    auto Z = def.InitialTrajectory();
+    alsolver.SetTrajectory(Z);
+    alsolver.GetOptions().constraint_tolerance = 1e-6;
+    alsolver.Solve();
+    *Z = *def.InitialTrajectory();
+    alsolver.Solve();
+    EXPECT(alsolver.GetStats().iterations_total == 14);
+    EXPECT(alsolver.GetStats().iterations_outer == 5);
+    EXPECT(std::abs(alsolver.GetiLQRSolver().Cost() - 0.03893465058924039) < 1e-12);
+    EXPECT(alsolver.GetStatus() == SolverStatus::kSolved);
+  }
+  CASE("AugLagTest.PrintViolations (:382-399)");
+  {
+    problem::Problem prob = def.MakeProblem();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> alsolver(N);
+    alsolver.InitializeFromProblem(prob);
+    alsolver.SetTrajectory(def.InitialTrajectory());
+    alsolver.Solve();
+    std::vector<constraints::ConstraintInfo> coninfo = alsolver.GetConstraintInfo();
+    EXPECT((int)coninfo.size() == N + 1);
+    EXPECT(coninfo[0].index == 0);
+    EXPECT(coninfo[0].label == "Control Bound");
+    EXPECT(coninfo[0].type == "Inequality Constraint" && coninfo[0].violation.size() == 4);
+    coninfo = alsolver.GetConstraintInfo(/*sort=*/true);
+    EXPECT(coninfo[0].index == alsolver.NumSegments());
+    EXPECT(coninfo[0].label == "Goal Constraint");
+    EXPECT(std::abs(coninfo[0].MaxViolation() - alsolver.GetMaxViolation()) < 1e-15);
+    alsolver.PrintViolations(true, 4, stdout);
+  }
+  CASE("AugLagTest.TwoSolves (:249-287): second inner solve after a dual and penalty update takes one iteration");
+  {
+    auto alsolver = def.MakeALSolver();
+    alsolver->GetiLQRSolver().Solve();
+    EXPECT(alsolver->GetiLQRSolver().GetStats().iterations_inner == 10);
+    EXPECT(std::abs(alsolver->GetMaxViolation() - 0.00017691645708972636) / 0.00017691645708972636 < 1e-6);
+    alsolver->UpdateDuals();
+    alsolver->UpdatePenalties();
+    alsolver->GetiLQRSolver().Solve();
+    EXPECT(alsolver->GetiLQRSolver().GetStats().iterations_inner == 1);
+    EXPECT(std::abs(alsolver->MaxViolation() - 6.26e-5) / 6.26e-5 < 0.1);
+  }
+}
+
+// ---- test/examples/example_unicycle_test.cpp, example_triple_integrator_test.cpp ---------------------------------
+static void ExampleTests() {
+  CASE("ExampleUnicycle three obstacles (example_unicycle_test.cpp:18-50, 69-89)");
+  {
+    problems::UnicycleProblem def;
+    def.SetScenario(problems::UnicycleProblem::kThreeObstacles);
+    ilqr::iLQR<3, 2> plain = def.MakeSolver();
+    EXPECT(std::abs(plain.Cost() - 133.1151550141444) < 1e-6);
+    ilqr::iLQR<3, 2> al = def.MakeSolver(true);
+    EXPECT(std::abs(al.Cost() - 141.9639680271223) < 1e-6);
+    auto solver = def.MakeALSolver();
+    solver->SetPenalty(10.0);
+    EXPECT(std::abs(solver->GetiLQRSolver().Cost() - 221.6032851439234) < 1e-6);
+    solver->Solve();
+    EXPECT(solver->GetStatus() == SolverStatus::kSolved);
+    EXPECT(solver->MaxViolation() < 1e-4);
+    EXPECT(solver->GetStats().cost_decrease.back() < 1e-4);
+    EXPECT(solver->GetStats().gradient.back() < 1e-2);
+    EXPECT(solver->GetStats().iterations_total == 50 && solver->GetStats().iterations_outer == 5);
+  }
+  CASE("ExampleTripleIntegrator (example_triple_integrator_test.cpp:16-70)");
+  {
+    problems::TripleIntegratorProblem def;
+    augmented_lagrangian::AugmentedLagrangianiLQR<6, 2> uncon(def.MakeProblem(false));
+    uncon.SetTrajectory(def.InitialTrajectory());
+    uncon.Solve();
+    EXPECT(uncon.GetStats().iterations_total == 2 && uncon.GetStatus() == SolverStatus::kSolved);
+    augmented_lagrangian::AugmentedLagrangianiLQR<6, 2> con(def.MakeProblem(true));
+    auto Z = def.InitialTrajectory();
+    con.SetTrajectory(Z);
+    con.Solve();
+    EXPECT(con.GetStatus() == SolverStatus::kSolved);
+    EXPECT(con.MaxViolation() < 1e-4);
+    EXPECT(std::abs(Z->Control(0)[0] - 100.0) < 1e-6 && std::abs(Z->Control(0)[1] - 200.0) < 1e-6);
+    EXPECT(std::abs(Z->Control(def.N - 1)[0] - 100.0) < 1e-6 && std::abs(Z->Control(def.N - 1)[1] - 200.0) < 1e-6);
+  }
+  CASE("Facade: calls before the trajectory exists keep the problem usable (ADVICE r1: step set late)");
+  {
+    problems::UnicycleProblem def;
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> solver(def.MakeProblem());
+    EXPECT(solver.NumConstraints(0) == 4);  // creates the device state before any trajectory / step is known
+    EXPECT(solver.GetDuals().size() == (size_t)solver.NumConstraints());
+    bool threw = false;
+    try {
+      solver.GetiLQRSolver().Rollout();  // no trajectory, hence no step: refused, not integrated with h = 0
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    solver.SetTrajectory(def.InitialTrajectory());
+    solver.Solve();
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.GetStats().iterations_total == 11);
+  }
+}
+
+int main() {
+  try {
+    UnicycleiLQRTest();
+    AugLagTest();
+    ExampleTests();
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 100;
+  }
+  std::printf("%d checks, %d failed\n", g_checks, g_failed);
+  return g_failed;
+}

@@ -10,9 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_benchmark_unicycle_driver():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "perf"), "benchmark_unicycle"])
     exe = os.path.join(ROOT, "perf", "benchmark_unicycle")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "perf")])
     r = subprocess.run([exe, "2", "256"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     # kThreeObstacles through the facade: 50 iLQR iterations in 5 AL iterations, kSolved
@@ -27,3 +26,46 @@ def test_benchmark_unicycle_driver():
     tree = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s*(\w+)\s+(\d+)\s+\d+\s+\d+\s*$", r.stdout, re.M)}
     assert {"al", "ilqr", "backward_pass", "expansions", "forward_pass", "sweep_fused", "init"} <= set(tree)
     assert tree["al"] > 0 and tree["ilqr"] > 0 and tree["ilqr"] <= tree["al"] * 1.05
+
+
+def _build(dirname, exe):
+    path = os.path.join(ROOT, dirname, exe)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, dirname), exe])
+    return path
+
+
+@pytest.mark.gpu
+def test_reference_gtests_through_the_facade():
+    """tests/cpp/facade_reference_tests.cpp: the reference's own gtest cases for the hot path
+    (unicycle_ilqr_test.cpp:27-144, auglag_test.cpp:249-399, example_*_test.cpp) replayed through the facade."""
+    exe = _build(os.path.join("tests", "cpp"), "facade_reference_tests")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert re.search(r"(\d+) checks, 0 failed", r.stdout)
+    assert "Goal Constraint at index 100" in r.stdout  # PrintViolations(sort = true), al_solver.hpp:68-81
+
+
+@pytest.mark.gpu
+def test_benchmark_triple_integrator_driver():
+    exe = _build("perf", "benchmark_triple_integrator")
+    r = subprocess.run([exe, "2", "1024"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    # example_triple_integrator_test.cpp:16-70: 2 iterations unconstrained; constrained solve reaches the tolerance
+    assert re.search(r"Unconstrained triple integrator: iters = 2, outer = 1, status = 0", r.stdout), r.stdout
+    m = re.search(r"Constrained triple integrator: iters = (\d+), outer = (\d+), status = 0, violation = ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(3)) < 1e-4, r.stdout
+    assert re.search(r"batch 1024 run 1: .* solved 1024/1024, 2048 instance-iterations", r.stdout), r.stdout
+    assert "Description                  Time (us)   %Total  %Parent" in r.stdout
+
+
+@pytest.mark.gpu
+def test_benchmark_expansions_driver():
+    exe = _build("perf", "benchmark_expansions")
+    r = subprocess.run([exe, "20"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = re.findall(r"batch\s+(\d+): UpdateExpansions\s+([0-9.]+) us per call", r.stdout)
+    assert [int(b) for b, _ in rows] == [1, 64, 1024, 4096, 16384], r.stdout
+    # batching is the point: 4096 instances cost far less than 4096 single-instance calls
+    t = {int(b): float(us) for b, us in rows}
+    assert t[4096] < 50 * t[1]

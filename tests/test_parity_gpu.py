@@ -225,10 +225,7 @@ def _config5_sensitivity(P, A, oracle_make, oracle_lib, batch):
     dK ~ 3e-3 norm-wise, dX ~ 5e-7).  Returns the oracle solve and the max-norm spread of X, U, K, d over
     three perturbed solves: the yardstick the GPU is compared against, instead of an asserted tolerance."""
     import ctypes
-    rng = np.random.default_rng(P.SEED_BASE + 5)
-    pos = np.tile(np.array([1.0, -1.0, 0.5]), (batch, 1))
-    if batch > 1:
-        pos[1:] = rng.uniform(-2.0, 2.0, (batch - 1, 3))
+    pos = P.batch_quadrotor12_goals(batch)
 
     def run(xf_pos):
         s = P.quadrotor12(oracle_make, batch=batch, dtype=A.F64, xf_pos=xf_pos)
