@@ -418,7 +418,9 @@ class Engine final : public EngineBase {
   // wavefront), everything else on the one-lane-per-instance VALU kernel.
   // The MFMA backward pass computes in fp64 whatever the storage type of the engine is
   static constexpr bool kMfmaBackward = n == 3 && m == 2;
-  // larger models: one instance per wavefront, matrices in LDS (k_backward_coop)
+  // larger models: one instance per wavefront -- on the 16x16x4 fp64 matrix cores (k_backward_mfma16), or with
+  // the matrices in LDS and the products on the vector ALUs (k_backward_coop: ALTRO_HIP_BACKWARD=coop)
+  static constexpr bool kMfma16Backward = n > 4 && n <= 12 && m <= 4;
   static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
@@ -427,6 +429,15 @@ class Engine final : public EngineBase {
           hipLaunchKernelGGL((k_backward_mfma<T, M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
         else
           hipLaunchKernelGGL((k_backward_mfma<T, M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+        return;
+      }
+    }
+    if constexpr (kMfma16Backward) {
+      if (!force_valu_backward_ && !force_coop_backward_ && mfma_offsets_ok_) {
+        if (A.record_ctg)
+          hipLaunchKernelGGL((k_backward_mfma16<T, M, true>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
+        else
+          hipLaunchKernelGGL((k_backward_mfma16<T, M, false>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
         return;
       }
     }
@@ -1142,7 +1153,13 @@ class Engine final : public EngineBase {
   double* d_tmp_ = nullptr;
   int* d_list_[2] = {nullptr, nullptr};
   bool mfma_offsets_ok_ = false;
-  bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr;
+  // ALTRO_HIP_BACKWARD = valu | coop selects a fallback backward kernel (tests); ALTRO_HIP_VALU_BACKWARD: legacy
+  static bool BackwardEnvIs(const char* what) {
+    const char* e = std::getenv("ALTRO_HIP_BACKWARD");
+    return e && std::string(e) == what;
+  }
+  bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
+  bool force_coop_backward_ = BackwardEnvIs("coop");
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;

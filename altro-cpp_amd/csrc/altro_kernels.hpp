@@ -854,6 +854,311 @@ __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<T> A, DevOpt
 }
 
 // -------------------------------------------------------------------------------------------------
+// iLQR::BackwardPass on the 16x16x4 fp64 matrix cores for the larger models (4 < n <= 12, m <= 4: the
+// 2-dof triple integrator and the 12-state model of BASELINE configs[4]): ONE INSTANCE PER WAVEFRONT, every
+// matrix of the Riccati step a 16 x 16 tile spread over the 64 lanes.
+//
+// v_mfma_f64_16x16x4_f64 (lane layout confirmed on gfx950 by scripts/probes/mfma_f64_16x16_probe.hip): with
+// r = lane / 16, c = lane % 16, the A operand holds A[i = c][k = r], the B operand B[k = r][j = c], and the
+// result D[i][j] sits in lane (r = i % 4, c = j), register i / 4.  A tile kept in that "D form" (register v of
+// lane (r, c) = X[r + 4 v][c]) is therefore chunk v of the RIGHT operand of a later product as it stands, and
+// the same register passed as the LEFT operand means chunk v of X^T.  With
+//     prod(X, Z) = X^T Z = sum over the row chunks v of mfma(X[v], Z[v], .)
+// the recursion of knot_point_function_type.hpp:149-235 chains through the matrix cores with no lane shuffle,
+// vectors riding along as column n of the tiles, exactly like the 4 x 4 kernel above:
+//     W_A = prod([P|p], A) = P A (+ a row p^T A that only ever meets zero rows), W_B = prod([P|p], B)
+//     [Qxx|Qx] = [lxx|lx] + prod(A, [W_A|p])    [Qux|Qu] = [lux|lu] + prod(B, [W_A|p])    Quu = luu + prod(B, W_B)
+//     [K|d] = prod(-(Quu + rho I)^-1, [Qux|Qu])          (gains from the REGULARISED Quu, quirk Q3)
+//     G = prod(Quu, [K|d])                               (un-regularised)
+//     [P|p] = [Qxx|Qx] + prod([Qux|Qu], [K|d]) + prod([K|d], [Qux|Qu]) + prod([K|d], G)
+// Products contract over the rows of both operands: ceil(n / 4) instructions when those are state rows, ONE when
+// they are control rows (m <= 4): 5 * 3 + 5 = 20 matrix instructions per knot for n = 12 (64 cycles each) instead
+// of ~36 kflop on the vector ALUs through LDS (k_backward_coop: ~4 us per knot).  The m x m Cholesky
+// factorisation (the reference's failure verdict: a pivot <= 0) and the inverse are computed by every lane from an
+// LDS broadcast of Quu, each lane solving for its own column.  Tile loads run a block of knots ahead of the
+// recursion; the gains are buffered in LDS and written out every kM16Chunk knots.
+// -------------------------------------------------------------------------------------------------
+typedef double mfma16_acc __attribute__((ext_vector_type(4)));
+constexpr int kM16Ahead = 2;   // knots per prefetch block
+constexpr int kM16Chunk = 32;  // knots of gains buffered in LDS between two bulk stores
+
+template <class T, class M, bool CTG>
+__global__ __launch_bounds__(kBlock) void k_backward_mfma16(DevArrays<T> A, DevOpts o, int all) {
+  constexpr int n = M::n, m = M::m;
+  static_assert(n > 4 && n <= 12 && m >= 1 && m <= 4, "16x16 MFMA backward pass: 4 < n <= 12 (one spare column for the vectors), m <= 4");
+  using R = Rec<T, n, m>;
+  using RS = rec_scalar_t<T, M>;
+  using RR = Rec<RS, n, m>;
+  constexpr int RC = (n + 3) / 4;  // row chunks of a state-sized tile
+  const int lane = threadIdx.x;
+  const int r = lane >> 4, c = lane & 15;
+  const int b = instance_of_slot(A, blockIdx.x, all);
+  if (b < 0) return;  // uniform
+  const int N = A.N;
+  const unsigned Bp = A.Bp;
+  __shared__ double sKD[kM16Chunk * RR::KP];
+  __shared__ double sQ[16];
+
+  // ---- tile element owned by this lane in register v (byte offset inside the expansion record; the lanes that
+  //      own a structural zero read the zeroed pad record behind knot N with stride 0) ----
+  // 32-bit BYTE offsets from the start of the front pad (kBwdFrontPad records in front of knot 0, which the
+  // last, unused prefetch block may touch): a load is scalar base + vector offset, a cursor step one subtraction
+  constexpr unsigned kES = (unsigned)sizeof(RS);
+  const unsigned strideB = Bp * (unsigned)RR::EP * kES;
+  const unsigned frontB = (unsigned)kBwdFrontPad * strideB;
+  const unsigned zoff = frontB + (unsigned)(N + 1) * strideB;
+  const unsigned rec0 = frontB + (unsigned)b * (unsigned)RR::EP * kES;
+  const char* __restrict__ Eb = reinterpret_cast<const char*>(A.EXP) - (size_t)frontB;
+  auto ldE = [&](unsigned off) __attribute__((always_inline)) -> double {
+    return (double)*reinterpret_cast<const RS*>(Eb + off);
+  };
+  static_assert(2 * kM16Ahead <= kBwdFrontPad, "the prefetch may run two blocks below knot 0");
+  for (int i = lane; i < kM16Chunk * RR::KP; i += kBlock) sKD[i] = 0.0;  // record padding is stored too
+  constexpr int NT = 3 * RC + 2;  // tile registers per knot: A, B, [lxx|lx] (RC each), [lux|lu], luu
+  unsigned base[NT], step[NT];
+#pragma unroll
+  for (int v = 0; v < RC; ++v) {
+    const int row = r + 4 * v;
+    const int eA = (row < n && c < n) ? R::oAB + row + c * n : -1;
+    const int eB = (row < n && c < m) ? R::oAB + n * n + row + c * n : -1;
+    const int e1 = (row < n) ? (c < n ? R::oLxx + row + c * n : (c == n ? R::oLx + row : -1)) : -1;
+    base[v] = eA >= 0 ? rec0 + kES * eA : zoff;
+    step[v] = eA >= 0 ? strideB : 0u;
+    base[RC + v] = eB >= 0 ? rec0 + kES * eB : zoff;
+    step[RC + v] = eB >= 0 ? strideB : 0u;
+    base[2 * RC + v] = e1 >= 0 ? rec0 + kES * e1 : zoff;
+    step[2 * RC + v] = e1 >= 0 ? strideB : 0u;
+  }
+  {
+    const int e2 = (r < m) ? (c < n ? R::oLxu + c + r * n : (c == n ? R::oLu + r : -1)) : -1;  // [lux | lu]
+    const int e3 = (r < m && c < m) ? R::oLuu + r + c * m : -1;
+    base[3 * RC] = e2 >= 0 ? rec0 + kES * e2 : zoff;
+    step[3 * RC] = e2 >= 0 ? strideB : 0u;
+    base[3 * RC + 1] = e3 >= 0 ? rec0 + kES * e3 : zoff;
+    step[3 * RC + 1] = e3 >= 0 ? strideB : 0u;
+  }
+  const int offKD = (r < m) ? (c < n ? R::oK + r + c * m : (c == n ? R::oD + r : -1)) : -1;  // [K | d], register 0
+  struct Tiles {
+    double t[NT];
+  };
+  unsigned cur[NT];
+  auto issue = [&](Tiles& S) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      S.t[i] = ldE(cur[i]);
+      cur[i] -= step[i];  // past knot 0 the cursor walks into the front pad (those tiles are never used)
+    }
+  };
+
+  // running cost in knot order (ilqr.hpp:326-334)
+  double J0 = 0.0;
+  for (int kb = 0; kb <= N; kb += kBlock) {
+    const int kk = kb + lane;
+    const double v = (double)A.costs[(unsigned)(kk <= N ? kk : N) * Bp + (unsigned)b];
+    for (int j = 0; j < kBlock && kb + j <= N; ++j) J0 += __shfl(v, j);
+  }
+  double rho = A.rho_reg[b], drho = A.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
+  int max_reg_count = 0;
+  int status = A.status[b];
+  bool need = N > 0;
+
+  auto mfma = [](double a, double bb, mfma16_acc acc) __attribute__((always_inline)) -> mfma16_acc {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+  };
+  const mfma16_acc zero4 = {0.0, 0.0, 0.0, 0.0};
+
+  while (need) {
+    // CalcTerminalCostToGo (knot_point_function_type.hpp:135-138): [P|p] = [lxx|lx] of knot N
+    double Pp[RC];
+#pragma unroll
+    for (int v = 0; v < RC; ++v) Pp[v] = ldE(base[2 * RC + v] + (unsigned)N * step[2 * RC + v]);
+    if (CTG) {
+#pragma unroll
+      for (int v = 0; v < RC; ++v) {
+        const int row = r + 4 * v;
+        if (row < n && c <= n) RECP(A.CTG, N, R::CP)[c < n ? R::oP + row + c * n : R::op + row] = (T)Pp[v];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) cur[i] = base[i] + (unsigned)(N - 1) * step[i];
+    Tiles Sa[kM16Ahead], Sb[kM16Ahead];
+#pragma unroll
+    for (int j = 0; j < kM16Ahead; ++j) issue(Sa[j]);
+    bool failed = false;
+    int slot = 0, k_top = N - 1;
+    auto flush = [&]() __attribute__((always_inline)) {
+      RS* const KDp = (RS*)A.KD;
+      for (int i = lane; i < slot * RR::KP; i += kBlock) {
+        const int sl = i / RR::KP, e = i - sl * RR::KP;
+        KDp[((size_t)(unsigned)(k_top - sl) * Bp + (unsigned)b) * RR::KP + e] = (RS)sKD[i];
+      }
+      k_top -= slot;
+      slot = 0;
+    };
+    // one knot; returns false on a failed factorisation
+    auto knot = [&](int k, const Tiles& S) __attribute__((always_inline)) -> bool {
+      const double* tA = S.t;
+      const double* tB = S.t + RC;
+      const double* t1 = S.t + 2 * RC;
+      const double t2 = S.t[3 * RC], t3 = S.t[3 * RC + 1];
+      // W_A = P A, W_B = P B (contraction over the state rows of [P|p] and of A / B)
+      mfma16_acc WA = zero4, WB = zero4;
+#pragma unroll
+      for (int v = 0; v < RC; ++v) {
+        WA = mfma(Pp[v], tA[v], WA);
+        WB = mfma(Pp[v], tB[v], WB);
+      }
+      // [W_A | p]: column n takes the vector
+      double Waug[RC];
+#pragma unroll
+      for (int v = 0; v < RC; ++v) Waug[v] = (c < n) ? WA[v] : Pp[v];
+      mfma16_acc Q2 = {t2, 0.0, 0.0, 0.0}, Q3 = {t3, 0.0, 0.0, 0.0}, Q1;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Q1[v] = v < RC ? t1[v < RC ? v : 0] : 0.0;
+#pragma unroll
+      for (int v = 0; v < RC; ++v) {
+        Q3 = mfma(tB[v], WB[v], Q3);    // Quu
+        Q2 = mfma(tB[v], Waug[v], Q2);  // [Qux | Qu]
+      }
+#pragma unroll
+      for (int v = 0; v < RC; ++v) Q1 = mfma(tA[v], Waug[v], Q1);  // [Qxx | Qx] (not needed before the cost-to-go)
+      // ---- (Quu + rho I)^-1: broadcast the m x m block through LDS, factorise redundantly ----
+      if (r < m && c < m) sQ[r + c * 4] = Q3[0];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double L[m * m], Linv[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int i = 0; i < m; ++i) L[i + j * m] = sQ[i + j * 4];
+#pragma unroll
+      for (int i = 0; i < m; ++i) L[i + i * m] += rho;
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < m; ++j) {  // Eigen::LLT (lower): a pivot <= 0 is a failure
+        double xjj = L[j + j * m];
+#pragma unroll
+        for (int l = 0; l < j; ++l) xjj = fma(-L[j + l * m], L[j + l * m], xjj);
+        if (xjj <= 0.0) ok = false;
+        const double li = rsqrt_nr(ok ? xjj : 1.0);
+        Linv[j] = li;
+        L[j + j * m] = xjj * li;
+#pragma unroll
+        for (int i = j + 1; i < m; ++i) {
+          double sacc = L[i + j * m];
+#pragma unroll
+          for (int l = 0; l < j; ++l) sacc = fma(-L[i + l * m], L[j + l * m], sacc);
+          L[i + j * m] = sacc * li;
+        }
+      }
+      if (!ok) return false;  // uniform: every lane factorised the same matrix
+      // column c of the inverse (each lane its own right-hand side e_c), then this lane's row
+      double x[m];
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        double sacc = (c == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = 0; l < i; ++l) sacc = fma(-L[i + l * m], x[l], sacc);
+        x[i] = sacc * Linv[i];
+      }
+#pragma unroll
+      for (int i = m - 1; i >= 0; --i) {
+        double sacc = x[i];
+#pragma unroll
+        for (int l = i + 1; l < m; ++l) sacc = fma(-L[l + i * m], x[l], sacc);
+        x[i] = sacc * Linv[i];
+      }
+      double mine = 0.0;
+#pragma unroll
+      for (int i = 0; i < m; ++i) mine = (r == i) ? x[i] : mine;
+      const double MinvNeg = (r < m && c < m) ? -mine : 0.0;
+      // [K | d] and Quu [K | d]: contraction over the control rows, one instruction each
+      const mfma16_acc KDt = mfma(MinvNeg, Q2[0], zero4);
+      const mfma16_acc G = mfma(Q3[0], KDt[0], zero4);
+      // [P|p] = [Qxx|Qx] + Qux^T [K|d] + K^T [Qux|Qu] + K^T Quu [K|d]
+      mfma16_acc Pn = mfma(Q2[0], KDt[0], Q1);
+      Pn = mfma(KDt[0], Q2[0], Pn);
+      Pn = mfma(KDt[0], G[0], Pn);
+#pragma unroll
+      for (int v = 0; v < RC; ++v) Pp[v] = Pn[v];
+      // expected cost decrease: column n, rows < m hold d; every lane accumulates, rows are added after the sweep
+      dV0 = fma(KDt[0], Q2[0], dV0);
+      dV1 = fma(KDt[0], G[0], dV1);
+      if (offKD >= 0) sKD[slot * RR::KP + offKD] = KDt[0];
+      if (CTG) {
+#pragma unroll
+        for (int v = 0; v < RC; ++v) {
+          const int row = r + 4 * v;
+          if (row < n && c <= n) RECP(A.CTG, k, R::CP)[c < n ? R::oP + row + c * n : R::op + row] = (T)Pn[v];
+        }
+      }
+      ++slot;
+      return true;
+    };
+    int k = N - 1;
+    auto block = [&](Tiles* Cur, Tiles* Nxt) __attribute__((always_inline)) -> int {  // 1 go on, 0 reached knot 0, -1 failed
+#pragma unroll
+      for (int j = 0; j < kM16Ahead; ++j) {
+        if (!knot(k - j, Cur[j])) return -1;
+        if (j == 0) {
+#pragma unroll
+          for (int jj = 0; jj < kM16Ahead; ++jj) issue(Nxt[jj]);
+        }
+        if (k - j == 0) return 0;
+      }
+      k -= kM16Ahead;
+      if (slot + kM16Ahead > kM16Chunk) flush();
+      return 1;
+    };
+    int res;
+    for (;;) {
+      res = block(Sa, Sb);
+      if (res != 1) break;
+      res = block(Sb, Sa);
+      if (res != 1) break;
+    }
+    if (res < 0) {
+      // ilqr.hpp:409-427: raise the regularisation and restart the sweep.  What the expected decrease has
+      // accumulated so far stays (quirk Q4) -- including this knot's share: the reference adds it only after a
+      // successful factorisation, and knot() returns before touching dV0 / dV1 on failure.
+      increase_reg(o, &rho, &drho);
+      if (rho >= o.bp_reg_max) max_reg_count++;
+      if (max_reg_count >= o.bp_reg_fail_threshold) {
+        status = ALTRO_BACKWARD_PASS_REGULARIZATION_FAILED;
+        need = false;
+      }
+      failed = true;
+    }
+    flush();
+    if (!failed) need = false;  // sweep completed
+  }
+  // d^T Qu, d^T Quu d: rows 0 .. m-1 of column n
+  {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+      a0 += __shfl(dV0, 16 * i + n);
+      a1 += __shfl(dV1, 16 * i + n);
+    }
+    dV0 = a0;
+    dV1 = 0.5 * a1;
+  }
+  if (lane != 0) return;
+  A.J0[b] = J0;
+  if (A.need_init_cost[b]) {
+    A.initial_cost[b] = J0;
+    A.need_init_cost[b] = 0;
+  }
+  A.reg_log[b] = rho;  // stats_.Log("reg", rho_)
+  decrease_reg(o, &rho, &drho);
+  A.rho_reg[b] = rho;
+  A.drho[b] = drho;
+  A.dV0[b] = dV0;
+  A.dV1[b] = dV1;
+  A.status[b] = status;
+}
+
+// -------------------------------------------------------------------------------------------------
 // iLQR::Rollout (ilqr.hpp:453-459), one lane per instance
 // -------------------------------------------------------------------------------------------------
 template <class T, class M>

@@ -1,6 +1,7 @@
-"""The three backward-pass kernels (MFMA: n = 3, m = 2; cooperative one-instance-per-wavefront: n >= 6;
-one-lane-per-instance VALU: fallback, forced with ALTRO_HIP_VALU_BACKWARD) against each other and against
-the oracle, including the restart-on-Cholesky-failure schedule of ilqr.hpp:409-427 on every one of them."""
+"""The backward-pass kernels -- MFMA 4x4x4 (n = 3, m = 2), MFMA 16x16x4 (n = 6 and n = 12: the default there),
+cooperative one-instance-per-wavefront on the vector ALUs (ALTRO_HIP_BACKWARD=coop), one-lane-per-instance
+VALU (ALTRO_HIP_BACKWARD=valu) -- against each other and against the oracle, including the
+restart-on-Cholesky-failure schedule of ilqr.hpp:409-427 on every one of them."""
 import os
 import subprocess
 import sys
@@ -99,30 +100,39 @@ def _child(tmp_path, tag, env_extra):
 @pytest.fixture(scope="module")
 def variants(tmp_path_factory):
     d = tmp_path_factory.mktemp("bwd")
-    return _child(d, "default", {}), _child(d, "valu", {"ALTRO_HIP_VALU_BACKWARD": "1"})
+    return (_child(d, "default", {}), _child(d, "coop", {"ALTRO_HIP_BACKWARD": "coop"}),
+            _child(d, "valu", {"ALTRO_HIP_BACKWARD": "valu"}))
 
 
 def test_coop_backward_is_bitwise_the_valu_backward(variants):
     """k_backward_coop performs the operations of riccati_q / riccati_gains in the same order and type
     (altro_kernels.hpp, header of k_backward_coop): n = 6 and n = 12 engines must return the same bits
     whichever of the two kernels ran."""
-    coop, valu = variants
+    _, coop, valu = variants
     for k in coop.files:
         if k.startswith(("ti_", "quad_", "restart_triple", "restart_quad")):
             assert np.array_equal(coop[k], valu[k]), k
 
 
-def test_mfma_backward_agrees_with_valu_on_the_restart_schedule(variants):
-    mfma, valu = variants
-    for f in ("status", "iterations_total", "regularization"):
-        assert np.array_equal(mfma["restart_unicycle_" + f], valu["restart_unicycle_" + f]), f
-    assert np.allclose(mfma["restart_unicycle_X"], valu["restart_unicycle_X"], rtol=1e-6, atol=1e-8)
+def test_mfma_backward_agrees_with_valu(variants):
+    """The matrix-core kernels (4x4x4 for the unicycle, 16x16x4 for n = 6 / 12) associate the products differently
+    from the vector-ALU kernels: same schedule (iteration counts, statuses, regularisation), values to rounding."""
+    mfma, _, valu = variants
+    for tag in ("restart_unicycle", "restart_triple_integrator", "restart_quadrotor12", "ti_ilqr", "ti_al", "quad_al"):
+        for f in ("status", "iterations_total", "regularization"):
+            assert np.array_equal(mfma[f"{tag}_{f}"], valu[f"{tag}_{f}"]), (tag, f)
+    for tag in ("restart_unicycle", "restart_triple_integrator", "restart_quadrotor12", "ti_ilqr", "ti_al"):
+        assert np.allclose(mfma[tag + "_X"], valu[tag + "_X"], rtol=1e-6, atol=1e-8), tag
+    # one backward pass of the 12-state model from the same expansions: gains and cost-to-go of all 200 knots
+    for key, tol in (("quad_step_K", 1e-9), ("quad_step_d", 1e-9), ("quad_step_P", 1e-10), ("quad_step_p", 1e-10)):
+        a, b = mfma[key], valu[key]
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (key, np.abs(a - b).max(), np.abs(b).max())
 
 
 @pytest.mark.parametrize("name", list(RESTART))
 def test_cholesky_restart_against_oracle(A, oracle_make, variants, name):
-    """ilqr.hpp:409-427 on every backward kernel: default (MFMA for the unicycle, cooperative for n = 6 / 12)
-    and the VALU fallback, against the oracle in fp64."""
+    """ilqr.hpp:409-427 on every backward kernel: default (MFMA 4x4x4 for the unicycle, MFMA 16x16x4 for
+    n = 6 / 12), cooperative and VALU, against the oracle in fp64."""
     o = RESTART[name](A, oracle_make)
     o.set_options(max_iterations_inner=4)
     o.solve_ilqr()
