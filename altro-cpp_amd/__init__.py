@@ -95,6 +95,27 @@ def load_library(path=None):
     return _lib_cache[path]
 
 
+MODEL_USER_BASE = 1000
+
+
+def register_model_source(name, source, check_jacobian=True, _lib=None, _prefix="altro_"):
+    """User-defined dynamics (altro_register_model_source, include/altro_hip.h): `source` defines
+    ``struct UserModel { static constexpr int n, m; f(x, u, xdot); jac(x, u, J); }``.  Compiles (or loads from the
+    on-disk cache) the plugin and returns the model kind for ``BatchSolver.set_model``."""
+    lib = _lib if _lib is not None else load_library()
+    f = getattr(lib, _prefix + "register_model_source")
+    f.restype = C.c_int
+    kind = C.c_int(0)
+    st = f(name.encode(), source.encode(), C.c_int(1 if check_jacobian else 0), C.byref(kind))
+    if st != OK:
+        g = getattr(lib, _prefix + "last_error")
+        g.restype = C.c_char_p
+        g.argtypes = [C.c_void_p]
+        msg = g(None)
+        raise AltroError(f"{_prefix}register_model_source failed ({st}): {msg.decode() if msg else ''}")
+    return kind.value
+
+
 def _dp(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 

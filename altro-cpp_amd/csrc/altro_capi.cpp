@@ -3,19 +3,32 @@
 // Records the problem definition exactly as the reference's altro::problem::Problem setters do,
 // creates the device engine lazily on the first compute call, and forwards every entry point.
 // No exception crosses the boundary; there is NO CPU fallback.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <random>
+#include <sstream>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "altro_common.hpp"
 
 using namespace altro_hip;
+
+#define ALTRO_USER_PLUGIN_ABI_HOST 2  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -49,6 +62,63 @@ struct altro_solver_s {
 };
 
 static thread_local std::string g_create_error;
+
+// ---- user-model plugins (altro_register_model_source; see altro_user_model.hpp) ---------------------------------
+namespace {
+struct UserModelEntry {
+  std::string name, so_path;
+  void* dl = nullptr;
+  int n = 0, m = 0;
+  EngineBase* (*make)(const altro_desc*, std::string*) = nullptr;
+  int (*check)(int, const double*, int, double, double*) = nullptr;
+  bool checked = false;
+  uint64_t hash = 0;
+};
+std::mutex g_models_mu;
+std::vector<UserModelEntry> g_models;  // kind = ALTRO_MODEL_USER_BASE + index
+
+uint64_t Fnv1a(const std::string& s, uint64_t h = 1469598103934665603ULL) {
+  for (unsigned char ch : s) {
+    h ^= ch;
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+bool ReadFile(const std::string& path, std::string* out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  *out = ss.str();
+  return true;
+}
+std::string Tail(const std::string& s, size_t n) { return s.size() > n ? s.substr(s.size() - n) : s; }
+
+// FunctionBase::CheckJacobian (functionbase.cpp:35-73) on the device: 64 points uniform in [-1, 1]^(n+m)
+// (VectorXd::Random), forward differences with 1e-6, tolerance kDefaultTolerance = 1e-4 (functionbase.hpp:86)
+altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) {
+  if (e.checked) return ALTRO_OK;
+  const int samples = 64, nm = e.n + e.m;
+  std::mt19937_64 gen(e.hash);
+  std::vector<double> z((size_t)samples * nm);
+  for (double& v : z) v = -1.0 + 2.0 * (static_cast<double>(gen() >> 11) * 0x1p-53);
+  double max_err = 0.0;
+  const int rc = e.check(device, z.data(), samples, 1e-6, &max_err);
+  if (rc != 0) {
+    *err = "user model '" + e.name + "': the Jacobian check could not run on the device (code " + std::to_string(rc) + ")";
+    return ALTRO_HIP_ERROR;
+  }
+  if (!(max_err < 1e-4)) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "user model '%s': jac() does not match finite differences of f(): ||J_fd - J|| = %.3g >= 1e-4 "
+             "(FunctionBase::CheckJacobian)", e.name.c_str(), max_err);
+    *err = buf;
+    return ALTRO_INVALID_ARG;
+  }
+  e.checked = true;
+  return ALTRO_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -122,7 +192,24 @@ altro_status Ensure(altro_handle h) {
         e = f64 ? MakeEngineQuad12F64(d, &err) : MakeEngineQuad12F32(d, &err);
         break;
       default:
-        err = "altro_set_model has not been called";
+        if (h->spec.model_kind >= ALTRO_MODEL_USER_BASE) {
+          std::lock_guard<std::mutex> lk(g_models_mu);
+          const size_t idx = (size_t)(h->spec.model_kind - ALTRO_MODEL_USER_BASE);
+          if (idx >= g_models.size()) {
+            err = "unknown user model kind (altro_register_model_source returns the kind)";
+            break;
+          }
+          UserModelEntry& um = g_models[idx];
+          if (um.n != d.n || um.m != d.m) {
+            err = "state/control dimensions do not match the user model";
+            break;
+          }
+          // the Jacobian check runs once per model, at registration or -- registered without a device -- here
+          if (CheckUserJacobian(um, d.device_id, &err) != ALTRO_OK) break;
+          e = um.make(&d, &err);
+        } else {
+          err = "altro_set_model has not been called";
+        }
         break;
     }
     if (!e) {
@@ -165,6 +252,123 @@ altro_status DefChanged(altro_handle h) {
 }  // namespace
 
 extern "C" {
+
+altro_status altro_register_model_source(const char* name, const char* source, int check_jacobian, int* kind_out) {
+  if (!name || !source || !kind_out) return ALTRO_INVALID_ARG;
+  std::string& err = g_create_error;
+  // the engine headers live next to the library (in-tree: altro-cpp_amd/csrc); ALTRO_HIP_INCLUDE_DIR overrides
+  std::string inc;
+  if (const char* e = std::getenv("ALTRO_HIP_INCLUDE_DIR")) {
+    inc = e;
+  } else {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void*>(&altro_create), &info) || !info.dli_fname) {
+      err = "cannot locate libaltro_hip.so (dladdr)";
+      return ALTRO_HIP_ERROR;
+    }
+    inc = info.dli_fname;
+    const size_t slash = inc.find_last_of('/');
+    inc = slash == std::string::npos ? "." : inc.substr(0, slash);
+  }
+  std::string hdrs;
+  for (const char* f : {"altro_common.hpp", "altro_device.hpp", "altro_kernels.hpp", "altro_engine.hpp", "altro_user_model.hpp",
+                        "../../include/altro_hip.h"}) {
+    std::string txt;
+    if (!ReadFile(inc + "/" + f, &txt)) {
+      err = std::string("engine header ") + f + " not found in " + inc + " (set ALTRO_HIP_INCLUDE_DIR)";
+      return ALTRO_NOT_READY;
+    }
+    hdrs += txt;
+  }
+  std::string arch = "gfx950";
+  if (const char* e = std::getenv("ALTRO_HIP_ARCH")) {
+    arch = e;
+  } else {
+    hipDeviceProp_t p;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDeviceProperties(&p, 0) == hipSuccess) {
+      arch = p.gcnArchName;
+      arch = arch.substr(0, arch.find(':'));
+    }
+  }
+  const std::string flags = "-O3 -std=c++17 -fPIC -shared -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value "
+                            "-Wno-unused-result --offload-arch=" + arch;
+  const uint64_t hash = Fnv1a(flags, Fnv1a(hdrs, Fnv1a(source)));
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  for (size_t i = 0; i < g_models.size(); ++i)
+    if (g_models[i].hash == hash) {  // same source, same library: already loaded
+      *kind_out = ALTRO_MODEL_USER_BASE + (int)i;
+      return ALTRO_OK;
+    }
+  std::string cache = inc + "/_user_cache";
+  if (const char* e = std::getenv("ALTRO_HIP_CACHE_DIR")) cache = e;
+  mkdir(cache.c_str(), 0755);
+  char hx[32];
+  snprintf(hx, sizeof(hx), "%016llx", (unsigned long long)hash);
+  const std::string stem = cache + "/altro_user_" + hx;
+  const std::string so = stem + ".so";
+  if (access(so.c_str(), R_OK) != 0) {
+    const std::string src = stem + ".hip", log = stem + ".log", tmp = stem + "." + std::to_string((long)getpid()) + ".tmp.so";
+    {
+      std::ofstream f(src);
+      f << "// generated by altro_register_model_source for the user model '" << name << "'\n"
+        << "#include \"altro_engine.hpp\"\n#define ALTRO_MODEL_FN __device__ __forceinline__\n"
+        << "namespace altro_user {\n#line 1 \"user model " << name << "\"\n" << source << "\n}  // namespace altro_user\n"
+        << "#include \"altro_user_model.hpp\"\n";
+      if (!f) {
+        err = "cannot write " + src + " (set ALTRO_HIP_CACHE_DIR to a writable directory)";
+        return ALTRO_NOT_READY;
+      }
+    }
+    std::string hipcc = "/opt/rocm/bin/hipcc";
+    if (const char* e = std::getenv("HIPCC")) hipcc = e;
+    const std::string cmd = hipcc + " " + flags + " -I'" + inc + "' -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
+    const int rc = std::system(cmd.c_str());
+    if (rc != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
+      std::string out;
+      ReadFile(log, &out);
+      err = "compiling the user model '" + std::string(name) + "' failed:\n" + Tail(out, 1500);
+      unlink(tmp.c_str());
+      return ALTRO_INVALID_ARG;
+    }
+  }
+  UserModelEntry e;
+  e.name = name;
+  e.so_path = so;
+  e.hash = hash;
+  e.dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!e.dl) {
+    err = std::string("dlopen of the user-model plugin failed: ") + dlerror();
+    return ALTRO_HIP_ERROR;
+  }
+  auto abi = reinterpret_cast<int (*)()>(dlsym(e.dl, "altro_user_abi"));
+  auto dims = reinterpret_cast<void (*)(int*, int*)>(dlsym(e.dl, "altro_user_dims"));
+  e.make = reinterpret_cast<EngineBase* (*)(const altro_desc*, std::string*)>(dlsym(e.dl, "altro_user_make_engine"));
+  e.check = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_jacobian"));
+  if (!abi || !dims || !e.make || !e.check || abi() != ALTRO_USER_PLUGIN_ABI_HOST) {
+    err = "the cached user-model plugin " + so + " does not match this library; delete it";
+    dlclose(e.dl);
+    return ALTRO_HIP_ERROR;
+  }
+  dims(&e.n, &e.m);
+  if (check_jacobian) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {  // without a device the check runs at first use
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) dev = 0;  // clear a sticky "no device selected" state; device 0 is fine
+      altro_status st = CheckUserJacobian(e, dev, &err);
+      if (st != ALTRO_OK) {
+        dlclose(e.dl);
+        return st;
+      }
+    }
+  } else {
+    e.checked = true;  // the caller vouches for the Jacobian
+  }
+  g_models.push_back(e);
+  *kind_out = ALTRO_MODEL_USER_BASE + (int)g_models.size() - 1;
+  return ALTRO_OK;
+}
 
 altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams) {
   if (!h) return ALTRO_INVALID_ARG;

@@ -149,6 +149,33 @@ def quadrotor12(make, batch=1, N=200, dtype=F32, xf_pos=None, **kw):
 
 
 # ---------------------------------------------------------------------------------------------------
+# A user-defined model (tests/models/cartpole.hpp through altro_register_model_source): move the cart
+# ---------------------------------------------------------------------------------------------------
+def cartpole_move(make, model_kind, batch=1, N=60, dtype=F64, goal=None, **kw):
+    """Cart-pole with the pole hanging down: drive the cart to p = goal and come to rest (n = 4, m = 1),
+    force bounded by +-3, goal constraint at the last knot.  ``goal`` may be a scalar or [B]."""
+    n, m = 4, 1
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.05)
+    hd = float(h)
+    goal = np.full(batch, 1.0) if goal is None else np.broadcast_to(np.asarray(goal, dtype=np.float64), (batch,))
+    xf = np.zeros((batch, n))
+    xf[:, 0] = goal
+    Q = np.eye(n) * (1e-1 * hd)
+    R = np.eye(m) * (1e-2 * hd)
+    Qf = np.eye(n) * 100.0
+    s.set_model(model_kind)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, Q, R, xf, np.zeros(m))
+    s.set_lqr_cost(N, N + 1, Qf, R * 0, xf, np.zeros(m))
+    s.add_control_bound(0, N, [-3.0], [3.0])
+    s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
 # Seeded synthetic batches (SURVEY.md section 8(d)); instance 0 = the exact reference problem.
 # The generator is std::mt19937_64 (the C++ facade, include/altro/problems.hpp, draws the same numbers from
 # the standard library's engine), uniform doubles as a + (b - a) * (x >> 11) * 2^-53, one instance after the

@@ -64,7 +64,8 @@ typedef enum altro_dtype { ALTRO_F64 = 0, ALTRO_F32 = 1 } altro_dtype;
 typedef enum altro_model_kind {
   ALTRO_MODEL_UNICYCLE = 1,          /* examples/unicycle.cpp:12-33, n=3 m=2 */
   ALTRO_MODEL_TRIPLE_INTEGRATOR = 2, /* examples/triple_integrator.cpp:9-33, n=3*dof m=dof */
-  ALTRO_MODEL_QUADROTOR12 = 3        /* build-defined 12-state/4-control model (BASELINE config 5) */
+  ALTRO_MODEL_QUADROTOR12 = 3,       /* build-defined 12-state/4-control model (BASELINE config 5) */
+  ALTRO_MODEL_USER_BASE = 1000       /* kinds >= this: user models, see altro_register_model_source */
 } altro_model_kind;
 
 /* Closed registry of constraints (examples/basic_constraints.hpp, obstacle_constraints.hpp). */
@@ -178,6 +179,24 @@ void altro_default_options(altro_options* opts);
 /* Problem::SetDynamics for all k with DiscretizedModel<Model, RungeKutta4> (problem.hpp:155-166).
  * params: TRIPLE_INTEGRATOR -> {dof}; UNICYCLE -> none; QUADROTOR12 -> none. */
 altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams);
+
+/* USER-DEFINED DYNAMICS -- the reference's plug-in surface for models (problem::ContinuousDynamics,
+ * altro/problem/dynamics.hpp:59-95: Evaluate + Jacobian, wrapped in DiscretizedModel<Model, RungeKutta4>,
+ * problem/discretized_model.hpp:24-65).  A kernel cannot call the caller's virtual functions, so the model crosses
+ * this boundary as SOURCE: a translation-unit fragment that defines
+ *     struct UserModel {
+ *       static constexpr int n = ..., m = ...;
+ *       template <class T> ALTRO_MODEL_FN static void f(const T* x, const T* u, T* xdot);
+ *       template <class T> ALTRO_MODEL_FN static void jac(const T* x, const T* u, T* J);   // n x (n+m), column-major
+ *     };
+ * The library compiles it with hipcc for the device's architecture into a plugin that carries every kernel of the
+ * solver instantiated for these dynamics (cached on disk by content hash: first registration ~1 minute, later ones
+ * milliseconds; ALTRO_HIP_CACHE_DIR, default <library dir>/_user_cache), and returns the model kind to pass to
+ * altro_set_model.  check_jacobian != 0 runs the device-side FunctionBase::CheckJacobian
+ * (altro/common/functionbase.cpp:35-73: forward differences, 64 random points, tolerance 1e-4) once -- now if a
+ * device is present, else when the first handle using the model is created; a mismatch is ALTRO_INVALID_ARG.
+ * Errors (compiler output included) are reported through altro_last_error(NULL).  No CPU fallback. */
+altro_status altro_register_model_source(const char* name, const char* source, int check_jacobian, int* kind_out);
 
 /* Trajectory::SetUniformStep (trajectory.hpp:122-130).  hstep > 0.  Belongs to the trajectory, not to the
  * problem definition: may be called at any time (also between solves).  Calls that integrate (rollout,

@@ -119,6 +119,25 @@ struct Quadrotor12Model {
   }
 };
 
+#ifdef ORACLE_USER_MODEL
+// A user model (the source text altro_register_model_source() takes, e.g. tests/models/cartpole.hpp) compiled
+// for the host: the oracle build with -DORACLE_USER_MODEL='"file"' answers model kinds >= ALTRO_MODEL_USER_BASE
+// with it, so that a user model has a CPU reference (tests/test_user_model_gpu.py).
+#define ALTRO_MODEL_FN inline
+namespace altro_user {
+using std::cos;
+using std::sin;
+#include ORACLE_USER_MODEL
+}  // namespace altro_user
+template <class T>
+struct UserModelAdapter {
+  static constexpr int n = altro_user::UserModel::n, m = altro_user::UserModel::m;
+  int dof = 0;
+  void f(const T* x, const T* u, T* xd) const { altro_user::UserModel::f(x, u, xd); }
+  void jac(const T* x, const T* u, T* J) const { altro_user::UserModel::jac(x, u, J); }
+};
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Host-side problem specification (dtype independent, fp64).
 // ------------------------------------------------------------------------------------------------
@@ -1181,6 +1200,10 @@ std::unique_ptr<SolverBase> MakeForModel(oracle_handle h, int b) {
     return MakeInstance<T>(h, b, TripleIntegratorModel<T, 1>());
   if (h->model_kind == ALTRO_MODEL_QUADROTOR12 && D.n == 12 && D.m == 4)
     return MakeInstance<T>(h, b, Quadrotor12Model<T>());
+#ifdef ORACLE_USER_MODEL
+  if (h->model_kind >= ALTRO_MODEL_USER_BASE && D.n == UserModelAdapter<T>::n && D.m == UserModelAdapter<T>::m)
+    return MakeInstance<T>(h, b, UserModelAdapter<T>());
+#endif
   return nullptr;
 }
 
