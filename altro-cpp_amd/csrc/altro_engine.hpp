@@ -421,6 +421,8 @@ class Engine final : public EngineBase {
   // larger models: one instance per wavefront -- on the 16x16x4 fp64 matrix cores (k_backward_mfma16), or with
   // the matrices in LDS and the products on the vector ALUs (k_backward_coop: ALTRO_HIP_BACKWARD=coop)
   static constexpr bool kMfma16Backward = n > 4 && n <= 12 && m <= 4;
+  // gain records big enough (m n + m >= 14 elements) that reading K from global memory can pay: see kdg_
+  static constexpr bool kKdgEligible = n * m >= 12;
   static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
@@ -466,8 +468,14 @@ class Engine final : public EngineBase {
       const int per_wave = (ninst <= num_cus_) ? 1 : fwd_per_wave_;
       const size_t lds = fwd_shared_bytes_ + (size_t)per_wave * fwd_per_inst_bytes_;
       const dim3 grid2((ninst + per_wave - 1) / per_wave);
-      hipLaunchKernelGGL((k_forward2<T, M>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode, all,
-                         per_wave);
+      if (kdg_) {
+        if constexpr (kKdgEligible)
+          hipLaunchKernelGGL((k_forward2<T, M, true>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+                             all, per_wave);
+      } else {
+        hipLaunchKernelGGL((k_forward2<T, M, false>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+                           all, per_wave);
+      }
       return;
     }
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
@@ -931,12 +939,33 @@ class Engine final : public EngineBase {
       fwd_per_inst_bytes_ = per_inst;
       fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
+      kdg_ = false;
+      if constexpr (kKdgEligible) {
+        // Models whose gain records fill the LDS (12-state model: 83 of 134 KB per instance -> one instance per CU):
+        // keep only d in LDS, let the rollout wave read K from global memory one knot ahead, and put up to three
+        // instances into one workgroup (one workgroup per CU, 160 KiB)
+        const size_t per_inst_b = per_inst - (size_t)N_ * R::KP * sizeof(T) + (size_t)N_ * R::mP * sizeof(T);
+        int pw_b = lanes_max;
+        while (pw_b > 1 && shared_bytes + pw_b * per_inst_b > 160 * 1024) pw_b--;
+        if (shared_bytes + per_inst > 80 * 1024 && pw_b > 1 && !std::getenv("ALTRO_HIP_NO_KDG")) {
+          kdg_ = true;
+          fwd_per_wave_ = pw_b;
+          fwd_per_inst_bytes_ = per_inst_b;
+          fwd_lds_bytes_ = shared_bytes + pw_b * per_inst_b;
+        }
+      }
       if (fwd_lds_bytes_ > 160 * 1024) {
         fwd_lds_bytes_ = 0;
         fwd_per_wave_ = lanes_max;
       } else if (fwd_lds_bytes_ > 64 * 1024) {
-        ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+        if (kdg_) {
+          if constexpr (kKdgEligible)
+            ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+        } else {
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+        }
       }
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
@@ -1160,6 +1189,7 @@ class Engine final : public EngineBase {
   }
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
+  bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., true>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;

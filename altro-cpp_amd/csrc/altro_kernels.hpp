@@ -1526,7 +1526,8 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
                               int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
                               int* active_out = nullptr, T* sLamW = nullptr, T* sPenW = nullptr,
-                              double* ff = nullptr) {
+                              double* ff = nullptr, int kd_stride = Rec<T, M::n, M::m>::KP,
+                              int kd_off = Rec<T, M::n, M::m>::oD) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -1548,7 +1549,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
 #pragma unroll
         for (int i = 0; i < m; ++i) {
           using RS = rec_scalar_t<T, M>;
-          const T dv = sKD ? sKD[k * R::KP + R::oD + i]
+          const T dv = sKD ? sKD[k * kd_stride + kd_off + i]
                            : (T)RECP((const RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[R::oD + i];
           const T uv = sU ? sU[k * R::mP + i] : RECP(A.U, k, R::mP)[i];
           mx = max_(mx, abs_(dv) / (abs_(uv) + T(1)));
@@ -2136,11 +2137,10 @@ struct RolloutBounds {
 // checks (RolloutBounds), the gradient measure of the trial (ilqr.hpp:574-583 with the trial's controls)
 // and the candidate store.  None of it feeds the cost, so it runs beside the cost wave.
 template <class T, class M>
-ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, const T* xch, int lane, bool valid, T* candp,
-                                double& gs, RolloutBounds<T>& bnd) {
+ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
+                                bool valid, T* candp, double& gs, RolloutBounds<T>& bnd) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
-  using R = Rec<T, n, m>;
   for (int k = kbegin; k < kend; ++k) {
     lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
     const T* slot = xch + (k & 1) * (nm * kBlock);
@@ -2150,7 +2150,7 @@ ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, const T* xch
 #pragma unroll
     for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
 #pragma unroll
-    for (int i = 0; i < m; ++i) d[i] = sKD[k * R::KP + R::oD + i];
+    for (int i = 0; i < m; ++i) d[i] = sKD[k * kd_stride + kd_off + i];
     bnd.template visit<n, m>(xb, ub);
     // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
     T gnum = T(0), gden = T(1);
@@ -2288,11 +2288,16 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
 }
 
 // Phase 0 of the two-wave forward pass: copy the read-only inputs of up to kBlock / 20 instances into
-// LDS with `nthreads` threads (tt = index of this thread).  with_kd = false leaves the gains alone
-// (the fused sweep kernel has the backward pass write them straight into LDS).
+// LDS with `nthreads` threads (tt = index of this thread).  kd_mode: kKdNone leaves the gains alone (the fused
+// sweep kernel has the backward pass write them straight into LDS); kKdFull stages the whole gain records;
+// kKdFeedforward only d (records of mP elements): the models whose gain records would fill the LDS (n = 12:
+// 83 KB per instance) read K from global memory in the rollout wave instead, so that three instances share a
+// workgroup instead of one.
+enum KdMode { kKdNone = 0, kKdFull = 1, kKdFeedforward = 2 };
 template <class T, class M>
 ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, const FwdLds<T>& L, unsigned char* smem_raw,
-                              T* sPool, int per_wave, int all, int tt, int nthreads, bool with_kd) {
+                              T* sPool, int per_wave, int all, int tt, int nthreads, int kd_mode) {
+  const bool with_kd = kd_mode != kKdNone;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
   const unsigned Bp = A.Bp;
@@ -2307,7 +2312,8 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
     constexpr int VN = R::V;
     const int kStride = nthreads;
     constexpr int D = 2;  // items per thread, array and instance in flight (N = 100: two rounds)
-    const int perX = R::nP / VN, perU = R::mP / VN, perK = R::KP / VN;
+    const int perX = R::nP / VN, perU = R::mP / VN, perK = (kd_mode == kKdFeedforward ? R::mP : R::KP) / VN;
+    const int kd_first = kd_mode == kKdFeedforward ? R::oD : 0;  // first record element that is staged
     const int cX = (N + 1) * perX, cU = N * perU, cK = N * perK, cR = L.nR, cS = L.nS;
     int cmax = (with_kd && cK > cX) ? cK : cX;
     cmax = cmax > cR ? cmax : cR;
@@ -2337,10 +2343,11 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
             using RS = rec_scalar_t<T, M>;
             int vi = i < cK ? i : cK - 1;
             const int k = vi / perK, w = vi - k * perK;
-            const RS* src = RECP((const RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP)) + w * VN;
+            const RS* src = RECP((const RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP)) + kd_first + w * VN;
             T* e = reinterpret_cast<T*>(&vk[g][j]);
 #pragma unroll
-            for (int q = 0; q < VN; ++q) e[q] = (T)src[q];
+            for (int q = 0; q < VN; ++q)  // (d-only: the last vector of the padded block may run past d; never past the record)
+              e[q] = (kd_first + w * VN + q < Rec<RS, M::n, M::m>::KP) ? (T)src[(kd_first + w * VN + q < Rec<RS, M::n, M::m>::KP) ? q : 0] : T(0);
           }
           sl[g][j] = cR > 0 ? SOA(A.lam, i < cR ? i : cR - 1) : T(0);
           sp[g][j] = cR > 0 ? SOA(A.pen, i < cR ? i : cR - 1) : T(0);
@@ -2378,7 +2385,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 // bytes in global memory, for the per-lane (divergent) indexing of phases 2 and 3; indexing the
 // by-value copy that way would force it into scratch.  FUSED: called by k_sweep_fused with the LDS
 // block already filled; fh = {J0, dV0, dV1, initial_cost} handed over in LDS.
-template <class T, class M, bool FUSED>
+template <class T, class M, bool FUSED, bool KDG = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr) {
@@ -2403,7 +2410,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   STAMP(wave * 8 + 0);
 
   // ---- phase 0: stage the instance's read-only inputs in LDS (both waves copy) ------------------
-  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * R::KP, pd->total_rows, pd->nslots, R::V};
+  // KDG: the feedback gains stay in global memory (read by the rollout wave one knot ahead), LDS keeps d only
+  static_assert(!(FUSED && KDG), "the fused kernel keeps the gain records in LDS");
+  constexpr int kKdStride = KDG ? R::mP : R::KP, kKdOff = KDG ? 0 : R::oD;
+  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * kKdStride, pd->total_rows, pd->nslots, R::V};
   T* sm = reinterpret_cast<T*>(smem_raw) + (grp < per_wave ? grp : 0) * L.total();
   T* sX = sm;
   T* sU = sX + L.nX;
@@ -2416,7 +2426,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
-    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock, true);
+    forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock,
+                         KDG ? kKdFeedforward : kKdFull);
     __syncthreads();
   }
   STAMP(wave * 8 + 1);
@@ -2446,7 +2457,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       const int kc = k < N ? k : N - 1;
       load_rec<T, R::nP>(sX + kc * R::nP, q.xk);
       load_rec<T, R::mP>(sU + kc * R::mP, q.uk);
-      load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
+      if constexpr (KDG) {
+        using RS = rec_scalar_t<T, M>;
+        using RR = Rec<RS, n, m>;
+        load_rec_as<T, RS, R::KP, RR::KP, m * n + m>((const RS*)A.KD + ((size_t)(unsigned)kc * (unsigned)A.Bp + (unsigned)b) * RR::KP, q.kd);
+      } else {
+        load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
+      }
     };
     auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
       T ub[m], xn[n];
@@ -2525,7 +2542,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     bnd.check = o.check_forwardpass_bounds != 0;
     bnd.smax2 = T(o.state_max) * T(o.state_max);
     bnd.umax2 = T(o.control_max) * T(o.control_max);
-    aux_consumer_run<T, M>(0, N, sKD, xch, lane, valid, cand_base + tb, gs, bnd);
+    aux_consumer_run<T, M>(0, N, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + tb, gs, bnd);
     lds_barrier();  // barrier N: terminal state
     {
       const T* slot = xch + (N & 1) * (nm * kBlock);
@@ -2661,16 +2678,16 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
-                       FUSED ? sPen : nullptr, FUSED ? ff : nullptr);
+                       FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
   STAMP(8 + 6);
 }
 
-template <class T, class M>
+template <class T, class M, bool KDG>
 __global__ __launch_bounds__(kFwdWaves * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                          const ProblemDesc pd_arg, DevOpts o, int mode, int all,
                                                          int per_wave) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  forward2_body<T, M, false>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
+  forward2_body<T, M, false, KDG>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
 }
 
 // iLQR::UpdateExpansions of one instance by `nthreads` threads, reading the trajectory, multipliers and
@@ -2775,7 +2792,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
     //      forward pass keep the LDS copies current from then on ----
     if (loops == 0) {
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, false);
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, kKdNone);
       __syncthreads();
     }
     // ---- E: expansions from the LDS block ----
