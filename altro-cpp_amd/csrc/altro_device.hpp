@@ -166,9 +166,6 @@ struct DevArrays {
   // host-visible (pinned, mapped) word that receives this launch's instance count: the host sizes the
   // next grid from it without a device-to-host copy in the stream (nullptr: not published)
   int* host_count;
-#ifdef ALTRO_X
-  long long* dbg;
-#endif
   // optional per-iteration history [field][cap][Bp]
   double* hist;
   int* hist_len;

@@ -1031,9 +1031,6 @@ class Engine final : public EngineBase {
       if (rs != ALTRO_OK) return rs;
     }
     ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 4) * sizeof(int), stream_));
-#ifdef ALTRO_X
-    if (!A_.dbg) hipMalloc((void**)&A_.dbg, 32 * sizeof(long long));
-#endif
     for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
     std::vector<char> fused_flag;
@@ -1126,20 +1123,6 @@ class Engine final : public EngineBase {
     }
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     ALTRO_HIP_CHECK(hipGetLastError());
-#ifdef ALTRO_X
-    {
-      long long h[32];
-      hipMemcpy(h, A_.dbg, sizeof(h), hipMemcpyDeviceToHost);
-      fprintf(stderr, "stamps(cycles rel. to wave0 entry): R:");
-      for (int i = 0; i < 5; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
-      fprintf(stderr, "  C:");
-      for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
-      fprintf(stderr, "  B: %lld %lld", h[17] - h[16], h[18] - h[16]);
-      fprintf(stderr, "  FUSED w0[E0 Eend Bend sync]: %lld %lld %lld %lld  w1[Eend Send sync Fend]: %lld %lld %lld %lld\n", h[20] - h[20],
-              h[21] - h[20], h[22] - h[20], h[23] - h[20], h[25] - h[20], h[26] - h[20], h[27] - h[20], h[28] - h[20]);
-      fprintf(stderr, "   w0: stage issued %lld, staged+sync %lld, E computed+stores issued %lld\n", h[29] - h[20], h[30] - h[20], h[31] - h[20]);
-    }
-#endif
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
     if (persistent_launched) {
       int extra[2] = {0, 0};

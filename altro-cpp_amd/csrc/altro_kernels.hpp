@@ -593,13 +593,6 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   const int b = inst_on ? b0 : 0;
   const int N = A.N;
   const unsigned Bp = A.Bp;
-#ifdef ALTRO_X
-  const bool dbg_on = A.dbg && blockIdx.x == 0 && lane == 0 && A.it_total[b] == 60;
-#define BSTAMP(i) if (dbg_on) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
-#else
-#define BSTAMP(i)
-#endif
-  BSTAMP(16);
   // element of each tile this lane owns (offset inside the expansion record; -1: structural zero)
   const int offA = (r < n && c < n) ? R::oAB + r + c * n : -1;
   const int offB = (r < n && c < m) ? R::oAB + n * n + r + c * n : -1;
@@ -697,8 +690,6 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       }
     }
   }
-
-  BSTAMP(17);
   // The gains are collected in LDS and written out in bulk: a store in the loop would share the memory
   // counter with the prefetched tiles (loads and stores retire out of order with respect to each
   // other), and every wait on a tile would have to drain the whole queue.
@@ -809,7 +800,6 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
     need = need && !running;  // instances that reached knot 0 are done
     if (!FUSED) flush();
   }
-  BSTAMP(18);
   {
     double a0, a1;
     rows01(dV0, a0, a1);
@@ -2401,13 +2391,6 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const bool valid = b0 >= 0;
   if (__ballot(valid) == 0ull) return;  // every wave takes the same decision
   const int b = valid ? b0 : 0;
-#ifdef ALTRO_X
-  const bool dbg_on = A.dbg && blockIdx.x == 0 && lane == 0 && A.it_total[b] == 60;
-#define STAMP(i) if (dbg_on) A.dbg[(i)] = (long long)__builtin_readcyclecounter()
-#else
-#define STAMP(i)
-#endif
-  STAMP(wave * 8 + 0);
 
   // ---- phase 0: stage the instance's read-only inputs in LDS (both waves copy) ------------------
   // KDG: the feedback gains stay in global memory (read by the rollout wave one knot ahead), LDS keeps d only
@@ -2430,7 +2413,6 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                          KDG ? kKdFeedforward : kKdFull);
     __syncthreads();
   }
-  STAMP(wave * 8 + 1);
 
   T x0[R::nP];
   load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
@@ -2505,9 +2487,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     T* slot = xch + (N & 1) * (nm * kBlock);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
-    STAMP(2);
     lds_barrier();  // barrier N
-    STAMP(3);
     lds_barrier();  // barrier A (auxiliary wave -> cost wave)
     // phase 2 is shared by all waves: wait for the selection, take every third block of knots
     __syncthreads();  // barrier S
@@ -2603,9 +2583,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
 #undef ALTRO_RUN
   }
-  STAMP(8 + 2);
   lds_barrier();  // barrier N: terminal state and rollout outcome
-  STAMP(8 + 3);
   {
     const T* slot = xch + (N & 1) * (nm * kBlock);
     T xN[n], uz[m];
@@ -2653,7 +2631,6 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     last_status = __shfl(st, grp * LS + (nlive - 1));
     if (ok_g) t_replay = 31 - __clz(ok_g);
   }
-  STAMP(8 + 4);
   // ---- phase 2: copy the winner into Z_, evaluate the c_ it leaves behind; the knots are spread over
   //      the lanes of BOTH waves (the rollout wave has nothing else left to do)
   {
@@ -2675,11 +2652,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   __syncthreads();  // barrier V: the other wave's share of the violation
   if (!valid) return;
   viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
-  STAMP(8 + 5);
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
                        FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
-  STAMP(8 + 6);
 }
 
 template <class T, class M, bool KDG>
@@ -2782,13 +2757,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
   double prev_rho = -1.0, prev_drho = -1.0;
   int skipped = 0;
   int loops = 0;
-#ifdef ALTRO_X
-#define FSTAMP(i) if (A.dbg && blockIdx.x == 0 && lane == 0 && loops == 40) A.dbg[20 + (i)] = (long long)__builtin_readcyclecounter()
-#else
-#define FSTAMP(i)
-#endif
   for (;;) {
-    FSTAMP(wave * 4 + 0);
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
     //      forward pass keep the LDS copies current from then on ----
     if (loops == 0) {
@@ -2802,12 +2771,10 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
       expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kFwdWaves * kBlock);
     }
     __syncthreads();  // drains the stores: the records are in L2 for the backward wave, the costs in LDS
-    FSTAMP(wave * 4 + 1);
 
     if (wave == 0) {
       // ---- B ----
       backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
-      FSTAMP(2);
     } else if (wave == 1) {
       // running cost in knot order (ilqr.hpp:326-334)
       double J0 = 0.0;
@@ -2823,14 +2790,11 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
         fh[0] = J0;
         fh[3] = ic;
       }
-      FSTAMP(4 + 2);
     }
     __syncthreads();
-    FSTAMP(wave * 4 + 3);
 
     // ---- F ----
     forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
-    if (wave == 1) FSTAMP(8);
     ++loops;
     __syncthreads();
     if (!persistent || *active_flag == 0) break;

@@ -1,22 +1,27 @@
-# Profiles for profiles/: kernel trace stats + HBM traffic counters (separate --pmc passes).
+# Profiles for profiles/: kernel-trace stats + HBM traffic / SQ counters (separate --pmc passes) of one bench config.
+#   scripts/gpu_profile.sh [config]      (default 2; output under gpurun_out/profile_c<config>/)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/profile
 export TMPDIR=/tmp
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-rm -rf gpurun_out/profile/*
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profile/trace -o bench -- $CMD > gpurun_out/profile/trace_run.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/profile/fetch -o bench -- $CMD > gpurun_out/profile/fetch_run.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/profile/write -o bench -- $CMD > gpurun_out/profile/write_run.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/profile/sq -o bench -- $CMD > gpurun_out/profile/sq_run.log 2>&1
-python - <<'PY'
-import csv, glob, collections, json
+C=${1:-2}
+P=gpurun_out/profile_c$C
+rm -rf $P; mkdir -p $P
+CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o bench -- $CMD > $P/trace_run.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -o bench -- $CMD > $P/fetch_run.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -o bench -- $CMD > $P/write_run.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $P/sq -o bench -- $CMD > $P/sq_run.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $P/mfma -o bench -- $CMD > $P/mfma_run.log 2>&1
+python - $P <<'PY'
+import csv, glob, collections, json, sys
+P = sys.argv[1]
 def short(name):
-    for k, v in (('k_sweep_fused', 'k_sweep_fused'), ('k_forward', 'k_forward'), ('k_backward', 'k_backward'), ('k_expansions', 'k_expansions'), ('k_rollout', 'k_rollout'), ('k_al_init', 'k_al_init'), ('k_solve_setup', 'k_solve_setup'), ('k_pack_results', 'k_pack_results')):
-        if k in name: return v
+    for k in ('k_sweep_fused', 'k_forward2', 'k_forward', 'k_backward_mfma16', 'k_backward_mfma', 'k_backward_coop', 'k_backward', 'k_expansions',
+              'k_rollout', 'k_al_init', 'k_solve_setup', 'k_pack_results', 'k_set_rows', 'k_reset_stats'):
+        if k in name: return k
     return name[:40]
 out = {}
-for tag in ('fetch', 'write', 'sq'):
-    f = glob.glob(f'gpurun_out/profile/{tag}/**/*counter_collection.csv', recursive=True)
+for tag in ('fetch', 'write', 'sq', 'mfma'):
+    f = glob.glob(f'{P}/{tag}/**/*counter_collection.csv', recursive=True)
     if not f: continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
@@ -24,14 +29,16 @@ for tag in ('fetch', 'write', 'sq'):
     for k, d in acc.items():
         for c, v in d.items():
             out.setdefault(k, {})[c] = {'launches': len(v), 'sum': sum(v), 'avg': sum(v) / len(v)}
-f = glob.glob('gpurun_out/profile/trace/**/*kernel_stats.csv', recursive=True)
+f = glob.glob(f'{P}/trace/**/*kernel_stats.csv', recursive=True)
 if f:
+    import shutil
+    shutil.copy(f[0], f'{P}/kernel_stats.csv')
     for r in csv.DictReader(open(f[0])):
         out.setdefault(short(r['Name']), {})['trace'] = {'calls': int(r['Calls']), 'total_ns': float(r['TotalDurationNs']), 'avg_ns': float(r['AverageNs']), 'pct': float(r['Percentage'])}
-json.dump(out, open('gpurun_out/profile/summary.json', 'w'), indent=1)
-for k in ('k_sweep_fused', 'k_forward', 'k_backward', 'k_expansions'):
-    print(k, json.dumps(out.get(k, {}))[:900])
+json.dump(out, open(f'{P}/summary.json', 'w'), indent=1)
+for k, v in out.items():
+    if 'trace' in v and v['trace']['pct'] > 1.0: print(k, json.dumps(v)[:700])
 PY
-cp gpurun_out/profile/trace/*kernel_stats.csv gpurun_out/profile/kernel_stats.csv 2>/dev/null
-python bench.py --steps 5 --warmup 1 2>&1 | tail -1 > gpurun_out/profile/bench_line.json
-ls gpurun_out/profile
+for d in trace fetch write sq mfma; do rm -rf $P/$d; done
+python bench.py --config $C --steps 5 --warmup 1 2>&1 | tail -1 > $P/bench_line.json
+ls $P
