@@ -4,6 +4,7 @@
 // with an asymmetric product, and measures the dependent-issue cost of the instruction (through C and
 // through the B operand) for one wavefront alone on its SIMD.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
 __global__ void probe(const double* a, const double* b, double* d) {
@@ -62,7 +63,8 @@ int main() {
       double ref = 0;
       for (int k = 0; k < 4; ++k) ref += A[i][k] * B[k][j];
       const double got = hd[(i / 4) * 64 + j + 16 * (i % 4)];
-      if (got != ref && ++bad < 8) printf("mismatch D[%d][%d]: got %.17g want %.17g\n", i, j, got, ref);
+      // (the instruction accumulates k = 0..3 in its own order: compare to a few ulp, the layout errors are O(1))
+      if (fabs(got - ref) > 1e-12 * fabs(ref) && ++bad < 8) printf("mismatch D[%d][%d]: got %.17g want %.17g\n", i, j, got, ref);
     }
   printf("mfma_f64_16x16x4 layout (A lane i+16k, B lane j+16k, D lane j+16(i%%4) reg i/4): %s\n", bad ? "WRONG" : "confirmed");
   long long* dc; double* dout; long long hc[3];
