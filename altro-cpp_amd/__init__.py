@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaltro_hip.so")
+# ALTRO_HIP_LIB: load another build of the library (experiments: scripts/README.md); still no CPU fallback
+LIB_PATH = os.environ.get("ALTRO_HIP_LIB") or os.path.join(_HERE, "csrc", "libaltro_hip.so")
 
 # --- enums (include/altro_hip.h) -------------------------------------------------------------------
 OK, INVALID_ARG, HIP_ERROR, NOT_READY, UNSUPPORTED = 0, 1, 2, 3, 4

@@ -180,12 +180,24 @@ ALTRO_DEV void sincos_(T x, T* s, T* c);
 // is a short Cody-Waite reduction (exact for |x| < 1e5 thanks to FMA) + the fdlibm minimax kernels
 // on [-pi/4, pi/4]: <= 1.5 ulp from the correctly rounded value, which is also what glibc (the CPU
 // oracle) delivers, so results agree to ~1e-16.  Larger arguments take the ocml path.
+// Keeps a value in its register across this point: the compiler can neither sink the computation that produced
+// it into a conditional region nor replace a select on it by a branch.  On a lone wavefront a divergent region
+// (s_and_saveexec + s_cbranch_execz + s_or exec) costs ~50 cycles even when every lane takes the same side.
+ALTRO_DEV void pin(double& x) { asm volatile("" : "+v"(x)); }
+ALTRO_DEV void pin(float& x) { asm volatile("" : "+v"(x)); }
+ALTRO_DEV void pin(int& x) { asm volatile("" : "+v"(x)); }
+// The same for a wave-uniform integer, kept in a SCALAR register: under scalar-register pressure the compiler
+// re-loads values that came from the kernel arguments (s_load_dword + s_waitcnt: a memory round trip, exposed on
+// a serial chain) instead of spilling them; a pinned value can only be spilled to a vector lane.
+ALTRO_DEV void pin_s(int& x) { asm volatile("" : "+s"(x)); }
+
 template <>
 ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
-  if (!(fabs(x) < 1.0e5)) {
-    sincos(x, s, c);
-    return;
-  }
+  // Arguments of 1e5 and beyond (a line-search trial that blew up) take ocml's path with its full argument
+  // reduction.  The test is WAVE-UNIFORM (a ballot, i.e. a scalar branch): the fast path below is computed by every
+  // lane, and only when some lane of the wave is out of range do those lanes recompute -- per lane the same values
+  // as a divergent if / else, without a divergent region on the rollout's serial chain.
+  const bool big = !(fabs(x) < 1.0e5);
   const double kq = rint(x * 6.36619772367581382433e-01);  // x * 2/pi
   // pi/2 split: hi has 53 bits, lo the next 53
   double r = fma(-kq, 1.57079632679489655800e+00, x);
@@ -207,11 +219,16 @@ ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
-  const int q = (int)kq & 3;
+  const int q = big ? 0 : ((int)kq & 3);
   const double s0 = (q & 1) ? cr : sr;
   const double c0 = (q & 1) ? sr : cr;
-  *s = (q & 2) ? -s0 : s0;
-  *c = ((q + 1) & 2) ? -c0 : c0;
+  double so = (q & 2) ? -s0 : s0;
+  double co = ((q + 1) & 2) ? -c0 : c0;
+  if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+    if (big) sincos(x, &so, &co);
+  }
+  *s = so;
+  *c = co;
 }
 template <>
 ALTRO_DEV void sincos_<float>(float x, float* s, float* c) {
@@ -313,7 +330,7 @@ struct UnicycleM {  // examples/unicycle.cpp:12-33
     // kernels evaluated directly on d (no range reduction, no quadrant selects): ~25 instructions
     // instead of ~57, accurate to ~2 ulp.  Larger steps take the full sincos.
     const T d2 = w * T(0.5) * hh, d4 = w * hh;
-    if (abs_(d4) < T(0.78)) {
+    {
       T sd, cd;
       sincos_small(d2, &sd, &cd);
       s2 = s1 * cd + c1 * sd;
@@ -322,9 +339,15 @@ struct UnicycleM {  // examples/unicycle.cpp:12-33
       const T sdd = T(2) * sd * cd, cdd = fma(T(-2) * sd, sd, T(1));
       s4 = s1 * cdd + c1 * sdd;
       c4 = c1 * cdd - s1 * sdd;
-    } else {
-      sincos_(x[2] + d2, &s2, &c2);
-      sincos_(x[2] + d4, &s4, &c4);
+    }
+    // larger steps: the full sincos.  Wave-uniform test (see sincos_): the lanes in range keep the values above,
+    // exactly what a per-lane if / else selects, and the common case has no divergent region on the chain.
+    const bool wide = !(abs_(d4) < T(0.78));
+    if (__builtin_expect(__ballot(wide) != 0ull, 0)) {
+      if (wide) {
+        sincos_(x[2] + d2, &s2, &c2);
+        sincos_(x[2] + d4, &s4, &c4);
+      }
     }
     if (EXACT) {
       const T k1x = v * c1, k1y = v * s1;

@@ -732,7 +732,8 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       // reciprocal square roots in sequence (same O(cond) * eps accuracy as forming L^-T L^-1).
       const double qa = q00 + rho, qc = q11 + rho;
       const double det = fma(qa, qc, -(q10 * q10));
-      const double rd = rcp_nr(det);
+      double rd = rcp_nr(det);
+      pin(rd);  // computed by every lane, not inside a region of the lanes that hold the 2 x 2 block
       // rows 2 and 3 did not receive Quu: every lane reads the verdict of lane (r = 0, c = 0) of its block
       const bool fail = ((unsigned)__ballot((qa <= 0.0) || (det <= 0.0)) & verdict_bit) != 0u;
       // -(Quu + rho I)^-1, this lane's entry (zero outside the 2x2 block)
@@ -763,16 +764,23 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
         gave_up = failed && give;
       }
       Pp = commit ? Pn : Pp;
+      pin(Pp);
       // expected cost decrease d^T Qu, d^T Quu d: every lane accumulates its own product (rows 0 and 1
       // of the vector column are the meaningful ones); the two rows are added once, after the sweep
-      const double KDc = commit ? KD : 0.0;
+      double KDc = commit ? KD : 0.0;
+      pin(KDc);  // a select, then two unconditional FMAs -- not an if / else around them
       dV0 = fma(KDc, Q2, dV0);
       dV1 = fma(KDc, G, dV1);
       // gains into the LDS block (lanes with nothing to store hit a junk slot)
-      if (FUSED)
-        sKDf[(commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane] = (T)(RS)KD;  // as stored
-      else
-        sKD[(commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane] = KD;
+      if (FUSED) {
+        int idx = (commit && offKD >= 0) ? k * R::KP + offKD : fused_junk + lane;
+        pin(idx);
+        sKDf[idx] = (T)(RS)KD;  // as stored
+      } else {
+        int idx = (commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane;
+        pin(idx);
+        sKD[idx] = KD;
+      }
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
       need = need && !gave_up;
       slot++;
@@ -2082,6 +2090,7 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 
 ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
 // iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the cost wave so that they
 // stay off the rollout wave's serial chain.  Step k of the rollout fails with kStateLimit when
 // ||x_{k+1}|| > state_max, else with kControlLimit when ||u_k|| > control_max; the first failing step
@@ -2097,19 +2106,18 @@ struct RolloutBounds {
   bool first = true;
   template <int n>
   ALTRO_DEV void settle(const T* x) {
-    if (!check) return;
+    if (!check) return;  // wave-uniform
     T sx = T(0);
 #pragma unroll
     for (int i = 0; i < n; ++i) sx += x[i] * x[i];
-    if (ok && !first) {
-      if (sx > smax2) {  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
-        ok = false;
-        st = ALTRO_STATE_LIMIT;
-      } else if (pend_u) {
-        ok = false;
-        st = ALTRO_CONTROL_LIMIT;
-      }
-    }
+    // selects, not branches: this runs once per knot beside the rollout's chain (a divergent region costs ~50 cycles)
+    const bool live = ok && !first;
+    const bool fail_x = live && sx > smax2;  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
+    const bool fail_u = live && !fail_x && pend_u;
+    int st_new = fail_x ? (int)ALTRO_STATE_LIMIT : (fail_u ? (int)ALTRO_CONTROL_LIMIT : st);
+    pin(st_new);
+    st = st_new;
+    ok = ok && !(fail_x || fail_u);
     first = false;
   }
   template <int n, int m>
@@ -2182,22 +2190,47 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
     c_row = kc.con[kCi].row_off;
   }
   if (kHasB) b_row = kc.con[kBi].row_off;
-  const int nrows = kc.nrows;
-  // Jc / (2 rho): the penalty is wave-uniform and hardly ever changes from knot to knot, so its reciprocal
-  // is kept (one IEEE division, ~70 cycles, when it changes) and the quotient comes from Markstein's
-  // correction step, which returns the correctly rounded Jc / (2 rho) -- the same bits -- in 3 operations
+  int nrows = kc.nrows, rowbase = run.rowbase, k_begin = run.k_begin;
+  // loop invariants that came from the kernel arguments: in scalar registers for the whole loop (pin_s), or the
+  // compiler re-loads them from memory at every knot -- a scalar-load round trip right behind the barrier
+  pin_s(c_p);
+  pin_s(c_pi);
+  pin_s(c_off);
+  pin_s(c_row);
+  pin_s(b_row);
+  pin_s(nrows);
+  pin_s(rowbase);
+  pin_s(k_begin);
+  // Jc / (2 rho): the penalty hardly ever changes from knot to knot, so its reciprocal is kept (one IEEE
+  // division, ~70 cycles, when it changes -- behind a WAVE-UNIFORM test, or the compiler turns the rare branch
+  // into an unconditional division and a select) and the quotient comes from Markstein's correction step, which
+  // returns the correctly rounded Jc / (2 rho) -- the same bits -- in 3 operations
   T inv_rho2 = T(0), inv_for = T(0);
   auto div_2rho = [&](T num, T rho) __attribute__((always_inline)) -> T {
     const T den = T(2) * rho;
-    if (den != inv_for) {  // wave-uniform
-      inv_for = den;
-      inv_rho2 = T(1) / den;
+    const bool stale = den != inv_for;
+    if (__ballot(stale) != 0ull) {
+      const T fresh = T(1) / den;
+      inv_rho2 = stale ? fresh : inv_rho2;
+      inv_for = stale ? den : inv_for;
     }
     const T q = num * inv_rho2;
     const T r = fma(-den, q, num);
     return fma(r, inv_rho2, q);
   };
-  for (int k = run.k_begin; k < kend; ++k) {
+  // multipliers of the bound rows: fetched one knot AHEAD, before the barrier (they do not depend on the hand-off),
+  // so that behind the barrier only the slot itself has to make the LDS round trip
+  T blam[2 * m], brho = T(1);
+  auto fetch_bound_rows = [&](int k, T* lam_out, T& rho_out) __attribute__((always_inline)) {
+    if (kHasB) {
+      const int rb = rowbase + (k - k_begin) * nrows;
+      rho_out = C.pen(rb + b_row);
+#pragma unroll
+      for (int j = 0; j < 2 * m; ++j) lam_out[j] = C.lam(rb + b_row + j);
+    }
+  };
+  fetch_bound_rows(k_begin, blam, brho);
+  for (int k = k_begin; k < kend; ++k) {
     lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
     const T* slot = xch + (k & 1) * (nm * kBlock);
     T xb[n], ub[m];
@@ -2205,13 +2238,11 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
 #pragma unroll
     for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
-    const int rb = run.rowbase + (k - run.k_begin) * nrows;
-    T blam[2 * m], brho = T(1);
-    if (kHasB) {
-      brho = C.pen(rb + b_row);
-#pragma unroll
-      for (int j = 0; j < 2 * m; ++j) blam[j] = C.lam(rb + b_row + j);
-    }
+    const int rb = rowbase + (k - k_begin) * nrows;
+    // this knot's multipliers are in registers; the next knot's are requested now (the last request of a run is
+    // clamped to its own knot and unused)
+    T blam_next[2 * m], brho_next = T(1);
+    fetch_bound_rows(k + 1 < kend ? k + 1 : k, blam_next, brho_next);
     if (FK == kFastGeneric) {
       J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
     } else {
@@ -2273,6 +2304,11 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
         circle_term();
       }
       J += (double)Jk;
+    }
+    if (kHasB) {
+      brho = brho_next;
+#pragma unroll
+      for (int j = 0; j < 2 * m; ++j) blam[j] = blam_next[j];
     }
   }
 }
@@ -2792,7 +2828,6 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
       }
     }
     __syncthreads();
-
     // ---- F ----
     forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
     ++loops;
