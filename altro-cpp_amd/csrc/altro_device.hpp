@@ -191,6 +191,35 @@ ALTRO_DEV void pin(int& x) { asm volatile("" : "+v"(x)); }
 // a serial chain) instead of spilling them; a pinned value can only be spilled to a vector lane.
 ALTRO_DEV void pin_s(int& x) { asm volatile("" : "+s"(x)); }
 
+// d = a * b + c as the three-address v_fma_f64.  For a polynomial step p <- z * p + K with K a loop-invariant
+// coefficient register the compiler otherwise picks the two-address v_fmac_f64 and pays a v_mov_b64 copy of K per
+// step; it also runs the sine and the cosine polynomial one after the other, each step waiting ~12 cycles for the
+// previous one.  fdlibm_sincos_kernels() below issues the two chains interleaved, step by step.
+ALTRO_DEV double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// __kernel_sin / __kernel_cos of fdlibm on |r| <= pi/4 (r*r = z): the same operations as the plain C version in the
+// same order per chain, hence the same bits.
+ALTRO_DEV void fdlibm_sincos_kernels(double r, double* s, double* c) {
+  const double z = r * r;
+  double ps = fma3(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  double pc = fma3(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  ps = fma3(z, ps, 2.75573137070700676789e-06);
+  pc = fma3(z, pc, -2.75573143513906633035e-07);
+  ps = fma3(z, ps, -1.98412698298579493134e-04);
+  pc = fma3(z, pc, 2.48015872894767294178e-05);
+  ps = fma3(z, ps, 8.33333333332248946124e-03);
+  pc = fma3(z, pc, -1.38888888888741095749e-03);
+  ps = fma3(z, ps, -1.66666666666666324348e-01);
+  pc = fma3(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  *s = fma(r * z, ps, r);
+  *c = w + (((1.0 - w) - hz) + z * (z * pc));
+}
+
 template <>
 ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
   // Arguments of 1e5 and beyond (a line-search trial that blew up) take ocml's path with its full argument
@@ -202,23 +231,8 @@ ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
   // pi/2 split: hi has 53 bits, lo the next 53
   double r = fma(-kq, 1.57079632679489655800e+00, x);
   r = fma(-kq, 6.12323399573676603587e-17, r);
-  const double z = r * r;
-  // __kernel_sin
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
-  const double sr = fma(r * z, ps, r);
-  // __kernel_cos
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  double sr, cr;
+  fdlibm_sincos_kernels(r, &sr, &cr);
   const int q = big ? 0 : ((int)kq & 3);
   const double s0 = (q & 1) ? cr : sr;
   const double c0 = (q & 1) ? sr : cr;
@@ -239,21 +253,7 @@ template <class T>
 ALTRO_DEV void sincos_small(T x, T* s, T* c);
 template <>
 ALTRO_DEV void sincos_small<double>(double r, double* s, double* c) {
-  const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
-  *s = fma(r * z, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  *c = w + (((1.0 - w) - hz) + z * (z * pc));
+  fdlibm_sincos_kernels(r, s, c);
 }
 template <>
 ALTRO_DEV void sincos_small<float>(float r, float* s, float* c) {
@@ -280,10 +280,10 @@ template <>
 ALTRO_DEV float sqrt_<float>(float x) {
   return sqrtf(x);
 }
-template <class T>
-ALTRO_DEV T abs_(T x) {
-  return x < T(0) ? -x : x;
-}
+// |x| as the free source modifier of the consuming instruction (a compare-and-select costs four instructions and
+// a VCC hazard on a lone wave's chain); differs from `x < 0 ? -x : x` only in the sign of a zero result
+ALTRO_DEV double abs_(double x) { return __builtin_fabs(x); }
+ALTRO_DEV float abs_(float x) { return __builtin_fabsf(x); }
 template <class T>
 ALTRO_DEV T min_(T a, T b) {
   return b < a ? b : a;

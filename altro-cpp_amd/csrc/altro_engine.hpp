@@ -930,7 +930,7 @@ class Engine final : public EngineBase {
       const int lanes_max = kBlock / kLineSearchLanes;
       fwd_per_wave_ = lanes_max;
       while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
-      const size_t shared_bytes = (padv(pool.size()) + 2 * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int) +
+      const size_t shared_bytes = (padv(pool.size()) + kFwdSlots * (size_t)nm * kBlock) * sizeof(T) + 2 * kBlock * sizeof(int) +
                                   kBlock * sizeof(double);
       while (fwd_per_wave_ > 1 && shared_bytes + fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
       if (const char* e = std::getenv("ALTRO_HIP_FWD_PER_WAVE")) fwd_per_wave_ = std::max(1, std::min(fwd_per_wave_, atoi(e)));

@@ -2090,6 +2090,15 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 
 ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The rollout wave hands (xbar_k, ubar_k) to the two consumer waves through a ring of kFwdSlots LDS slots and
+// the workgroup barrier is taken once per PAIR of knots: the producer syncs after the odd knots (and after the
+// terminal one), the consumers before the even ones.  Barrier j publishes knots 2j, 2j+1; the producer overwrites
+// their slots with knots 2j+4, 2j+5 only after barrier j+1, which the consumers reach after finishing pair j.
+constexpr int kFwdSlots = 4;
+ALTRO_DEV bool producer_syncs_after(int k, int N) { return (k & 1) != 0 || k == N; }
+ALTRO_DEV bool consumer_syncs_before(int k) { return (k & 1) == 0; }
+ALTRO_DEV int fwd_slot(int k) { return k & (kFwdSlots - 1); }
+
 
 // iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the cost wave so that they
 // stay off the rollout wave's serial chain.  Step k of the rollout fails with kStateLimit when
@@ -2104,20 +2113,23 @@ struct RolloutBounds {
   int st = ALTRO_UNSOLVED;
   bool pend_u = false;
   bool first = true;
+  // The common case -- no trial of the wave is past a limit -- costs the two norms, two compares and one scalar
+  // branch per knot: the bookkeeping of a failure sits behind a WAVE-UNIFORM test (a divergent region costs ~50
+  // cycles on this wave's chain even when no lane enters it).
   template <int n>
   ALTRO_DEV void settle(const T* x) {
     if (!check) return;  // wave-uniform
     T sx = T(0);
 #pragma unroll
     for (int i = 0; i < n; ++i) sx += x[i] * x[i];
-    // selects, not branches: this runs once per knot beside the rollout's chain (a divergent region costs ~50 cycles)
-    const bool live = ok && !first;
-    const bool fail_x = live && sx > smax2;  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
-    const bool fail_u = live && !fail_x && pend_u;
-    int st_new = fail_x ? (int)ALTRO_STATE_LIMIT : (fail_u ? (int)ALTRO_CONTROL_LIMIT : st);
-    pin(st_new);
-    st = st_new;
-    ok = ok && !(fail_x || fail_u);
+    const bool over_x = sx > smax2;  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
+    const bool hit = ok && !first && (over_x || pend_u);
+    if (__ballot(hit) != 0ull) {
+      if (hit) {
+        ok = false;
+        st = over_x ? (int)ALTRO_STATE_LIMIT : (int)ALTRO_CONTROL_LIMIT;
+      }
+    }
     first = false;
   }
   template <int n, int m>
@@ -2140,8 +2152,8 @@ ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, int kd_strid
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   for (int k = kbegin; k < kend; ++k) {
-    lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
-    const T* slot = xch + (k & 1) * (nm * kBlock);
+    if (consumer_syncs_before(k)) lds_barrier();  // publishes (xbar, ubar) of knots k, k+1 of every trial
+    const T* slot = xch + fwd_slot(k) * (nm * kBlock);
     T xb[n], ub[m], d[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
@@ -2231,8 +2243,8 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   };
   fetch_bound_rows(k_begin, blam, brho);
   for (int k = k_begin; k < kend; ++k) {
-    lds_barrier();  // barrier k: slot k&1 holds (xbar_k, ubar_k) of every trial
-    const T* slot = xch + (k & 1) * (nm * kBlock);
+    if (consumer_syncs_before(k)) lds_barrier();  // publishes (xbar, ubar) of knots k, k+1 of every trial
+    const T* slot = xch + fwd_slot(k) * (nm * kBlock);
     T xb[n], ub[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
@@ -2442,7 +2454,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T* sIp = sPen + L.rowsP();
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
-  int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);  // [2][64]: ok, status of each trial
+  int* flags = reinterpret_cast<int*>(xch + kFwdSlots * nm * kBlock);  // [2][64]: ok, status of each trial
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
     forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock,
@@ -2493,7 +2505,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         for (int l = 0; l < n; ++l) sacc += cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
         ub[i] = cur.uk[i] + sacc + cur.kd[R::oD + i] * alpha;
       }
-      T* slot = xch + (k & 1) * (nm * kBlock);
+      T* slot = xch + fwd_slot(k) * (nm * kBlock);
 #pragma unroll
       for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
 #pragma unroll
@@ -2507,7 +2519,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
-      lds_barrier();  // barrier k
+      if (producer_syncs_after(k, N)) lds_barrier();
     };
     {
       Nominal qa, qb;
@@ -2520,10 +2532,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (k < N) knot(k, qa, qb);
     }
     // final hand-off: x_N
-    T* slot = xch + (N & 1) * (nm * kBlock);
+    T* slot = xch + fwd_slot(N) * (nm * kBlock);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
-    lds_barrier();  // barrier N
+    lds_barrier();  // barrier N (producer_syncs_after(N, N))
     lds_barrier();  // barrier A (auxiliary wave -> cost wave)
     // phase 2 is shared by all waves: wait for the selection, take every third block of knots
     __syncthreads();  // barrier S
@@ -2559,9 +2571,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     bnd.smax2 = T(o.state_max) * T(o.state_max);
     bnd.umax2 = T(o.control_max) * T(o.control_max);
     aux_consumer_run<T, M>(0, N, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + tb, gs, bnd);
-    lds_barrier();  // barrier N: terminal state
+    if (consumer_syncs_before(N)) lds_barrier();  // barrier N: terminal state
     {
-      const T* slot = xch + (N & 1) * (nm * kBlock);
+      const T* slot = xch + fwd_slot(N) * (nm * kBlock);
       T xN[n];
 #pragma unroll
       for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
@@ -2619,9 +2631,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
 #undef ALTRO_RUN
   }
-  lds_barrier();  // barrier N: terminal state and rollout outcome
+  if (consumer_syncs_before(N)) lds_barrier();  // barrier N: terminal state and rollout outcome
   {
-    const T* slot = xch + (N & 1) * (nm * kBlock);
+    const T* slot = xch + fwd_slot(N) * (nm * kBlock);
     T xN[n], uz[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
@@ -2782,7 +2794,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
   T* sKDf = sm + L.nX + L.nU;
   T* sPool = sm + L.total();
   T* xch = sPool + L.padv(pd->npool);
-  int* flags = reinterpret_cast<int*>(xch + 2 * nm * kBlock);
+  int* flags = reinterpret_cast<int*>(xch + kFwdSlots * nm * kBlock);
   double* fh = reinterpret_cast<double*>(flags + 2 * kBlock) + kBlock;  // behind the gradient slots
   const int fused_junk = (int)(reinterpret_cast<T*>(fh + 6) - sKDf);  // one junk slot per lane, in units of T
 
