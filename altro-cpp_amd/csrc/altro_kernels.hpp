@@ -2100,68 +2100,94 @@ ALTRO_DEV bool consumer_syncs_before(int k) { return (k & 1) == 0; }
 ALTRO_DEV int fwd_slot(int k) { return k & (kFwdSlots - 1); }
 
 
-// iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the cost wave so that they
+// iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the auxiliary wave so that they
 // stay off the rollout wave's serial chain.  Step k of the rollout fails with kStateLimit when
 // ||x_{k+1}|| > state_max, else with kControlLimit when ||u_k|| > control_max; the first failing step
-// decides.  visit() sees (x_k, u_k): it settles step k-1 (x_k and the remembered verdict on u_{k-1}),
-// then remembers u_k.  The rollout wave keeps integrating a failed trial; nothing reads the result.
-template <class T>
-struct RolloutBounds {
-  bool check;
-  T smax2, umax2;
-  bool ok = true;
-  int st = ALTRO_UNSOLVED;
-  bool pend_u = false;
-  bool first = true;
-  // The common case -- no trial of the wave is past a limit -- costs the two norms, two compares and one scalar
-  // branch per knot: the bookkeeping of a failure sits behind a WAVE-UNIFORM test (a divergent region costs ~50
-  // cycles on this wave's chain even when no lane enters it).
-  template <int n>
-  ALTRO_DEV void settle(const T* x) {
-    if (!check) return;  // wave-uniform
-    T sx = T(0);
-#pragma unroll
-    for (int i = 0; i < n; ++i) sx += x[i] * x[i];
-    const bool over_x = sx > smax2;  // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed
-    const bool hit = ok && !first && (over_x || pend_u);
-    if (__ballot(hit) != 0ull) {
-      if (hit) {
-        ok = false;
-        st = over_x ? (int)ALTRO_STATE_LIMIT : (int)ALTRO_CONTROL_LIMIT;
-      }
+// decides.  The rollout wave keeps integrating a failed trial; nothing reads the result.
+// The verdicts of all trials of the wave live in wave-uniform bit masks (scalar registers, bit = trial):
+// the common case -- no trial past a limit -- costs two compares (which write a scalar mask directly),
+// a handful of scalar operations and one scalar branch per knot.
+struct BoundMasks {
+  unsigned long long ok = ~0ull, state = 0ull, ctrl = 0ull, pend = 0ull;
+  // One rollout step: over_x = "x_{k+1} is past its limit", over_u_next = "u_{k+1} is past its limit"
+  // (remembered for the next step).  The caller masks out x_0 (never checked) and idle lanes.
+  ALTRO_DEV void step(unsigned long long over_x, unsigned long long over_u_next) {
+    const unsigned long long hit = (over_x | pend) & ok;
+    if (hit != 0ull) {
+      state |= over_x & ok;
+      ctrl |= pend & ok & ~over_x;
+      ok &= ~hit;
     }
-    first = false;
+    pend = over_u_next;
   }
-  template <int n, int m>
-  ALTRO_DEV void visit(const T* x, const T* u) {
-    if (!check) return;
-    settle<n>(x);
-    T su = T(0);
-#pragma unroll
-    for (int i = 0; i < m; ++i) su += u[i] * u[i];
-    pend_u = su > umax2;
+  ALTRO_DEV bool lane_ok(int bit) const { return ((ok >> bit) & 1ull) != 0ull; }
+  ALTRO_DEV int lane_status(int bit) const {
+    return ((state >> bit) & 1ull) ? (int)ALTRO_STATE_LIMIT : ((ctrl >> bit) & 1ull) ? (int)ALTRO_CONTROL_LIMIT
+                                                                                   : (int)ALTRO_UNSOLVED;
   }
 };
 
-// The auxiliary wave of the forward pass, one knot per barrier like the cost wave: the rollout's bound
-// checks (RolloutBounds), the gradient measure of the trial (ilqr.hpp:574-583 with the trial's controls)
-// and the candidate store.  None of it feeds the cost, so it runs beside the cost wave.
-template <class T, class M>
-ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
-                                bool valid, T* candp, double& gs, RolloutBounds<T>& bnd) {
+// The value lanes 32..63 hold, delivered to lanes 0..31 (v_permlane32_swap: no LDS round trip)
+ALTRO_DEV double from_upper_half(double x) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto bb = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)bb[1], (int)a[1]);
+}
+
+// The auxiliary wave of the forward pass: the rollout's bound checks (BoundMasks), the gradient measure of the
+// trial (ilqr.hpp:574-583 with the trial's controls) and the candidate stores, for the knots 0..N, then the
+// verdicts for the cost wave (flags, gsx).  None of it feeds the cost, so it runs beside the cost wave.
+//
+// PAIRED (the persistent tail kernel: one instance = 20 trials per workgroup, two thirds of the lanes would idle):
+// the rollout wave publishes two knots per barrier, and the two halves of this wave take one each -- lanes 0..31
+// knot 2j, lanes 32..63 knot 2j+1 of trial (lane & 31) -- so the wave's instruction stream runs once per PAIR of
+// knots.  What is sequential over the knots stays sequential: the bound verdicts are scalar masks stepped in knot
+// order, and the gradient measure is summed in the lower half in knot order (the upper half's term arrives through
+// v_permlane32_swap), bit-identical to the one-knot-at-a-time loop.
+template <class T, class M, bool PAIRED>
+ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
+                            bool valid, T* cand_inst, int* flags, double* gsx) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
-  for (int k = kbegin; k < kend; ++k) {
-    if (consumer_syncs_before(k)) lds_barrier();  // publishes (xbar, ubar) of knots k, k+1 of every trial
+  const bool check = o.check_forwardpass_bounds != 0;
+  const T smax2 = T(o.state_max) * T(o.state_max), umax2 = T(o.control_max) * T(o.control_max);
+  const int half = PAIRED ? (lane >> 5) : 0;
+  const int col = PAIRED ? (lane & 31) : lane;           // the rollout-wave lane whose trial this lane follows
+  const bool mine = PAIRED ? col < LS : valid;  // (a PAIRED workgroup has exactly one, live, instance)
+  T* const candp = cand_inst + (unsigned)(PAIRED ? col : lane % LS) * (unsigned)nm;
+  BoundMasks bm;
+  double gs = 0.0;
+  constexpr int kStep = PAIRED ? 2 : 1;
+  for (int k0 = 0; k0 <= N; k0 += kStep) {
+    if (consumer_syncs_before(k0)) lds_barrier();  // publishes (xbar, ubar) of knots k0, k0+1 of every trial
+    const int k = k0 + half;                       // k <= N + 1; N is the terminal knot (a state only)
+    const bool inner = k < N;
     const T* slot = xch + fwd_slot(k) * (nm * kBlock);
     T xb[n], ub[m], d[m];
 #pragma unroll
-    for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
+    for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + col];
 #pragma unroll
-    for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + lane];
+    for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + col];  // stale at the terminal knot: masked below
+    const int kg = inner ? k : N - 1;
 #pragma unroll
-    for (int i = 0; i < m; ++i) d[i] = sKD[k * kd_stride + kd_off + i];
-    bnd.template visit<n, m>(xb, ub);
+    for (int i = 0; i < m; ++i) d[i] = sKD[kg * kd_stride + kd_off + i];
+    if (check) {  // wave-uniform
+      T sx = T(0), su = T(0);
+#pragma unroll
+      for (int i = 0; i < n; ++i) sx += xb[i] * xb[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) su += ub[i] * ub[i];
+      // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2: no sqrt needed.  x_0 is given, not checked.
+      const unsigned long long ox = __ballot(mine && k > 0 && k <= N && sx > smax2);
+      const unsigned long long ou = __ballot(mine && inner && su > umax2);
+      if (PAIRED) {
+        bm.step(ox & 0xffffffffull, ou & 0xffffffffull);
+        bm.step(ox >> 32, ou >> 32);
+      } else {
+        bm.step(ox, ou);
+      }
+    }
     // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
     T gnum = T(0), gden = T(1);
 #pragma unroll
@@ -2172,14 +2198,22 @@ ALTRO_DEV void aux_consumer_run(int kbegin, int kend, const T* sKD, int kd_strid
         gden = den;
       }
     }
-    gs += (double)(gnum / gden);
-    if (valid) {  // idle lanes must not touch instance 0's candidates
+    const double r = inner ? (double)(gnum / gden) : 0.0;  // gs >= +0: adding +0 leaves every bit alone
+    gs += r;
+    if (PAIRED) gs += from_upper_half(r);
+    if (mine && k <= N) {  // idle lanes must not touch the candidates
       T* cand = candp + (unsigned)k * (unsigned)(LS * nm);
 #pragma unroll
       for (int i = 0; i < n; ++i) cand[i] = xb[i];
 #pragma unroll
-      for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
+      for (int i = 0; i < m; ++i) cand[n + i] = ub[i];  // (the terminal knot's slot has room for the unused u)
     }
+  }
+  const int bit = PAIRED ? col : lane;
+  if (!PAIRED || half == 0) {
+    flags[lane] = bm.lane_ok(bit) ? 1 : 0;
+    flags[kBlock + lane] = bm.lane_status(bit);
+    gsx[lane] = gs;
   }
 }
 
@@ -2562,31 +2596,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   // workgroup and per CU -- in LDS, so that the knot loop issues no global store at all
   T* const cand_base = FUSED ? sCand : A.trial;
   const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
-  const unsigned tb = cand_off0 + (unsigned)t * (unsigned)nm;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
-    double gs = 0.0;
-    RolloutBounds<T> bnd;
-    bnd.check = o.check_forwardpass_bounds != 0;
-    bnd.smax2 = T(o.state_max) * T(o.state_max);
-    bnd.umax2 = T(o.control_max) * T(o.control_max);
-    aux_consumer_run<T, M>(0, N, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + tb, gs, bnd);
-    if (consumer_syncs_before(N)) lds_barrier();  // barrier N: terminal state
-    {
-      const T* slot = xch + fwd_slot(N) * (nm * kBlock);
-      T xN[n];
-#pragma unroll
-      for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
-      bnd.template settle<n>(xN);  // the last step of the rollout
-      if (valid) {
-        T* cand = cand_base + (tb + (unsigned)N * (unsigned)(LS * nm));
-#pragma unroll
-        for (int i = 0; i < n; ++i) cand[i] = xN[i];
-      }
-      flags[lane] = bnd.ok ? 1 : 0;
-      flags[kBlock + lane] = bnd.st;
-      gsx[lane] = gs;
-    }
+    aux_wave_run<T, M, FUSED>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx);
     lds_barrier();    // barrier A
     __syncthreads();  // barrier S
     {
