@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("ALTRO_HIP_LIB") or os.path.join(_HERE, "csrc", "libal
 OK, INVALID_ARG, HIP_ERROR, NOT_READY, UNSUPPORTED = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 MODEL_UNICYCLE, MODEL_TRIPLE_INTEGRATOR, MODEL_QUADROTOR12 = 1, 2, 3
-CON_GOAL, CON_CONTROL_BOUND, CON_CIRCLE = 1, 2, 3
+CON_GOAL, CON_CONTROL_BOUND, CON_CIRCLE, CON_USER = 1, 2, 3, 4
 # altro::SolverStatus, altro/common/solver_stats.hpp:20-31
 (SOLVED, UNSOLVED, STATE_LIMIT, CONTROL_LIMIT, COST_INCREASE, MAX_ITERATIONS, MAX_OUTER_ITERATIONS,
  MAX_INNER_ITERATIONS, MAX_PENALTY, BACKWARD_PASS_REGULARIZATION_FAILED) = range(10)
@@ -189,11 +189,22 @@ class BatchSolver:
         self._call("set_lqr_cost", C.c_int(k_begin), C.c_int(k_end), _dp(Qc), _dp(Rc), _dp(xref),
                    _dp(uref), C.c_int(per))
 
+    def set_user_cost(self, k_begin, k_end, params):
+        """The UserCost of the handle's user model (register_model_source) on knots [k_begin, k_end);
+        params: [UserCost::nparams] or [B][nparams]."""
+        p = _f64(params)
+        per = 1 if p.ndim == 2 else 0
+        self._call("set_user_cost", C.c_int(k_begin), C.c_int(k_end), _dp(p), C.c_int(p.shape[-1]), C.c_int(per))
+
     def add_constraint(self, kind, k_begin, k_end, params):
         p = _f64(params)
         per = 1 if p.ndim == 2 else 0
         self._call("add_constraint", C.c_int(kind), C.c_int(k_begin), C.c_int(k_end), _dp(p),
                    C.c_int(p.shape[-1]), C.c_int(per))
+
+    def add_user_constraint(self, k_begin, k_end, params):
+        """The UserConstraint of the handle's user model on knots [k_begin, k_end); params: [nparams] or [B][nparams]."""
+        self.add_constraint(CON_USER, k_begin, k_end, params)
 
     def add_goal_constraint(self, k, xf):
         self.add_constraint(CON_GOAL, k, k + 1, xf)

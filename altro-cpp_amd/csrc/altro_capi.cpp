@@ -28,7 +28,7 @@
 
 using namespace altro_hip;
 
-#define ALTRO_USER_PLUGIN_ABI_HOST 2  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
+#define ALTRO_USER_PLUGIN_ABI_HOST 3  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -71,6 +71,9 @@ struct UserModelEntry {
   int n = 0, m = 0;
   EngineBase* (*make)(const altro_desc*, std::string*) = nullptr;
   int (*check)(int, const double*, int, double, double*) = nullptr;
+  int (*check_functors)(int, const double*, int, double, double*) = nullptr;
+  int functors = 0;  // bit 0: the source defines a UserCost, bit 1: a UserConstraint
+  int cost_nparams = 0, con_p = 0, con_nparams = 0, con_equality = 0;
   bool checked = false;
   uint64_t hash = 0;
 };
@@ -114,6 +117,28 @@ altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) 
              "(FunctionBase::CheckJacobian)", e.name.c_str(), max_err);
     *err = buf;
     return ALTRO_INVALID_ARG;
+  }
+  if (e.functors) {
+    // ScalarFunction::CheckGradient, FunctionBase::CheckHessian / CheckJacobian (functionbase.cpp:42-125) for the
+    // user's cost and constraint, at the same points
+    double errs[3] = {0, 0, 0};
+    const int rc2 = e.check_functors(device, z.data(), samples, 1e-6, errs);
+    if (rc2 != 0) {
+      *err = "user model '" + e.name + "': the cost / constraint derivative check could not run on the device (code " +
+             std::to_string(rc2) + ")";
+      return ALTRO_HIP_ERROR;
+    }
+    const char* what[3] = {"UserCost::gradient() does not match finite differences of eval()",
+                           "UserCost::hessian() does not match finite differences of gradient()",
+                           "UserConstraint::jacobian() does not match finite differences of eval()"};
+    for (int q = 0; q < 3; ++q)
+      if (!(errs[q] < 1e-4)) {
+        char buf[320];
+        snprintf(buf, sizeof(buf), "user model '%s': %s: error %.3g >= 1e-4 (FunctionBase::Check%s)", e.name.c_str(), what[q],
+                 errs[q], q == 0 ? "Gradient" : q == 1 ? "Hessian" : "Jacobian");
+        *err = buf;
+        return ALTRO_INVALID_ARG;
+      }
   }
   e.checked = true;
   return ALTRO_OK;
@@ -312,9 +337,9 @@ altro_status altro_register_model_source(const char* name, const char* source, i
     {
       std::ofstream f(src);
       f << "// generated by altro_register_model_source for the user model '" << name << "'\n"
-        << "#include \"altro_engine.hpp\"\n#define ALTRO_MODEL_FN __device__ __forceinline__\n"
+        << "#include <hip/hip_runtime.h>\n#define ALTRO_MODEL_FN __device__ __forceinline__\n"
         << "namespace altro_user {\n#line 1 \"user model " << name << "\"\n" << source << "\n}  // namespace altro_user\n"
-        << "#include \"altro_user_model.hpp\"\n";
+        << "#include \"altro_user_model.hpp\"  // (the engine headers see ALTRO_USER_COST / ALTRO_USER_CONSTRAINT)\n";
       if (!f) {
         err = "cannot write " + src + " (set ALTRO_HIP_CACHE_DIR to a writable directory)";
         return ALTRO_NOT_READY;
@@ -345,12 +370,15 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   auto dims = reinterpret_cast<void (*)(int*, int*)>(dlsym(e.dl, "altro_user_dims"));
   e.make = reinterpret_cast<EngineBase* (*)(const altro_desc*, std::string*)>(dlsym(e.dl, "altro_user_make_engine"));
   e.check = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_jacobian"));
-  if (!abi || !dims || !e.make || !e.check || abi() != ALTRO_USER_PLUGIN_ABI_HOST) {
+  auto finfo = reinterpret_cast<int (*)(int*, int*, int*, int*)>(dlsym(e.dl, "altro_user_functor_info"));
+  e.check_functors = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_functors"));
+  if (!abi || !dims || !e.make || !e.check || !finfo || !e.check_functors || abi() != ALTRO_USER_PLUGIN_ABI_HOST) {
     err = "the cached user-model plugin " + so + " does not match this library; delete it";
     dlclose(e.dl);
     return ALTRO_HIP_ERROR;
   }
   dims(&e.n, &e.m);
+  e.functors = finfo(&e.cost_nparams, &e.con_p, &e.con_nparams, &e.con_equality);
   if (check_jacobian) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {  // without a device the check runs at first use
@@ -410,9 +438,27 @@ altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const do
   h->spec.costs.push_back(std::move(c));
   return ALTRO_OK;
 }
+altro_status altro_set_user_cost(altro_handle h, int k_begin, int k_end, const double* params, int nparams,
+                                 int per_instance) {
+  if (!h || nparams < 0 || (nparams > 0 && !params)) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  const altro_desc& d = h->spec.desc;
+  if (k_begin < 0 || k_end > d.N + 1 || k_begin >= k_end) {
+    h->err = "knot range out of bounds";
+    return ALTRO_INVALID_ARG;
+  }
+  CostSpec c;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.per_instance = per_instance ? 1 : 0;
+  c.user = 1;
+  if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? d.batch : 1));
+  h->spec.costs.push_back(std::move(c));  // UserCost::nparams is checked when the engine of the model exists
+  return ALTRO_OK;
+}
 altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_end, const double* params,
                                   int nparams, int per_instance) {
-  if (!h || !params || nparams <= 0) return ALTRO_INVALID_ARG;
+  if (!h || nparams < 0 || (nparams > 0 && !params) || (nparams == 0 && kind != ALTRO_CON_USER)) return ALTRO_INVALID_ARG;
   if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
   const altro_desc& d = h->spec.desc;
   if (k_begin < 0 || k_end > d.N + 1 || k_begin >= k_end) {
@@ -437,7 +483,7 @@ altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_e
   c.k_end = k_end;
   c.nparams = nparams;
   c.per_instance = per_instance;
-  c.params.assign(params, params + (size_t)nparams * (per_instance ? d.batch : 1));
+  if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? d.batch : 1));
   h->spec.cons.push_back(std::move(c));
   return ALTRO_OK;
 }

@@ -22,7 +22,9 @@ constexpr int kMaxSharedPool = 128;  // shared parameters that travel to the for
 struct CostSpec {
   int k_begin, k_end;
   std::vector<double> Q, R, xref, uref;
-  int per_instance;  // bit0 xref, bit1 uref
+  int per_instance;  // bit0 xref, bit1 uref (user cost: params are per instance)
+  int user = 0;      // the user model's UserCost instead of an LQR cost
+  std::vector<double> params;  // user cost: [nparams] or [B][nparams]
 };
 struct ConSpec {
   int kind, k_begin, k_end, nparams, per_instance;
@@ -67,6 +69,7 @@ struct CostGroupDesc {
   int q_off, r_off, c_off;   // pool element (shared) or slot (per instance)
   int q_pi, r_pi, c_pi;      // per-instance flags
   int q_diag, r_diag;        // Q / R are diagonal (every off-diagonal entry is exactly zero)
+  int user, u_off, u_pi;     // user cost (altro_set_user_cost): parameters at u_off (pool element / first slot)
 };
 // A run of consecutive knot points [k_begin, k_end) with the same class: rows of knot k start at
 // rowbase + (k - k_begin) * nrows(cls).  Lets the serial kernels keep the class in scalar registers.

@@ -19,6 +19,42 @@ namespace altro_hip {
 #define ALTRO_DEV __device__ __forceinline__
 
 // -------------------------------------------------------------------------------------------------
+// User-defined cost / constraint functors.  Only a user-model plugin (the translation
+// unit altro_register_model_source generates) defines ALTRO_USER_COST / ALTRO_USER_CONSTRAINT -- its source is
+// included BEFORE this header, in namespace altro_user.  Everywhere else the stand-ins below keep the call sites
+// well-formed and `if constexpr (kHasUser...)` removes them: the built-in engines compile exactly as without them.
+// -------------------------------------------------------------------------------------------------
+#ifdef ALTRO_USER_COST
+using UserCostF = altro_user::ALTRO_USER_COST;
+constexpr bool kHasUserCost = true;
+#else
+struct UserCostF {
+  static constexpr int nparams = 0;
+  template <class T>
+  ALTRO_DEV static T eval(const T*, const T*, const T*) { return T(0); }
+  template <class T>
+  ALTRO_DEV static void gradient(const T*, const T*, const T*, T*, T*) {}
+  template <class T>
+  ALTRO_DEV static void hessian(const T*, const T*, const T*, T*, T*, T*) {}
+};
+constexpr bool kHasUserCost = false;
+#endif
+#ifdef ALTRO_USER_CONSTRAINT
+using UserConF = altro_user::ALTRO_USER_CONSTRAINT;
+constexpr bool kHasUserCon = true;
+#else
+struct UserConF {
+  static constexpr int p = 1, nparams = 0;
+  static constexpr bool equality = false;
+  template <class T>
+  ALTRO_DEV static void eval(const T*, const T*, const T*, T*) {}
+  template <class T>
+  ALTRO_DEV static void jacobian(const T*, const T*, const T*, T*) {}
+};
+constexpr bool kHasUserCon = false;
+#endif
+
+// -------------------------------------------------------------------------------------------------
 // Device array bundle (passed to kernels by value)
 // -------------------------------------------------------------------------------------------------
 // Record layout.  Per-knot data of one instance is a contiguous, 16-byte aligned RECORD; records of
@@ -692,8 +728,26 @@ ALTRO_DEV T violation(int type, T c) {
 
 // QuadraticCost::Evaluate (examples/quadratic_cost.cpp:8-11); H == 0 for LQRCost.  When Q / R are
 // diagonal the exact-zero off-diagonal products are skipped (they contribute +0.0 to every sum).
+// The parameters of a user functor, read through the context (shared pool or per-instance slots)
+template <class T, int NP, class Ctx>
+ALTRO_DEV void load_user_params(const Ctx& C, int per_instance, int off, T* par) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) par[i] = C.par(per_instance, off, i);
+}
+// CostFunction::Evaluate of the user's cost (costfunction.hpp:52-58)
+template <class T, class Ctx>
+ALTRO_DEV T user_cost_eval(const Ctx& C, const CostGroupDesc& g, const T* x, const T* u) {
+  constexpr int NP = UserCostF::nparams;
+  T par[NP > 0 ? NP : 1];
+  load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
+  return UserCostF::eval(x, u, par);
+}
+
 template <class T, int n, int m, class Ctx>
 ALTRO_DEV T quad_cost(const Ctx& C, const CostGroupDesc& g, const T* x, const T* u) {
+  if constexpr (kHasUserCost) {
+    if (g.user) return user_cost_eval<T>(C, g, x, u);
+  }
   T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
   for (int i = 0; i < n; ++i) {
@@ -720,6 +774,28 @@ ALTRO_DEV T quad_cost(const Ctx& C, const CostGroupDesc& g, const T* x, const T*
     ru += C.par(g.r_pi, g.r_off, i) * u[i];
   }
   return T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
+}
+
+// ConstraintValues::AugLag (constraint_values.hpp:111-119) for the user's constraint: con_->Evaluate, then the
+// projected multipliers.  STORE: also c_ and the violation, as for the built-in kinds.
+template <class T, bool STORE, class Ctx>
+ALTRO_DEV void user_con_auglag(const Ctx& C, const ConDesc& cd, int r0, T rho, const T* x, const T* u, T& a, T& bsum,
+                               T& vmax) {
+  constexpr int P = UserConF::p, NP = UserConF::nparams;
+  T par[NP > 0 ? NP : 1], c[P];
+  load_user_params<T, NP>(C, cd.per_instance, cd.param_off, par);
+  UserConF::eval(x, u, par, c);
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    T lam = C.lam(r0 + i);
+    T lp = dual_proj(cd.type, lam - rho * c[i]);
+    a += lp * lp;
+    bsum += lam * lam;
+    if (STORE) {
+      C.store_c(r0 + i, c[i]);
+      vmax = max_(vmax, violation(cd.type, c[i]));
+    }
+  }
 }
 
 // ALCost::Evaluate (al_cost.hpp:264-274) = quadratic cost + sum of ConstraintValues::AugLag
@@ -781,7 +857,7 @@ ALTRO_DEV T knot_cost(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, 
           ++r;
           ++pi;
         }
-    } else {  // CIRCLE (examples/obstacle_constraints.hpp:99-107)
+    } else if (!kHasUserCon || cd.kind == ALTRO_CON_CIRCLE) {  // examples/obstacle_constraints.hpp:99-107
       for (int i = 0; i < cd.p; ++i) {
         T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
         T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
@@ -796,6 +872,8 @@ ALTRO_DEV T knot_cost(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, 
           vmax = max_(vmax, violation(1, c));
         }
       }
+    } else {
+      user_con_auglag<T, STORE>(C, cd, r0, rho, x, u, a, bsum, vmax);
     }
     T Jc = a - bsum;
     J += Jc / (2 * rho);
@@ -816,7 +894,7 @@ struct RunConsts {
 template <class T, int n, int m, class Ctx>
 ALTRO_DEV void load_run_consts(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, RunConsts<T, n, m>& R) {
   const CostGroupDesc& g = pd->grp[kc.cost_group];
-  R.diag = g.q_diag && g.r_diag;
+  R.diag = g.q_diag && g.r_diag && !(kHasUserCost && g.user);  // a user cost goes through quad_cost()
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     R.Qd[i] = C.shared(g.Q_off + i + i * n);
@@ -909,7 +987,7 @@ ALTRO_DEV T knot_cost_fast(const Ctx& C, const ProblemDesc* pd, const KnotClass&
             ++r;
             ++pi;
           }
-      } else {
+      } else if (!kHasUserCon || cd.kind == ALTRO_CON_CIRCLE) {
         for (int i = 0; i < cd.p; ++i) {
           T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
           T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
@@ -920,6 +998,9 @@ ALTRO_DEV T knot_cost_fast(const Ctx& C, const ProblemDesc* pd, const KnotClass&
           a += lp * lp;
           bsum += lam * lam;
         }
+      } else {
+        T vmax_unused = T(0);
+        user_con_auglag<T, false>(C, cd, r0, rho, x, u, a, bsum, vmax_unused);
       }
       T Jc = a - bsum;
       J += Jc / (2 * rho);
@@ -935,38 +1016,51 @@ template <class T, int n, int m, class Ctx>
 ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, int rb, const T* x,
                                 const T* u, T* gx, T* gu, T* hxx, T* hxu, T* huu) {
   const CostGroupDesc& g = pd->grp[kc.cost_group];
-  T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
+  T J;
+  bool user_cost = false;
+  if constexpr (kHasUserCost) user_cost = g.user != 0;
+  if (user_cost) {
+    // CostFunction::Evaluate / Gradient / Hessian of the user's cost (costfunction.hpp:52-73)
+    constexpr int NP = UserCostF::nparams;
+    T par[NP > 0 ? NP : 1];
+    load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
+    J = UserCostF::eval(x, u, par);
+    UserCostF::gradient(x, u, par, gx, gu);
+    UserCostF::hessian(x, u, par, hxx, hxu, huu);
+  } else {
+    T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = T(0);
+    for (int i = 0; i < n; ++i) {
+      T s = T(0);
 #pragma unroll
-    for (int j = 0; j < n; ++j) {
-      T q = C.shared(g.Q_off + i + j * n);
-      hxx[i + j * n] = q;
-      s += q * x[j];
+      for (int j = 0; j < n; ++j) {
+        T q = C.shared(g.Q_off + i + j * n);
+        hxx[i + j * n] = q;
+        s += q * x[j];
+      }
+      T qi = C.par(g.q_pi, g.q_off, i);
+      gx[i] = s + qi;  // (Qx + q) + Hu with H == 0
+      xQx += x[i] * s;
+      qx += qi * x[i];
     }
-    T qi = C.par(g.q_pi, g.q_off, i);
-    gx[i] = s + qi;  // (Qx + q) + Hu with H == 0
-    xQx += x[i] * s;
-    qx += qi * x[i];
-  }
 #pragma unroll
-  for (int i = 0; i < m; ++i) {
-    T s = T(0);
+    for (int i = 0; i < m; ++i) {
+      T s = T(0);
 #pragma unroll
-    for (int j = 0; j < m; ++j) {
-      T r = C.shared(g.R_off + i + j * m);
-      huu[i + j * m] = r;
-      s += r * u[j];
+      for (int j = 0; j < m; ++j) {
+        T r = C.shared(g.R_off + i + j * m);
+        huu[i + j * m] = r;
+        s += r * u[j];
+      }
+      T ri = C.par(g.r_pi, g.r_off, i);
+      gu[i] = s + ri;
+      uRu += u[i] * s;
+      ru += ri * u[i];
     }
-    T ri = C.par(g.r_pi, g.r_off, i);
-    gu[i] = s + ri;
-    uRu += u[i] * s;
-    ru += ri * u[i];
-  }
 #pragma unroll
-  for (int e = 0; e < n * m; ++e) hxu[e] = T(0);
-  T J = T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
+    for (int e = 0; e < n * m; ++e) hxu[e] = T(0);
+    J = T(0.5) * xQx + T(0.5) * uRu + qx + ru + C.par(g.c_pi, g.c_off, 0);
+  }
 
   for (int ci = 0; ci < kc.ncon; ++ci) {
     const ConDesc& cd = kc.con[ci];
@@ -1031,6 +1125,67 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
         gu[j] += -sg[j];
         huu[j + j * m] += sh[j];
       }
+    } else if (kHasUserCon && cd.kind == ALTRO_CON_USER) {
+      // the user's constraint: con_->Evaluate / Jacobian, then ConstraintValues::AugLagGradient / AugLagHessian
+      // (constraint_values.hpp:131-177) with the full p x (n+m) Jacobian
+      constexpr int P = UserConF::p, NP = UserConF::nparams, nm = n + m;
+      T par[NP > 0 ? NP : 1], c[P], jac[P * nm], lp[P];
+      load_user_params<T, NP>(C, cd.per_instance, cd.param_off, par);
+      UserConF::eval(x, u, par, c);
+      UserConF::jacobian(x, u, par, jac);
+#pragma unroll
+      for (int r = 0; r < P; ++r) {
+        T lam = C.lam(r0 + r);
+        T v = lam - rho * c[r];
+        lp[r] = dual_proj(cd.type, v);
+        T pj = dual_proj_jac(cd.type, v);
+        a += lp[r] * lp[r];
+        bsum += lam * lam;
+        C.store_c(r0 + r, c[r]);
+#pragma unroll
+        for (int j = 0; j < nm; ++j) jac[r + j * P] = pj * jac[r + j * P];  // jac_proj = proj_jac * jac
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        T sg = T(0);
+#pragma unroll
+        for (int r = 0; r < P; ++r) sg += jac[r + i * P] * lp[r];
+        gx[i] += -sg;
+      }
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        T sg = T(0);
+#pragma unroll
+        for (int r = 0; r < P; ++r) sg += jac[r + (n + i) * P] * lp[r];
+        gu[i] += -sg;
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          T sh = T(0);
+#pragma unroll
+          for (int r = 0; r < P; ++r) sh += (rho * jac[r + i * P]) * jac[r + j * P];
+          hxx[i + j * n] += sh;
+        }
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          T sh = T(0);
+#pragma unroll
+          for (int r = 0; r < P; ++r) sh += (rho * jac[r + i * P]) * jac[r + (n + j) * P];
+          hxu[i + j * n] += sh;
+        }
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          T sh = T(0);
+#pragma unroll
+          for (int r = 0; r < P; ++r) sh += (rho * jac[r + (n + i) * P]) * jac[r + (n + j) * P];
+          huu[i + j * m] += sh;
+        }
     } else {  // CIRCLE: dc_i/d(px,py) = (2(cx-px), 2(cy-py)) (obstacle_constraints.hpp:109-121)
       T g0 = T(0), g1 = T(0), h00 = T(0), h10 = T(0), h01 = T(0), h11 = T(0);
       for (int i = 0; i < cd.p; ++i) {

@@ -616,6 +616,37 @@ class Engine final : public EngineBase {
       }
       const CostSpec& c = s.costs[ci];
       CostGroupDesc g{};
+      if (c.user) {
+        // the user model's UserCost (altro_set_user_cost): only its parameters travel
+        if constexpr (!kHasUserCost) {
+          err_ = "this model defines no UserCost (altro_set_user_cost needs a user model whose source defines ALTRO_USER_COST)";
+          return ALTRO_INVALID_ARG;
+        } else {
+          constexpr int NP = UserCostF::nparams;
+          if ((int)c.params.size() != NP * (c.per_instance ? B_ : 1)) {
+            err_ = "user cost: expected " + std::to_string(NP) + " parameters" + (c.per_instance ? " per instance" : "");
+            return ALTRO_INVALID_ARG;
+          }
+          g.user = 1;
+          g.u_pi = c.per_instance ? 1 : 0;
+          // (the quadratic fields stay valid, all-zero pool entries: every generic read is in bounds)
+          g.Q_off = g.R_off = g.q_off = g.r_off = g.c_off = (int)pool.size();
+          for (int e = 0; e < n * n + m * m; ++e) pool.push_back(T(0));
+          if (!g.u_pi) {
+            g.u_off = (int)pool.size();
+            for (int e = 0; e < NP; ++e) pool.push_back(T(c.params[e]));
+          } else {
+            g.u_off = (int)ip.size();
+            for (int e = 0; e < NP; ++e) {
+              const int sl = new_slot();
+              for (int b = 0; b < B_; ++b) ip[sl][b] = T(c.params[(size_t)b * NP + e]);
+            }
+          }
+          group_of_cost[ci] = pd_.ngroups;
+          pd_.grp[pd_.ngroups++] = g;
+          continue;
+        }
+      }
       // QuadraticCost::LQRCost (examples/quadratic_cost.hpp:29-39), evaluated in T like the oracle
       g.Q_off = (int)pool.size();
       for (int e = 0; e < n * n; ++e) pool.push_back(T(c.Q[e]));
@@ -720,6 +751,19 @@ class Engine final : public EngineBase {
         }
         d.type = 1;
         d.p = c.nparams / 3;
+      } else if (c.kind == ALTRO_CON_USER) {
+        // the user model's UserConstraint: OutputDimension and cone come from its source
+        if constexpr (!kHasUserCon) {
+          err_ = "this model defines no UserConstraint (ALTRO_CON_USER needs a user model whose source defines ALTRO_USER_CONSTRAINT)";
+          return ALTRO_INVALID_ARG;
+        } else {
+          if (c.nparams != UserConF::nparams) {
+            err_ = "user constraint: expected " + std::to_string(UserConF::nparams) + " parameters";
+            return ALTRO_INVALID_ARG;
+          }
+          d.type = UserConF::equality ? 0 : 1;
+          d.p = UserConF::p;
+        }
       } else {
         err_ = "unknown constraint kind";
         return ALTRO_INVALID_ARG;

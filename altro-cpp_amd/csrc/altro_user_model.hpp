@@ -18,13 +18,19 @@
 // the user's dynamics, exactly as the built-in models are -- plus the device-side counterpart of
 // FunctionBase::CheckJacobian (altro/common/functionbase.cpp:35-73), which is run once at registration.
 // No file of the library is edited to add a model.
+//
+// The same source may define the reference's other two plug-in classes (include/altro_hip.h): a cost function
+// (problem::CostFunction, costfunction.hpp:52-73 -> struct UserCost, #define ALTRO_USER_COST UserCost) and a
+// constraint (constraints::Constraint<ConType>, constraint.hpp:173-202 -> struct UserConstraint,
+// #define ALTRO_USER_CONSTRAINT UserConstraint).  altro_device.hpp picks them up (UserCostF / UserConF); their
+// derivatives are checked on the device like the model's (k_check_functors below).
 #pragma once
 
 #include "altro_engine.hpp"
 
 namespace altro_hip {
 
-#define ALTRO_USER_PLUGIN_ABI 2  // bump when EngineBase or the entry points below change
+#define ALTRO_USER_PLUGIN_ABI 3  // bump when EngineBase or the entry points below change
 
 struct UserM : altro_user::UserModel {
   static constexpr bool kHasFusedRk4 = false;
@@ -61,6 +67,69 @@ __global__ void k_check_jacobian(const double* __restrict__ z, double* __restric
   err[s] = sqrt(e2);
 }
 
+// ScalarFunction::CheckGradient, FunctionBase::CheckHessian (functionbase.cpp:75-125) for the user's cost and
+// FunctionBase::CheckJacobian for the user's constraint, one sample (x, u, parameters) per thread, forward
+// differences: err[3 s + 0] = ||fd(eval) - gradient||, [3 s + 1] = ||fd(gradient) - hessian||_F,
+// [3 s + 2] = ||fd(eval) - jacobian||_F.
+template <int n, int m>
+__global__ void k_check_functors(const double* __restrict__ z, const double* __restrict__ par_cost,
+                                 const double* __restrict__ par_con, double* __restrict__ err, int samples, double eps) {
+  constexpr int nm = n + m;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= samples) return;
+  double x[nm];
+#pragma unroll
+  for (int i = 0; i < nm; ++i) x[i] = z[(size_t)s * nm + i];
+  double eg = 0.0, eh = 0.0, ej = 0.0;
+  if constexpr (kHasUserCost) {
+    constexpr int NP = UserCostF::nparams;
+    double par[NP > 0 ? NP : 1];
+    for (int i = 0; i < NP; ++i) par[i] = par_cost[(size_t)s * NP + i];
+    double g0[nm], g1[nm], H[nm * nm], hxx[n * n], hxu[n * m], huu[m * m];
+    const double J0 = UserCostF::eval(x, x + n, par);
+    UserCostF::gradient(x, x + n, par, g0, g0 + n);
+    UserCostF::hessian(x, x + n, par, hxx, hxu, huu);
+    for (int j = 0; j < nm; ++j)
+      for (int i = 0; i < nm; ++i)
+        H[i + j * nm] = (i < n && j < n) ? hxx[i + j * n] : (i < n) ? hxu[i + (j - n) * n] : (j < n) ? hxu[j + (i - n) * n]
+                                                                                                     : huu[(i - n) + (j - n) * m];
+    for (int j = 0; j < nm; ++j) {
+      const double keep = x[j];
+      x[j] = keep + eps;
+      const double J1 = UserCostF::eval(x, x + n, par);
+      UserCostF::gradient(x, x + n, par, g1, g1 + n);
+      x[j] = keep;
+      const double dg = (J1 - J0) / eps - g0[j];
+      eg += dg * dg;
+      for (int i = 0; i < nm; ++i) {
+        const double dh = (g1[i] - g0[i]) / eps - H[i + j * nm];
+        eh += dh * dh;
+      }
+    }
+  }
+  if constexpr (kHasUserCon) {
+    constexpr int P = UserConF::p, NP = UserConF::nparams;
+    double par[NP > 0 ? NP : 1];
+    for (int i = 0; i < NP; ++i) par[i] = par_con[(size_t)s * NP + i];
+    double c0[P], c1[P], J[P * nm];
+    UserConF::eval(x, x + n, par, c0);
+    UserConF::jacobian(x, x + n, par, J);
+    for (int j = 0; j < nm; ++j) {
+      const double keep = x[j];
+      x[j] = keep + eps;
+      UserConF::eval(x, x + n, par, c1);
+      x[j] = keep;
+      for (int r = 0; r < P; ++r) {
+        const double dj = (c1[r] - c0[r]) / eps - J[r + j * P];
+        ej += dj * dj;
+      }
+    }
+  }
+  err[3 * s + 0] = sqrt(eg);
+  err[3 * s + 1] = sqrt(eh);
+  err[3 * s + 2] = sqrt(ej);
+}
+
 }  // namespace altro_hip
 
 extern "C" {
@@ -77,6 +146,67 @@ altro_hip::EngineBase* altro_user_make_engine(const altro_desc* d, std::string* 
   using namespace altro_hip;
   if (d->dtype == ALTRO_F64) return MakeEngineImpl<double, UserM>(*d, err);
   return MakeEngineImpl<double, WithRec32<UserM>>(*d, err);
+}
+
+// What the source defines besides the model: bit 0 a UserCost, bit 1 a UserConstraint; their parameter counts,
+// the constraint's OutputDimension and cone.
+int altro_user_functor_info(int* cost_nparams, int* con_p, int* con_nparams, int* con_equality) {
+  using namespace altro_hip;
+  *cost_nparams = kHasUserCost ? UserCostF::nparams : 0;
+  *con_p = kHasUserCon ? UserConF::p : 0;
+  *con_nparams = kHasUserCon ? UserConF::nparams : 0;
+  *con_equality = (kHasUserCon && UserConF::equality) ? 1 : 0;
+  return (kHasUserCost ? 1 : 0) | (kHasUserCon ? 2 : 0);
+}
+
+// Device-side CheckGradient / CheckHessian / CheckJacobian of the user's cost and constraint at `samples` points:
+// z = (x, u) from the caller, parameters uniform in [0.5, 1.5] (weights, radii, limits: positive).
+// errs[0..2] = the largest gradient, Hessian and constraint-Jacobian error.  Returns 0 or a HIP error code.
+int altro_user_check_functors(int device, const double* z_host, int samples, double eps, double* errs) {
+  using namespace altro_hip;
+  errs[0] = errs[1] = errs[2] = 0.0;
+  if (!kHasUserCost && !kHasUserCon) return 0;
+  constexpr int nm = UserM::n + UserM::m;
+  constexpr int NPc = kHasUserCost ? UserCostF::nparams : 0, NPk = kHasUserCon ? UserConF::nparams : 0;
+  if (hipSetDevice(device) != hipSuccess) return 1;
+  std::vector<double> pc((size_t)samples * (NPc > 0 ? NPc : 1)), pk((size_t)samples * (NPk > 0 ? NPk : 1));
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {  // splitmix64
+    unsigned long long v = (st += 0x9E3779B97F4A7C15ull);
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    return 0.5 + (double)((v ^ (v >> 31)) >> 11) * 0x1p-53;
+  };
+  for (double& v : pc) v = next();
+  for (double& v : pk) v = next();
+  double *dz = nullptr, *dpc = nullptr, *dpk = nullptr, *derr = nullptr;
+  int rc = 0;
+  if (hipMalloc((void**)&dz, (size_t)samples * nm * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&dpc, pc.size() * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&dpk, pk.size() * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&derr, (size_t)samples * 3 * sizeof(double)) != hipSuccess)
+    rc = 2;
+  std::vector<double> herr((size_t)samples * 3, 0.0);
+  if (!rc && (hipMemcpy(dz, z_host, (size_t)samples * nm * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(dpc, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(dpk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+    rc = 3;
+  if (!rc) {
+    hipLaunchKernelGGL((k_check_functors<UserM::n, UserM::m>), dim3((samples + 63) / 64), dim3(64), 0, nullptr, dz, dpc, dpk,
+                       derr, samples, eps);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = 4;
+  }
+  if (!rc && hipMemcpy(herr.data(), derr, herr.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
+  hipFree(dz);
+  hipFree(dpc);
+  hipFree(dpk);
+  hipFree(derr);
+  for (int s = 0; s < samples; ++s)
+    for (int q = 0; q < 3; ++q) {
+      const double e = herr[(size_t)3 * s + q];
+      if (e > errs[q] || e != e) errs[q] = e;
+    }
+  return rc;
 }
 
 // Device-side CheckJacobian at `samples` points z = (x, u) given by the caller (uniform in [-1, 1], like

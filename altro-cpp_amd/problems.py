@@ -175,6 +175,34 @@ def cartpole_move(make, model_kind, batch=1, N=60, dtype=F64, goal=None, **kw):
     return s
 
 
+def cartpole_track(make, model_kind, batch=1, N=60, dtype=F64, goal=None, sway=0.04, **kw):
+    """The cart-pole move with the user's own cost and constraint (tests/models/cartpole_track.hpp): stage and
+    terminal cost = UserCost (with the non-quadratic pendulum term), the sway of the pole tip limited to +-sway by
+    UserConstraint on every knot after the first, plus the built-in force bound and goal constraint."""
+    n, m = 4, 1
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.05)
+    hd = float(h)
+    goal = np.full(batch, 1.0) if goal is None else np.broadcast_to(np.asarray(goal, dtype=np.float64), (batch,))
+    xf = np.zeros((batch, n))
+    xf[:, 0] = goal
+    stage = np.stack([goal, np.full(batch, 1e-1 * hd), np.full(batch, 2.0 * hd), np.full(batch, 1e-1 * hd),
+                      np.full(batch, 1e-1 * hd), np.full(batch, 1e-2 * hd)], axis=1)
+    term = np.stack([goal, np.full(batch, 100.0), np.full(batch, 100.0), np.full(batch, 100.0),
+                     np.full(batch, 100.0), np.zeros(batch)], axis=1)
+    corridor = np.stack([np.full(batch, -sway), np.full(batch, sway)], axis=1)
+    s.set_model(model_kind)
+    s.set_uniform_step(h)
+    s.set_user_cost(0, N, stage)
+    s.set_user_cost(N, N + 1, term)
+    s.add_control_bound(0, N, [-3.0], [3.0])
+    s.add_user_constraint(1, N + 1, corridor)
+    s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
 # ---------------------------------------------------------------------------------------------------
 # Seeded synthetic batches (SURVEY.md section 8(d)); instance 0 = the exact reference problem.
 # The generator is std::mt19937_64 (the C++ facade, include/altro/problems.hpp, draws the same numbers from

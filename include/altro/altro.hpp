@@ -196,6 +196,7 @@ class Trajectory {
 namespace examples {
 struct Unicycle {  // examples/unicycle.hpp
   static constexpr int kind = ALTRO_MODEL_UNICYCLE;
+  int Kind() const { return kind; }
   int StateDimension() const { return 3; }
   int ControlDimension() const { return 2; }
   std::vector<double> Params() const { return {}; }
@@ -203,6 +204,7 @@ struct Unicycle {  // examples/unicycle.hpp
 struct TripleIntegrator {  // examples/triple_integrator.hpp
   static constexpr int kind = ALTRO_MODEL_TRIPLE_INTEGRATOR;
   explicit TripleIntegrator(int dof = 1) : dof_(dof) {}
+  int Kind() const { return kind; }
   int StateDimension() const { return 3 * dof_; }
   int ControlDimension() const { return dof_; }
   std::vector<double> Params() const { return {static_cast<double>(dof_)}; }
@@ -210,15 +212,45 @@ struct TripleIntegrator {  // examples/triple_integrator.hpp
 };
 struct Quadrotor12 {  // build-defined model of BASELINE config 5
   static constexpr int kind = ALTRO_MODEL_QUADROTOR12;
+  int Kind() const { return kind; }
   int StateDimension() const { return 12; }
   int ControlDimension() const { return 4; }
   std::vector<double> Params() const { return {}; }
+};
+
+// The caller's own plug-in classes.  In the reference a user subclasses problem::ContinuousDynamics
+// (altro/problem/dynamics.hpp:59-95), problem::CostFunction (costfunction.hpp:52-73) and
+// constraints::Constraint<ConType> (constraint.hpp:173-202); a kernel cannot call host virtual functions, so here
+// the three travel as SOURCE (include/altro_hip.h, altro_register_model_source): `struct UserModel { n, m, f, jac }`
+// and, optionally, `struct UserCost` / `struct UserConstraint` announced by ALTRO_USER_COST / ALTRO_USER_CONSTRAINT.
+// The constructor compiles (or loads from the on-disk cache) the plugin and runs the device-side
+// CheckJacobian / CheckGradient / CheckHessian; errors (compiler output included) are thrown.
+struct UserModel {
+  UserModel(const std::string& name, const std::string& source, int n, int m, bool check_derivatives = true)
+      : n_(n), m_(m) {
+    const altro_status st = altro_register_model_source(name.c_str(), source.c_str(), check_derivatives ? 1 : 0, &kind_);
+    if (st != ALTRO_OK) {
+      const char* msg = altro_last_error(nullptr);
+      throw std::runtime_error("altro_register_model_source failed (" + std::to_string((int)st) + "): " + (msg ? msg : ""));
+    }
+  }
+  int Kind() const { return kind_; }
+  int StateDimension() const { return n_; }
+  int ControlDimension() const { return m_; }
+  std::vector<double> Params() const { return {}; }
+
+ private:
+  int kind_ = 0, n_, m_;
 };
 
 // examples/quadratic_cost.hpp:29-39.  xref may hold one reference or `batch` references.
 struct QuadraticCost {
   std::vector<double> Q, R, xref, uref;
   bool terminal = false;
+  // the UserCost of the problem's UserModel instead (see UserCost below): its parameters, one block or `batch` blocks
+  bool user = false;
+  std::vector<double> user_params;
+  int user_nparams = 0;
   static QuadraticCost LQRCost(const std::vector<double>& Q, const std::vector<double>& R,
                                const std::vector<double>& xref, const std::vector<double>& uref,
                                bool terminal = false) {
@@ -231,7 +263,17 @@ struct QuadraticCost {
     return c;
   }
   bool operator==(const QuadraticCost& o) const {
-    return Q == o.Q && R == o.R && xref == o.xref && uref == o.uref && terminal == o.terminal;
+    return Q == o.Q && R == o.R && xref == o.xref && uref == o.uref && terminal == o.terminal && user == o.user &&
+           user_params == o.user_params && user_nparams == o.user_nparams;
+  }
+};
+// problem::CostFunction of the caller (costfunction.hpp:52-73): the `struct UserCost` of the UserModel's source with
+// these parameters (UserCost::nparams doubles, or `batch` such blocks back to back).
+struct UserCost : QuadraticCost {
+  explicit UserCost(const std::vector<double>& params, int nparams = -1) {
+    user = true;
+    user_params = params;
+    user_nparams = nparams >= 0 ? nparams : static_cast<int>(params.size());
   }
 };
 
@@ -240,17 +282,33 @@ struct ConstraintDesc {
   std::vector<double> params;  // one instance's block, or batch blocks back to back
   int nparams = 0;             // length of one instance's block
   std::string label;
+  int user_p = 0;              // USER: OutputDimension of the source's UserConstraint
+  bool user_equality = false;  // USER: its cone (constraints::Equality / NegativeOrthant)
   bool operator==(const ConstraintDesc& o) const { return kind == o.kind && params == o.params && nparams == o.nparams; }
-  bool IsEquality() const { return kind == ALTRO_CON_GOAL; }
+  bool IsEquality() const { return kind == ALTRO_CON_GOAL || (kind == ALTRO_CON_USER && user_equality); }
   // Constraint<ConType>::GetConstraintType, altro/constraints/constraint.hpp:193-201
   std::string GetConstraintType() const { return IsEquality() ? "Equality Constraint" : "Inequality Constraint"; }
   int OutputDimension() const {
+    if (kind == ALTRO_CON_USER) return user_p;
     if (kind == ALTRO_CON_GOAL) return nparams;
     if (kind == ALTRO_CON_CIRCLE) return nparams / 3;
     int p = 0;  // CONTROL_BOUND: one row per finite bound (basic_constraints.hpp:138-145)
     for (int i = 0; i < nparams; ++i)
       if (std::abs(params[i]) < std::numeric_limits<double>::max()) ++p;
     return p;
+  }
+};
+// constraints::Constraint<ConType> of the caller (constraint.hpp:173-202): the `struct UserConstraint` of the
+// UserModel's source with these parameters; p = its OutputDimension, equality = its cone.
+struct UserConstraint : ConstraintDesc {
+  UserConstraint(const std::vector<double>& par, int p, bool equality = false, int npar = -1,
+                 const std::string& name = "User Constraint") {
+    kind = ALTRO_CON_USER;
+    params = par;
+    nparams = npar >= 0 ? npar : static_cast<int>(par.size());
+    user_p = p;
+    user_equality = equality;
+    label = name;
   }
 };
 // examples/basic_constraints.hpp:15-40
@@ -322,7 +380,7 @@ class Problem {
   void SetDynamics(const DiscretizedModel<Model>& dm, int k) {
     Range(k);
     if (k >= N_) throw std::runtime_error("dynamics are set on knots 0..N-1");
-    model_kind_ = Model::kind;
+    model_kind_ = dm.model.Kind();
     model_params_ = dm.model.Params();
     n_ = dm.model.StateDimension();
     m_ = dm.model.ControlDimension();
@@ -371,9 +429,14 @@ class Problem {
       int e = k + 1;
       while (e <= N_ && costs_[e] == costs_[k]) ++e;
       const auto& c = costs_[k];
-      const int per = ((int)c.xref.size() > n_ ? 1 : 0) | ((int)c.uref.size() > m_ ? 2 : 0);
-      Check(h, altro_set_lqr_cost(h, k, e, c.Q.data(), c.R.data(), c.xref.data(), c.uref.data(), per),
-            "altro_set_lqr_cost");
+      if (c.user) {
+        Check(h, altro_set_user_cost(h, k, e, c.user_params.data(), c.user_nparams,
+                                     (int)c.user_params.size() > c.user_nparams ? 1 : 0), "altro_set_user_cost");
+      } else {
+        const int per = ((int)c.xref.size() > n_ ? 1 : 0) | ((int)c.uref.size() > m_ ? 2 : 0);
+        Check(h, altro_set_lqr_cost(h, k, e, c.Q.data(), c.R.data(), c.xref.data(), c.uref.data(), per),
+              "altro_set_lqr_cost");
+      }
       k = e;
     }
     // insertion order within a knot is what matters (al_cost.hpp:267-272): emit constraint j of each knot

@@ -72,7 +72,8 @@ typedef enum altro_model_kind {
 typedef enum altro_constraint_kind {
   ALTRO_CON_GOAL = 1,          /* equality   c = x - xf          basic_constraints.hpp:15-40   */
   ALTRO_CON_CONTROL_BOUND = 2, /* inequality c = [lb-u; u-ub]    basic_constraints.hpp:42-151  */
-  ALTRO_CON_CIRCLE = 3         /* inequality c_i = r^2 - |p-c_i|^2  obstacle_constraints.hpp:69-127 */
+  ALTRO_CON_CIRCLE = 3,        /* inequality c_i = r^2 - |p-c_i|^2  obstacle_constraints.hpp:69-127 */
+  ALTRO_CON_USER = 4           /* the UserConstraint of the handle's user model, see altro_register_model_source */
 } altro_constraint_kind;
 
 /* altro::SolverStatus, altro/common/solver_stats.hpp:20-31 (same numeric values). */
@@ -195,7 +196,30 @@ altro_status altro_set_model(altro_handle h, int kind, const double* params, int
  * altro_set_model.  check_jacobian != 0 runs the device-side FunctionBase::CheckJacobian
  * (altro/common/functionbase.cpp:35-73: forward differences, 64 random points, tolerance 1e-4) once -- now if a
  * device is present, else when the first handle using the model is created; a mismatch is ALTRO_INVALID_ARG.
- * Errors (compiler output included) are reported through altro_last_error(NULL).  No CPU fallback. */
+ * Errors (compiler output included) are reported through altro_last_error(NULL).  No CPU fallback.
+ *
+ * USER-DEFINED COST AND CONSTRAINT -- the other two plug-in classes of the reference (problem::CostFunction,
+ * altro/problem/costfunction.hpp:52-73: Evaluate / Gradient / Hessian; constraints::Constraint<ConType>,
+ * altro/constraints/constraint.hpp:173-202: OutputDimension / Evaluate / Jacobian) travel in the same source, both
+ * optional and announced by a macro:
+ *     struct UserCost {
+ *       static constexpr int nparams = ...;      // doubles handed to every call (altro_set_user_cost)
+ *       template <class T> ALTRO_MODEL_FN static T    eval(const T* x, const T* u, const T* par);
+ *       template <class T> ALTRO_MODEL_FN static void gradient(const T* x, const T* u, const T* par, T* dx, T* du);
+ *       template <class T> ALTRO_MODEL_FN static void hessian(const T* x, const T* u, const T* par,
+ *                                                          T* dxdx, T* dxdu, T* dudu);  // n x n, n x m, m x m, column-major
+ *     };
+ *     #define ALTRO_USER_COST UserCost
+ *     struct UserConstraint {
+ *       static constexpr int p = ..., nparams = ...;   // OutputDimension; doubles handed to every call
+ *       static constexpr bool equality = false;        // ConType: constraints::Equality or NegativeOrthant (c <= 0)
+ *       template <class T> ALTRO_MODEL_FN static void eval(const T* x, const T* u, const T* par, T* c);
+ *       template <class T> ALTRO_MODEL_FN static void jacobian(const T* x, const T* u, const T* par, T* J);  // p x (n+m), column-major
+ *     };
+ *     #define ALTRO_USER_CONSTRAINT UserConstraint
+ * With check_jacobian != 0 the gradient, the Hessian and the constraint Jacobian are checked against finite
+ * differences on the device as well (FunctionBase::CheckGradient / CheckHessian / CheckJacobian,
+ * functionbase.cpp:42-125).  At the terminal knot u is the zero vector, as in the reference. */
 altro_status altro_register_model_source(const char* name, const char* source, int check_jacobian, int* kind_out);
 
 /* Trajectory::SetUniformStep (trajectory.hpp:122-130).  hstep > 0.  Belongs to the trajectory, not to the
@@ -210,6 +234,12 @@ altro_status altro_set_uniform_step(altro_handle h, float hstep);
 altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const double* Q,
                                 const double* R, const double* xref, const double* uref,
                                 int per_instance);
+
+/* Problem::SetCostFunction(std::make_shared<UserCost>(params), k) for k_begin <= k < k_end (problem.hpp:113-127)
+ * with the UserCost of the handle's user model (altro_register_model_source).  params: UserCost::nparams doubles,
+ * [B][nparams] when per_instance != 0.  The last cost set on a knot wins, whichever kind. */
+altro_status altro_set_user_cost(altro_handle h, int k_begin, int k_end, const double* params, int nparams,
+                                 int per_instance);
 
 /* Problem::SetConstraint(con, k) for k_begin <= k < k_end (problem.hpp:178-202).  Insertion order
  * is kept: at each knot the AL cost visits all equalities, then all inequalities, each in

@@ -29,6 +29,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../include/altro_hip.h"  // POD structs and enums only
@@ -137,6 +138,38 @@ struct UserModelAdapter {
   void jac(const T* x, const T* u, T* J) const { altro_user::UserModel::jac(x, u, J); }
 };
 #endif
+template <class M>
+struct IsUserModel : std::false_type {};
+#ifdef ORACLE_USER_MODEL
+template <class T>
+struct IsUserModel<UserModelAdapter<T>> : std::true_type {};
+#endif
+// The user's cost / constraint functors of the same source (problem::CostFunction, costfunction.hpp:52-73;
+// constraints::Constraint<ConType>, constraint.hpp:173-202), or stand-ins that are never called.
+#if defined(ORACLE_USER_MODEL) && defined(ALTRO_USER_COST)
+using UserCostF = altro_user::ALTRO_USER_COST;
+constexpr bool kHasUserCost = true;
+#else
+struct UserCostF {
+  static constexpr int nparams = 0;
+  template <class T> static T eval(const T*, const T*, const T*) { return T(0); }
+  template <class T> static void gradient(const T*, const T*, const T*, T*, T*) {}
+  template <class T> static void hessian(const T*, const T*, const T*, T*, T*, T*) {}
+};
+constexpr bool kHasUserCost = false;
+#endif
+#if defined(ORACLE_USER_MODEL) && defined(ALTRO_USER_CONSTRAINT)
+using UserConF = altro_user::ALTRO_USER_CONSTRAINT;
+constexpr bool kHasUserCon = true;
+#else
+struct UserConF {
+  static constexpr int p = 1, nparams = 0;
+  static constexpr bool equality = false;
+  template <class T> static void eval(const T*, const T*, const T*, T*) {}
+  template <class T> static void jacobian(const T*, const T*, const T*, T*) {}
+};
+constexpr bool kHasUserCon = false;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Host-side problem specification (dtype independent, fp64).
@@ -145,6 +178,8 @@ struct CostSpec {
   int k_begin, k_end;
   std::vector<double> Q, R, xref, uref;
   int per_instance;
+  int user = 0;  // oracle_set_user_cost: the user's cost with `params`
+  std::vector<double> params;
 };
 struct ConSpec {
   int kind, k_begin, k_end, nparams, per_instance;
@@ -233,6 +268,8 @@ struct Instance final : SolverBase {
 
   struct QCost {  // examples/quadratic_cost.hpp:13-27
     T Q[n * n], R[m * m], H[n * m], q[n], r[m], c;
+    bool user = false;    // the user's problem::CostFunction instead
+    std::vector<T> upar;  // its parameters
   };
   struct Con {  // altro/constraints/constraint_values.hpp:39-51
     int kind, type /*0 equality, 1 inequality*/, p;
@@ -303,6 +340,7 @@ struct Instance final : SolverBase {
   void SetLQRCost(int k, const double* Q, const double* R, const double* xref, const double* uref) {
     // QuadraticCost::LQRCost, examples/quadratic_cost.hpp:29-39
     QCost& c = cost[k];
+    c.user = false;
     for (int i = 0; i < n * n; ++i) c.Q[i] = T(Q[i]);
     for (int i = 0; i < m * m; ++i) c.R[i] = T(R[i]);
     for (int i = 0; i < n * m; ++i) c.H[i] = T(0);
@@ -326,10 +364,19 @@ struct Instance final : SolverBase {
     for (int i = 0; i < m; ++i) b += ur[i] * Ru[i];
     c.c = T(0.5) * a + T(0.5) * b;
   }
+  void SetUserCost(int k, const double* par, int npar) {
+    QCost& c = cost[k];
+    c.user = true;
+    c.upar.assign(par, par + npar);
+  }
   void AddConstraint(int k, int kind, const double* par, int npar) {
     Con c;
     c.kind = kind;
-    if (kind == ALTRO_CON_GOAL) {
+    if (kind == ALTRO_CON_USER) {
+      c.type = UserConF::equality ? 0 : 1;
+      c.p = UserConF::p;
+      c.par.assign(par, par + npar);
+    } else if (kind == ALTRO_CON_GOAL) {
       c.type = 0;
       c.p = n;
       c.par.resize(n);
@@ -379,7 +426,9 @@ struct Instance final : SolverBase {
   // ---- constraint evaluation ---------------------------------------------------------------
   // con_->Evaluate (basic_constraints.hpp:27-31,98-111; obstacle_constraints.hpp:99-107)
   static void ConEval(Con& c, const T* x, const T* u) {
-    if (c.kind == ALTRO_CON_GOAL) {
+    if (c.kind == ALTRO_CON_USER) {
+      if constexpr (IsUserModel<Model>::value) UserConF::eval(x, u, c.par.data(), c.c.data());
+    } else if (c.kind == ALTRO_CON_GOAL) {
       for (int i = 0; i < n; ++i) c.c[i] = x[i] - c.par[i];
     } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
       int nl = (int)c.lo.size();
@@ -394,9 +443,14 @@ struct Instance final : SolverBase {
     }
   }
   // con_->Jacobian; jac is p x (n+m), row r at jac[r*nm .. r*nm+nm)
-  static void ConJac(const Con& c, const T* x, const T*, T* jac) {
+  static void ConJac(const Con& c, const T* x, const T* u, T* jac) {
     for (int i = 0; i < c.p * nm; ++i) jac[i] = T(0);
-    if (c.kind == ALTRO_CON_GOAL) {
+    if (c.kind == ALTRO_CON_USER) {
+      T Jcm[UserConF::p * nm] = {};  // the user's Jacobian is p x (n+m) column-major (Eigen's default)
+      if constexpr (IsUserModel<Model>::value) UserConF::jacobian(x, u, c.par.data(), Jcm);
+      for (int r = 0; r < c.p; ++r)
+        for (int j = 0; j < nm; ++j) jac[r * nm + j] = Jcm[r + j * c.p];
+    } else if (c.kind == ALTRO_CON_GOAL) {
       for (int i = 0; i < n; ++i) jac[i * nm + i] = T(1);
     } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
       int nl = (int)c.lo.size();
@@ -431,6 +485,9 @@ struct Instance final : SolverBase {
 
   // QuadraticCost::Evaluate, examples/quadratic_cost.cpp:8-11
   static T QuadEval(const QCost& c, const T* x, const T* u) {
+    if constexpr (IsUserModel<Model>::value) {
+      if (c.user) return UserCostF::eval(x, u, c.upar.data());  // CostFunction::Evaluate
+    }
     T xQx = 0, xHu = 0, uRu = 0, qx = 0, ru = 0;
     for (int i = 0; i < n; ++i) {
       T s = 0;
@@ -466,21 +523,28 @@ struct Instance final : SolverBase {
     T* hxx = &lxx[k * n * n];
     T* hxu = &lxu[k * n * m];
     T* huu = &luu[k * m * m];
-    for (int i = 0; i < n; ++i) {
-      T s = 0, t = 0;
-      for (int j = 0; j < n; ++j) s += qc.Q[i + j * n] * x[j];
-      for (int j = 0; j < m; ++j) t += qc.H[i + j * n] * u[j];
-      gx[i] = s + qc.q[i] + t;
+    if (IsUserModel<Model>::value && qc.user) {  // CostFunction::Gradient / Hessian of the user's cost (costfunction.hpp:59-73)
+      if constexpr (IsUserModel<Model>::value) {
+        UserCostF::gradient(x, u, qc.upar.data(), gx, gu);
+        UserCostF::hessian(x, u, qc.upar.data(), hxx, hxu, huu);
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        T s = 0, t = 0;
+        for (int j = 0; j < n; ++j) s += qc.Q[i + j * n] * x[j];
+        for (int j = 0; j < m; ++j) t += qc.H[i + j * n] * u[j];
+        gx[i] = s + qc.q[i] + t;
+      }
+      for (int i = 0; i < m; ++i) {
+        T s = 0, t = 0;
+        for (int j = 0; j < m; ++j) s += qc.R[i + j * m] * u[j];
+        for (int j = 0; j < n; ++j) t += qc.H[j + i * n] * x[j];
+        gu[i] = s + qc.r[i] + t;
+      }
+      for (int i = 0; i < n * n; ++i) hxx[i] = qc.Q[i];
+      for (int i = 0; i < n * m; ++i) hxu[i] = qc.H[i];
+      for (int i = 0; i < m * m; ++i) huu[i] = qc.R[i];
     }
-    for (int i = 0; i < m; ++i) {
-      T s = 0, t = 0;
-      for (int j = 0; j < m; ++j) s += qc.R[i + j * m] * u[j];
-      for (int j = 0; j < n; ++j) t += qc.H[j + i * n] * x[j];
-      gu[i] = s + qc.r[i] + t;
-    }
-    for (int i = 0; i < n * n; ++i) hxx[i] = qc.Q[i];
-    for (int i = 0; i < n * m; ++i) hxu[i] = qc.H[i];
-    for (int i = 0; i < m * m; ++i) huu[i] = qc.R[i];
     // scratch reused across calls (one solver instance is only ever used by one thread at a time)
     std::vector<T>& jac = scratch_jac_;
     std::vector<T>& jp = scratch_jp_;
@@ -1173,6 +1237,12 @@ std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& md
   for (int k = 0; k < D.N; ++k) I.h[k] = h->hstep;
   I.h[D.N] = 0.0f;
   for (const CostSpec& c : h->costs) {
+    if (c.user) {
+      const int np = UserCostF::nparams;
+      const double* par = c.params.data() + (c.per_instance ? (size_t)b * np : 0);
+      for (int k = c.k_begin; k < c.k_end; ++k) I.SetUserCost(k, par, np);
+      continue;
+    }
     const double* xr = c.xref.data() + ((c.per_instance & 1) ? (size_t)b * n : 0);
     const double* ur = c.uref.data() + ((c.per_instance & 2) ? (size_t)b * m : 0);
     for (int k = c.k_begin; k < c.k_end; ++k) I.SetLQRCost(k, c.Q.data(), c.R.data(), xr, ur);
@@ -1329,6 +1399,20 @@ altro_status oracle_set_lqr_cost(oracle_handle h, int k_begin, int k_end, const 
   h->built = false;
   return ALTRO_OK;
 }
+altro_status oracle_set_user_cost(oracle_handle h, int k_begin, int k_end, const double* params, int nparams,
+                                  int per_instance) {
+  if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
+  if (!kHasUserCost || nparams != UserCostF::nparams) return ALTRO_INVALID_ARG;
+  CostSpec c;
+  c.k_begin = k_begin;
+  c.k_end = k_end;
+  c.per_instance = per_instance ? 1 : 0;
+  c.user = 1;
+  if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
+  h->costs.push_back(std::move(c));
+  h->built = false;
+  return ALTRO_OK;
+}
 altro_status oracle_add_constraint(oracle_handle h, int kind, int k_begin, int k_end,
                                    const double* params, int nparams, int per_instance) {
   if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
@@ -1338,7 +1422,8 @@ altro_status oracle_add_constraint(oracle_handle h, int kind, int k_begin, int k
   c.k_end = k_end;
   c.nparams = nparams;
   c.per_instance = per_instance;
-  c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
+  if (kind == ALTRO_CON_USER && (!kHasUserCon || nparams != UserConF::nparams)) return ALTRO_INVALID_ARG;
+  if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
   h->cons.push_back(std::move(c));
   h->built = false;
   return ALTRO_OK;

@@ -6,7 +6,7 @@ import __graft_entry__ as g
 A = g.load_package()
 P = importlib.import_module("altro_cpp_amd.problems")
 hm = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
-for B in (3, 64, 4096):
+for B in [int(x) for x in os.environ.get("PROBE_B", "3,64,4096").split(",")]:
     res = {}
     for N in (100, 200):
         s = P.batch_turn90(hm, batch=B, N=N)

@@ -4,6 +4,8 @@
 //   build: make -C tests/cpp        run: tests/cpp/facade_reference_tests   (needs a GPU; exit code = failures)
 #include <cmath>
 #include <cstdio>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -253,11 +255,56 @@ static void ExampleTests() {
   }
 }
 
+// ---- the reference's plug-in classes (ContinuousDynamics, CostFunction, Constraint<ConType>) on the facade ----------
+// tests/models/cartpole_track.hpp defines all three; tests/test_user_model_gpu.py checks the same problem against
+// the oracle, here the facade path (examples::UserModel / UserCost / UserConstraint -> Problem -> solver) is driven.
+static void UserFunctorTests() {
+  CASE("User-defined dynamics, cost function and constraint through the facade (dynamics.hpp:59-95, "
+       "costfunction.hpp:52-73, constraint.hpp:173-202)");
+  std::ifstream f(TRACK_SOURCE_PATH);
+  std::stringstream src;
+  src << f.rdbuf();
+  EXPECT(!src.str().empty());
+  const int N = 60;
+  const double goal = 1.2, sway = 0.04, h = 0.05;
+  examples::UserModel model("cartpole_track", src.str(), 4, 1);
+  problem::Problem prob(N);
+  const examples::UserCost stage({goal, 1e-1 * h, 2.0 * h, 1e-1 * h, 1e-1 * h, 1e-2 * h});
+  const examples::UserCost term({goal, 100.0, 100.0, 100.0, 100.0, 0.0});
+  for (int k = 0; k < N; ++k) {
+    prob.SetDynamics(problem::DiscretizedModel<examples::UserModel>(model), k);
+    prob.SetCostFunction(stage, k);
+    prob.SetConstraint(examples::ControlBound({-3.0}, {3.0}), k);
+  }
+  prob.SetCostFunction(term, N);
+  for (int k = 1; k <= N; ++k) prob.SetConstraint(examples::UserConstraint({-sway, sway}, 2), k);
+  prob.SetConstraint(examples::GoalConstraint({goal, 0.0, 0.0, 0.0}), N);
+  prob.SetInitialState({0.0, 0.0, 0.0, 0.0});
+  EXPECT(prob.IsFullyDefined());
+  EXPECT(prob.NumConstraints(0) == 2 && prob.NumConstraints(1) == 4 && prob.NumConstraints(N) == 6);
+  augmented_lagrangian::AugmentedLagrangianiLQR<4, 1> solver(prob);
+  auto Z = std::make_shared<Trajectory<4, 1>>(N);
+  Z->SetUniformStep(static_cast<float>(h));
+  solver.SetTrajectory(Z);
+  solver.Solve();
+  EXPECT(solver.GetStatus() == SolverStatus::kSolved);
+  EXPECT(solver.MaxViolation() < 1e-4);
+  double worst = 0.0;
+  for (int k = 0; k <= N; ++k) worst = std::max(worst, std::abs(0.5 * std::sin(Z->State(k)[1])));
+  EXPECT(worst > sway - 1e-3 && worst < sway + 1e-3);  // the sway limit is active and held
+  EXPECT(std::abs(Z->State(N)[0] - goal) < 1e-3 && std::abs(Z->State(N)[2]) < 1e-3);
+  const auto info = solver.GetConstraintInfo();
+  bool seen = false;
+  for (const auto& ci : info) seen = seen || ci.label == "User Constraint";
+  EXPECT(seen);
+}
+
 int main() {
   try {
     UnicycleiLQRTest();
     AugLagTest();
     ExampleTests();
+    UserFunctorTests();
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 100;

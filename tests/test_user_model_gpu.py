@@ -10,11 +10,22 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CARTPOLE = open(os.path.join(ROOT, "tests", "models", "cartpole.hpp")).read()
+TRACK = open(os.path.join(ROOT, "tests", "models", "cartpole_track.hpp")).read()  # + UserCost + UserConstraint
 
 
 @pytest.fixture(scope="module")
 def cartpole_oracle(A):
     path = os.path.join(ROOT, "oracle", "_build", "liboracle_cartpole.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as graft
+        graft.build_oracle()
+    lib = ctypes.CDLL(path)
+    return lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d, _lib=lib, _prefix="oracle_")
+
+
+@pytest.fixture(scope="module")
+def track_oracle(A):
+    path = os.path.join(ROOT, "oracle", "_build", "liboracle_cartpole_track.so")
     if not os.path.exists(path):
         import __graft_entry__ as graft
         graft.build_oracle()
@@ -84,3 +95,94 @@ def test_cartpole_solves_and_matches_the_oracle(A, P, hip_make, cartpole_oracle,
     for k in (0, 30, 59):
         eo, eg = o2.get_expansion(k), g2.get_expansion(k)
         assert np.allclose(eg["A"], eo["A"], rtol=1e-12, atol=1e-14) and np.allclose(eg["B"], eo["B"], rtol=1e-12, atol=1e-14)
+
+
+# ---- user-defined cost function and constraint (the other two plug-in classes of the reference) ------------------
+def test_source_with_cost_and_constraint_compiles(A):
+    """No GPU needed: the plugin of a source that also defines UserCost / UserConstraint cross-compiles and loads."""
+    os.environ.setdefault("ALTRO_HIP_ARCH", "gfx950")
+    assert A.register_model_source("cartpole_track", TRACK) >= A.MODEL_USER_BASE
+
+
+def test_user_functors_on_the_oracle(A, P, track_oracle):
+    """CPU: the oracle compiled with the same source solves the sway-limited move; the constraint is active."""
+    goals = np.linspace(0.4, 1.4, 6)
+    o = P.cartpole_track(track_oracle, A.MODEL_USER_BASE, batch=6, goal=goals)
+    o.solve()
+    st = o.get_stats()
+    assert (st["status"] == 0).all(), st["status"]
+    X, _ = o.get_trajectory()
+    sway = np.abs(0.5 * np.sin(X[:, :, 1])).max(axis=1)
+    assert sway[0] < 0.03 and (np.abs(sway[3:] - 0.04) < 2e-4).all(), sway  # inactive for the short move, active for the long ones
+
+
+@pytest.mark.gpu
+def test_user_cost_and_constraint_need_a_model_that_defines_them(A, P, hip_make):
+    kind = A.register_model_source("cartpole", CARTPOLE)  # dynamics only
+    s = hip_make(4, 1, 20, 2, A.F64)
+    s.set_model(kind); s.set_uniform_step(np.float32(0.05))
+    s.set_user_cost(0, 21, np.zeros(6))
+    s.set_initial_state(np.zeros(4)); s.set_trajectory(None, np.zeros((20, 1)))
+    with pytest.raises(A.AltroError, match="defines no UserCost"):
+        s.rollout()
+    s = hip_make(3, 2, 20, 2, A.F64)  # a built-in model
+    s.set_model(A.MODEL_UNICYCLE); s.set_uniform_step(np.float32(0.05))
+    s.set_lqr_cost(0, 21, np.eye(3), np.eye(2), np.zeros(3), np.zeros(2))
+    s.add_user_constraint(0, 20, np.zeros(2))
+    s.set_initial_state(np.zeros(3)); s.set_trajectory(None, np.zeros((20, 2)))
+    with pytest.raises(A.AltroError, match="defines no UserConstraint"):
+        s.rollout()
+
+
+@pytest.mark.gpu
+def test_wrong_cost_gradient_hessian_and_constraint_jacobian_are_rejected(A):
+    """ScalarFunction::CheckGradient, FunctionBase::CheckHessian / CheckJacobian (functionbase.cpp:42-125) on the device."""
+    cases = [("dx[1] = par[2] * sin(x[1]);", "dx[1] = -par[2] * sin(x[1]);", "UserCost::gradient"),
+             ("dxdx[1 + 1 * 4] = par[2] * cos(x[1]);", "dxdx[1 + 1 * 4] = par[2] * sin(x[1]);", "UserCost::hessian"),
+             ("J[1 + 1 * 2] = -dt;", "J[1 + 1 * 2] = dt;", "UserConstraint::jacobian")]
+    for i, (good, bad, what) in enumerate(cases):
+        src = TRACK.replace(good, bad)
+        assert src != TRACK
+        with pytest.raises(A.AltroError, match=what + r"\(\) does not match finite differences"):
+            A.register_model_source(f"cartpole_track_bad{i}", src)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name", ["F64", "F32"])
+def test_user_cost_and_constraint_match_the_oracle(A, P, hip_make, track_oracle, dtype_name):
+    kind = A.register_model_source("cartpole_track", TRACK)  # runs the derivative checks on the device
+    B = 40
+    goals = np.linspace(0.4, 1.4, B)
+    dt = getattr(A, dtype_name)
+    g = P.cartpole_track(hip_make, kind, batch=B, goal=goals, dtype=dt)
+    o = P.cartpole_track(track_oracle, kind, batch=B, goal=goals, dtype=A.F64 if dtype_name == "F64" else 2)
+    # step level first: cost, expansion with the user's gradient / Hessian and the user's constraint terms
+    g2 = P.cartpole_track(hip_make, kind, batch=4, goal=goals[-4:], dtype=A.F64)
+    o2 = P.cartpole_track(track_oracle, kind, batch=4, goal=goals[-4:], dtype=A.F64)
+    for s in (g2, o2):
+        s.set_trajectory(None, np.full((60, 1), 2.5)); s.rollout(); s.set_penalty(7.0); s.update_expansions()
+    assert np.allclose(g2.cost(), o2.cost(), rtol=1e-12)
+    Xr, _ = o2.get_trajectory()
+    assert np.abs(0.5 * np.sin(Xr[:, :, 1])).max() > 0.05  # the rollout violates the sway limit: the AL terms are live
+    for k in (1, 30, 59, 60):
+        eo, eg = o2.get_expansion(k), g2.get_expansion(k)
+        for f in (("lx", "lu", "lxx", "lxu", "luu") if k < 60 else ("lx", "lxx")):  # (the terminal knot has no control)
+            assert np.allclose(eg[f], eo[f], rtol=1e-11, atol=1e-12), (k, f, np.abs(eg[f] - eo[f]).max())
+    assert np.allclose(g2.get_constraint_values(), o2.get_constraint_values(), rtol=1e-12, atol=1e-14)
+    # the solves
+    g.solve(); o.solve()
+    so, sg = o.get_stats(), g.get_stats()
+    print("cart-pole track", dtype_name, "iterations", np.unique(so["iterations_total"], return_counts=True), "solved", (so["status"] == 0).mean())
+    for f in ("status", "iterations_total", "iterations_outer"):
+        assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
+    assert (so["status"] == 0).mean() > 0.9
+    ok = so["status"] == 0
+    (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
+    tol = 1e-7 if dtype_name == "F64" else 1e-5
+    assert np.allclose(Xg[ok], Xo[ok], rtol=tol, atol=tol), np.abs(Xg[ok] - Xo[ok]).max()
+    assert np.allclose(Ug[ok], Uo[ok], rtol=10 * tol, atol=10 * tol), np.abs(Ug[ok] - Uo[ok]).max()
+    assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-7)
+    assert np.allclose(g.get_duals()[ok], o.get_duals()[ok], rtol=1e3 * tol, atol=1e3 * tol)
+    # the sway limit holds (to the constraint tolerance) and is active for the long moves
+    sway = np.abs(0.5 * np.sin(Xg[:, :, 1])).max(axis=1)
+    assert (sway[ok] < 0.04 + 1e-3).all() and (sway[ok][-5:] > 0.04 - 1e-3).all(), sway
