@@ -2024,10 +2024,26 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 // one, or the last whose rollout succeeded: quirk Q6) out of the candidate scratch, evaluate and store
 // the constraint values it leaves in c_, and -- if accepted -- install it as the new trajectory.
 // Returns the max violation over those knots.  t_replay < 0: c_ is untouched since the expansion step.
+// One knot's term of the gradient measure (ilqr.hpp:574-583): max_i |d_i| / (|u_i| + 1).  The maximiser is picked by
+// cross-multiplication, then ONE division.
+template <class T, int m>
+ALTRO_DEV T grad_term(const T* d, const T* u) {
+  T gnum = T(0), gden = T(1);
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    const T num = abs_(d[i]), den = abs_(u[i]) + T(1);
+    if (num * gden > gnum * den) {
+      gnum = num;
+      gden = den;
+    }
+  }
+  return gnum / gden;
+}
+
 template <class T, class M, class Ctx>
 ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const Ctx& C, int b, int t_replay, bool accepted,
                            int k0, int stride, const T* cand_base, unsigned cand_off0, T* sXw = nullptr,
-                           T* sUw = nullptr) {
+                           T* sUw = nullptr, T* rk = nullptr, const T* sKD = nullptr, int kd_stride = 0, int kd_off = 0) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -2062,6 +2078,7 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
         knot_cost<T, n, m, true>(C, pd, kc, rb, xs[j], us[j], &v);
         viol = max_(viol, v);
         if (accepted) {
+          if (rk && k < N) rk[k] = grad_term<T, m>(sKD + k * kd_stride + kd_off, us[j]);
           T xr[R::nP], ur[R::mP];
 #pragma unroll
           for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[j][i < n ? i : 0] : T(0);
@@ -2147,7 +2164,7 @@ ALTRO_DEV double from_upper_half(double x) {
 // v_permlane32_swap), bit-identical to the one-knot-at-a-time loop.
 template <class T, class M, bool PAIRED>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
-                            bool valid, T* cand_inst, int* flags, double* gsx) {
+                            bool valid, T* cand_inst, int* flags, double* gsx, bool grad) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   const bool check = o.check_forwardpass_bounds != 0;
@@ -2170,8 +2187,10 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
 #pragma unroll
     for (int i = 0; i < m; ++i) ub[i] = slot[(n + i) * kBlock + col];  // stale at the terminal knot: masked below
     const int kg = inner ? k : N - 1;
+    if (grad) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < m; ++i) d[i] = sKD[kg * kd_stride + kd_off + i];
+      for (int i = 0; i < m; ++i) d[i] = sKD[kg * kd_stride + kd_off + i];
+    }
     if (check) {  // wave-uniform
       T sx = T(0), su = T(0);
 #pragma unroll
@@ -2188,19 +2207,11 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
         bm.step(ox, ou);
       }
     }
-    // grad term max_i |d_i| / (|u_i| + 1): pick the maximiser by cross-multiplication, divide once
-    T gnum = T(0), gden = T(1);
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      const T num = abs_(d[i]), den = abs_(ub[i]) + T(1);
-      if (num * gden > gnum * den) {
-        gnum = num;
-        gden = den;
-      }
+    if (grad) {
+      const double r = inner ? (double)grad_term<T, m>(d, ub) : 0.0;  // gs >= +0: adding +0 leaves every bit alone
+      gs += r;
+      if (PAIRED) gs += from_upper_half(r);
     }
-    const double r = inner ? (double)(gnum / gden) : 0.0;  // gs >= +0: adding +0 leaves every bit alone
-    gs += r;
-    if (PAIRED) gs += from_upper_half(r);
     if (mine && k <= N) {  // idle lanes must not touch the candidates
       T* cand = candp + (unsigned)k * (unsigned)(LS * nm);
 #pragma unroll
@@ -2496,6 +2507,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     __syncthreads();
   }
 
+  // The gradient measure of the accepted trial (ilqr.hpp:574-583 with the trial's controls).  FUSED: summed knot by
+  // knot by the auxiliary wave for every trial -- its two half-waves have the slack.  Batched sweeps, where that wave
+  // is the critical one: only for the winner, in phase 2 -- each knot's term into the hand-off slots (free by then),
+  // summed in knot order afterwards: the same additions in the same order.
+  const bool grad_in_loop = FUSED || 16 + per_wave * N > kFwdSlots * nm * kBlock;
+  T* const rk = grad_in_loop ? nullptr : xch + 16 + (grp < per_wave ? grp : 0) * N;
+
   T x0[R::nP];
   load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
   const T hh = T(pd->hstep);
@@ -2582,7 +2600,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS,
                                     FUSED ? sCand : A.trial,
                                     FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm,
-                                    FUSED ? sX : nullptr, FUSED ? sU : nullptr);
+                                    FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart[grp] = vm;
@@ -2598,7 +2616,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
-    aux_wave_run<T, M, FUSED>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx);
+    aux_wave_run<T, M, FUSED>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx,
+                              grad_in_loop);
     lds_barrier();    // barrier A
     __syncthreads();  // barrier S
     {
@@ -2608,7 +2627,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
         const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
                                             kFwdWaves * LS, cand_base, cand_off0, FUSED ? sX : nullptr,
-                                            FUSED ? sU : nullptr);
+                                            FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart2[grp] = vm;
@@ -2704,7 +2723,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T viol = T(0);
   if (valid) {
     viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, cand_base, cand_off0,
-                                FUSED ? sX : nullptr, FUSED ? sU : nullptr);
+                                FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
@@ -2712,6 +2731,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   __syncthreads();  // barrier V: the other wave's share of the violation
   if (!valid) return;
   viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
+  if (!grad_in_loop && accepted) {
+    double gsum = 0.0;
+    for (int k = 0; k < N; ++k) gsum += (double)rk[k];
+    g_sel = gsum;
+  }
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
                        FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
