@@ -423,6 +423,8 @@ class Engine final : public EngineBase {
   static constexpr bool kMfma16Backward = n > 4 && n <= 12 && m <= 4;
   // gain records big enough (m n + m >= 14 elements) that reading K from global memory can pay: see kdg_
   static constexpr bool kKdgEligible = n * m >= 12;
+  // rollout inputs from global memory, two knots ahead in three register sets: small records only
+  static constexpr bool kRgEligible = !kKdgEligible && R::KP + R::nP + R::mP <= 16;
   static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
     if constexpr (kMfmaBackward) {
@@ -470,10 +472,14 @@ class Engine final : public EngineBase {
       const dim3 grid2((ninst + per_wave - 1) / per_wave);
       if (kdg_) {
         if constexpr (kKdgEligible)
-          hipLaunchKernelGGL((k_forward2<T, M, true>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+          hipLaunchKernelGGL((k_forward2<T, M, kSrcKdg>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+                             all, per_wave);
+      } else if (rg_) {
+        if constexpr (kRgEligible)
+          hipLaunchKernelGGL((k_forward2<T, M, kSrcGlb>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
                              all, per_wave);
       } else {
-        hipLaunchKernelGGL((k_forward2<T, M, false>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+        hipLaunchKernelGGL((k_forward2<T, M, kSrcLds>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
                            all, per_wave);
       }
       return;
@@ -984,6 +990,42 @@ class Engine final : public EngineBase {
       fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
       kdg_ = false;
+      rg_ = false;
+      if constexpr (kRgEligible) {
+        // Small models: the rollout wave reads (xbar, ubar, K, d) from global memory two knots ahead; LDS keeps only the
+        // multipliers and the parameters, so that four workgroups (the register limit) instead of two share a CU.
+        // Needs the winner-only gradient measure of phase 2, whose terms live in the hand-off slots.
+        const size_t per_inst_g = (2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T);
+        // Taken when it lets more instances be resident on a CU than the fully staged variant: workgroups per CU =
+        // min(LDS limit, register limit: waves per SIMD of the kernel * 4 SIMDs / 3 waves).  Config 3 (fp32 records: 152
+        // VGPRs, three waves per SIMD): 6 -> 9 instances, -7 % per forward sweep; config 2 (fp64 records in flight: 171
+        // VGPRs, two waves per SIMD): 6 -> 6, and the staged variant is 2 % faster.  ALTRO_HIP_FWD_SRC=lds / global
+        // override the choice.
+        auto resident = [&](const void* fn, size_t lds_wg) {
+          hipFuncAttributes at{};
+          if (hipFuncGetAttributes(&at, fn) != hipSuccess || at.numRegs <= 0) return 0;
+          const int waves = std::min(8, 512 / ((at.numRegs + 7) / 8 * 8));  // per SIMD
+          const int by_regs = waves * 4 / kFwdWaves, by_lds = (int)(160 * 1024 / lds_wg);
+          return lanes_max * std::min(by_regs, by_lds);
+        };
+        const char* src = std::getenv("ALTRO_HIP_FWD_SRC");
+        bool want = false;
+        if (src) {
+          want = std::string(src) == "global";
+        } else if (fwd_per_wave_ == lanes_max) {
+          want = resident(reinterpret_cast<const void*>(&k_forward2<T, M, kSrcGlb>), shared_bytes + lanes_max * per_inst_g) >
+                 resident(reinterpret_cast<const void*>(&k_forward2<T, M, kSrcLds>), shared_bytes + lanes_max * per_inst);
+        } else {
+          want = true;  // the staged block does not even allow three instances per workgroup
+        }
+        if (want && 16 + lanes_max * N_ <= kFwdSlots * nm * kBlock && shared_bytes + lanes_max * per_inst_g <= 80 * 1024) {
+          rg_ = true;
+          fwd_per_wave_ = lanes_max;
+          if (const char* e = std::getenv("ALTRO_HIP_FWD_PER_WAVE")) fwd_per_wave_ = std::max(1, std::min(fwd_per_wave_, atoi(e)));
+          fwd_per_inst_bytes_ = per_inst_g;
+          fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst_g;
+        }
+      }
       if constexpr (kKdgEligible) {
         // Models whose gain records fill the LDS (12-state model: 83 of 134 KB per instance -> one instance per CU):
         // keep only d in LDS, let the rollout wave read K from global memory one knot ahead, and put up to three
@@ -1004,10 +1046,14 @@ class Engine final : public EngineBase {
       } else if (fwd_lds_bytes_ > 64 * 1024) {
         if (kdg_) {
           if constexpr (kKdgEligible)
-            ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, true>),
+            ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, kSrcKdg>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
+        } else if (rg_) {
+          if constexpr (kRgEligible)
+            ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, kSrcGlb>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
         } else {
-          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, false>),
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward2<T, M, kSrcLds>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds_bytes_));
         }
       }
@@ -1216,7 +1262,8 @@ class Engine final : public EngineBase {
   }
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
-  bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., true>)
+  bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., kSrcKdg>)
+  bool rg_ = false;   // ... all of the rollout wave's per-knot inputs (k_forward2<.., kSrcGlb>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;

@@ -2078,7 +2078,18 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
         knot_cost<T, n, m, true>(C, pd, kc, rb, xs[j], us[j], &v);
         viol = max_(viol, v);
         if (accepted) {
-          if (rk && k < N) rk[k] = grad_term<T, m>(sKD + k * kd_stride + kd_off, us[j]);
+          if (rk && k < N) {
+            if (sKD) {
+              rk[k] = grad_term<T, m>(sKD + k * kd_stride + kd_off, us[j]);
+            } else {  // the feedforward term of the gain record in global memory
+              using RS = rec_scalar_t<T, M>;
+              const RS* kdr = RECP((const RS*)A.KD, k, (Rec<RS, n, m>::KP)) + R::oD;
+              T dv[m];
+#pragma unroll
+              for (int i = 0; i < m; ++i) dv[i] = (T)kdr[i];
+              rk[k] = grad_term<T, m>(dv, us[j]);
+            }
+          }
           T xr[R::nP], ur[R::mP];
 #pragma unroll
           for (int i = 0; i < R::nP; ++i) xr[i] = i < n ? xs[j][i < n ? i : 0] : T(0);
@@ -2379,7 +2390,8 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
 enum KdMode { kKdNone = 0, kKdFull = 1, kKdFeedforward = 2 };
 template <class T, class M>
 ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, const FwdLds<T>& L, unsigned char* smem_raw,
-                              T* sPool, int per_wave, int all, int tt, int nthreads, int kd_mode) {
+                              T* sPool, int per_wave, int all, int tt, int nthreads, int kd_mode,
+                              bool with_traj = true) {
   const bool with_kd = kd_mode != kKdNone;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -2397,7 +2409,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
     constexpr int D = 2;  // items per thread, array and instance in flight (N = 100: two rounds)
     const int perX = R::nP / VN, perU = R::mP / VN, perK = (kd_mode == kKdFeedforward ? R::mP : R::KP) / VN;
     const int kd_first = kd_mode == kKdFeedforward ? R::oD : 0;  // first record element that is staged
-    const int cX = (N + 1) * perX, cU = N * perU, cK = N * perK, cR = L.nR, cS = L.nS;
+    const int cX = with_traj ? (N + 1) * perX : 0, cU = with_traj ? N * perU : 0, cK = N * perK, cR = L.nR, cS = L.nS;
     int cmax = (with_kd && cK > cX) ? cK : cX;
     cmax = cmax > cR ? cmax : cR;
     cmax = cmax > cS ? cmax : cS;
@@ -2419,8 +2431,10 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           const int i = i0 + j * kStride;
-          vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
-          vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
+          if (with_traj) {
+            vx[g][j] = ldrec(A.X, perX, cX, R::nP, i);
+            vu[g][j] = ldrec(A.U, perU, cU, R::mP, i);
+          }
           if (with_kd) {
             // gain record: stored as RS, staged as T (element offsets coincide, see load_rec_as)
             using RS = rec_scalar_t<T, M>;
@@ -2468,7 +2482,31 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
 // bytes in global memory, for the per-lane (divergent) indexing of phases 2 and 3; indexing the
 // by-value copy that way would force it into scratch.  FUSED: called by k_sweep_fused with the LDS
 // block already filled; fh = {J0, dV0, dV1, initial_cost} handed over in LDS.
-template <class T, class M, bool FUSED, bool KDG = false>
+// SRC: where the rollout wave's per-knot inputs (xbar, ubar, K, d) come from in the batched sweeps --
+//   kSrcLds  staged in LDS with everything else (17.7 KB per unicycle instance: two workgroups per CU);
+//   kSrcKdg  large models: K from global memory one knot ahead, the rest staged;
+//   kSrcGlb  small models: all four from global memory TWO knots ahead in three rotating register sets (L2-resident:
+//            the backward kernel has just written the gains); LDS keeps only the multipliers and parameters, so four
+//            workgroups fit a CU and the staging phase shrinks with it.
+enum FwdSrc { kSrcLds = 0, kSrcKdg = 1, kSrcGlb = 2 };
+// E elements of a 16-byte aligned record: 16-byte loads for the pairs, one 8-byte load for an odd last element
+template <class T, int E>
+ALTRO_DEV void load_elems(const T* p, T* out) {
+  static_assert(sizeof(T) == 8, "fp64 records");
+  using V = typename VecOf<T>::type;
+#pragma unroll
+  for (int i = 0; i + 1 < E; i += 2) {
+    const V v = *reinterpret_cast<const V*>(p + i);
+    out[i] = v.x;
+    out[i + 1] = v.y;
+  }
+  if (E & 1) out[E - 1] = p[E - 1];
+}
+#ifndef ALTRO_RG_AHEAD
+#define ALTRO_RG_AHEAD 2
+#endif
+constexpr int kRgAhead = ALTRO_RG_AHEAD;  // knots of prefetch distance of the kSrcGlb rollout wave (register sets - 1)
+template <class T, class M, bool FUSED, int SRC = kSrcLds>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr) {
@@ -2487,14 +2525,15 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 
   // ---- phase 0: stage the instance's read-only inputs in LDS (both waves copy) ------------------
   // KDG: the feedback gains stay in global memory (read by the rollout wave one knot ahead), LDS keeps d only
-  static_assert(!(FUSED && KDG), "the fused kernel keeps the gain records in LDS");
+  constexpr bool KDG = SRC == kSrcKdg, RG = SRC == kSrcGlb;
+  static_assert(!(FUSED && SRC != kSrcLds), "the fused kernel keeps the gain records in LDS");
   constexpr int kKdStride = KDG ? R::mP : R::KP, kKdOff = KDG ? 0 : R::oD;
-  const FwdLds<T> L{(N + 1) * R::nP, N * R::mP, N * kKdStride, pd->total_rows, pd->nslots, R::V};
+  const FwdLds<T> L{RG ? 0 : (N + 1) * R::nP, RG ? 0 : N * R::mP, RG ? 0 : N * kKdStride, pd->total_rows, pd->nslots, R::V};
   T* sm = reinterpret_cast<T*>(smem_raw) + (grp < per_wave ? grp : 0) * L.total();
-  T* sX = sm;
-  T* sU = sX + L.nX;
-  T* sKD = sU + L.nU;
-  T* sLam = sKD + L.nKD;
+  T* sX = RG ? nullptr : sm;  // (RG: nothing of the trajectory or the gains is staged; phases 2 and 3 read d and
+  T* sU = RG ? nullptr : sm + L.nX;  //  ubar from global memory)
+  T* sKD = RG ? nullptr : sm + L.nX + L.nU;
+  T* sLam = sm + L.nX + L.nU + L.nKD;
   T* sPen = sLam + L.rowsP();
   T* sIp = sPen + L.rowsP();
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
@@ -2503,7 +2542,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
     forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock,
-                         KDG ? kKdFeedforward : kKdFull);
+                         RG ? kKdNone : (KDG ? kKdFeedforward : kKdFull), !RG);
     __syncthreads();
   }
 
@@ -2511,7 +2550,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   // knot by the auxiliary wave for every trial -- its two half-waves have the slack.  Batched sweeps, where that wave
   // is the critical one: only for the winner, in phase 2 -- each knot's term into the hand-off slots (free by then),
   // summed in knot order afterwards: the same additions in the same order.
-  const bool grad_in_loop = FUSED || 16 + per_wave * N > kFwdSlots * nm * kBlock;
+  const bool grad_in_loop = FUSED || (!RG && 16 + per_wave * N > kFwdSlots * nm * kBlock);  // (RG: the engine checked)
   T* const rk = grad_in_loop ? nullptr : xch + 16 + (grp < per_wave ? grp : 0) * N;
 
   T x0[R::nP];
@@ -2532,30 +2571,46 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     // One knot of the rollout.  The nominal knot (xbar, ubar, K, d) comes from LDS one knot AHEAD: the
     // reads for knot k + 1 are issued before the arithmetic of knot k, so their latency hides behind
     // it; two register sets alternate (the loop is unrolled by two, no copies).
+    // (kSrcGlb keeps the gain record in its storage type -- fp32 under WithRec32 -- while it is in flight and converts
+    //  at use: a third fewer registers per set)
+    using RSn = rec_scalar_t<T, M>;
+    using KdT = std::conditional_t<RG, RSn, T>;
     struct Nominal {
-      T xk[R::nP], uk[R::mP], kd[R::KP];
+      T xk[R::nP], uk[R::mP];
+      KdT kd[RG ? (int)Rec<RSn, n, m>::KP : (int)R::KP];
     };
     auto fetch = [&](int k, Nominal& q) __attribute__((always_inline)) {
       const int kc = k < N ? k : N - 1;
-      load_rec<T, R::nP>(sX + kc * R::nP, q.xk);
-      load_rec<T, R::mP>(sU + kc * R::mP, q.uk);
-      if constexpr (KDG) {
+      if constexpr (RG) {
         using RS = rec_scalar_t<T, M>;
         using RR = Rec<RS, n, m>;
-        load_rec_as<T, RS, R::KP, RR::KP, m * n + m>((const RS*)A.KD + ((size_t)(unsigned)kc * (unsigned)A.Bp + (unsigned)b) * RR::KP, q.kd);
+        const unsigned Bp = A.Bp;
+        // (exactly n / m elements: a padded element would hold a register pair for the two knots the load is in flight,
+        //  in each of the three sets -- the difference between two and three waves per SIMD for the unicycle)
+        load_elems<T, n>(RECP(A.X, kc, R::nP), q.xk);
+        load_elems<T, m>(RECP(A.U, kc, R::mP), q.uk);
+        load_rec<RS, RR::KP>(RECP((const RS*)A.KD, kc, RR::KP), q.kd);
       } else {
-        load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
+        load_rec<T, R::nP>(sX + kc * R::nP, q.xk);
+        load_rec<T, R::mP>(sU + kc * R::mP, q.uk);
+        if constexpr (KDG) {
+          using RS = rec_scalar_t<T, M>;
+          using RR = Rec<RS, n, m>;
+          load_rec_as<T, RS, R::KP, RR::KP, m * n + m>((const RS*)A.KD + ((size_t)(unsigned)kc * (unsigned)A.Bp + (unsigned)b) * RR::KP, q.kd);
+        } else {
+          load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
+        }
       }
     };
     auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
       T ub[m], xn[n];
-      fetch(k + 1, nxt);
+      fetch(k + (RG ? kRgAhead : 1), nxt);
 #pragma unroll
       for (int i = 0; i < m; ++i) {
         T sacc = T(0);
 #pragma unroll
-        for (int l = 0; l < n; ++l) sacc += cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
-        ub[i] = cur.uk[i] + sacc + cur.kd[R::oD + i] * alpha;
+        for (int l = 0; l < n; ++l) sacc += (T)cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
+        ub[i] = cur.uk[i] + sacc + (T)cur.kd[R::oD + i] * alpha;
       }
       T* slot = xch + fwd_slot(k) * (nm * kBlock);
 #pragma unroll
@@ -2573,7 +2628,20 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
       if (producer_syncs_after(k, N)) lds_barrier();
     };
-    {
+    if constexpr (RG && kRgAhead == 2) {
+      // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
+      Nominal q0, q1, q2;
+      fetch(0, q0);
+      fetch(1, q1);
+      int k = 0;
+      for (; k + 2 < N; k += 3) {
+        knot(k, q0, q2);
+        knot(k + 1, q1, q0);
+        knot(k + 2, q2, q1);
+      }
+      if (k < N) knot(k, q0, q2);
+      if (k + 1 < N) knot(k + 1, q1, q0);
+    } else {
       Nominal qa, qb;
       fetch(0, qa);
       int k = 0;
@@ -2741,12 +2809,12 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                        FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
 }
 
-template <class T, class M, bool KDG>
+template <class T, class M, int SRC>
 __global__ __launch_bounds__(kFwdWaves * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                          const ProblemDesc pd_arg, DevOpts o, int mode, int all,
                                                          int per_wave) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  forward2_body<T, M, false, KDG>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
+  forward2_body<T, M, false, SRC>(A, pdg, &pd_arg, o, mode, all, per_wave, smem_raw, nullptr);
 }
 
 // iLQR::UpdateExpansions of one instance by `nthreads` threads, reading the trajectory, multipliers and
