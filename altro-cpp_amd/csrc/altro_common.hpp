@@ -16,6 +16,7 @@ constexpr int kMaxCostGroups = 8;
 constexpr int kLineSearchLanes = 20;  // speculative line-search trials evaluated side by side
 constexpr int kHistFields = 8;
 constexpr int kMaxRuns = 16;  // maximal runs of consecutive knots sharing one class
+constexpr int kMaxFastCircles = 3;  // circles of one constraint that the specialised cost-wave layouts keep in registers
 constexpr int kMaxSharedPool = 128;  // shared parameters that travel to the forward kernel as kernel arguments
 
 // ---- dtype-independent problem specification (what the altro::problem::Problem setters record) ---

@@ -720,6 +720,14 @@ template <class T>
 ALTRO_DEV T dual_proj_jac(int type, T v) {
   return type == 0 ? T(1) : (v > T(0) ? T(0) : T(1));
 }
+// CircleConstraint::Evaluate (examples/obstacle_constraints.hpp:99-107): c = r^2 - |p - centre|^2, in ONE operation
+// order.  With plain products the contraction the compiler picks for dx*dx + dy*dy - r*r depends on what it can
+// hoist out of the surrounding loop, and every evaluation of the constraint (trial cost, stored c_, expansion; the
+// persistent kernel and the batched sweeps) must give the same bits.
+template <class T>
+ALTRO_DEV T circle_value(T dx, T dy, T rr) {
+  return -fma(dx, dx, fma(dy, dy, -(rr * rr)));
+}
 // c - Pi_K(c): |c| for equalities, max(c, 0) for inequalities (constraint_values.hpp:215-220)
 template <class T>
 ALTRO_DEV T violation(int type, T c) {
@@ -862,7 +870,7 @@ ALTRO_DEV T knot_cost(const Ctx& C, const ProblemDesc* pd, const KnotClass& kc, 
         T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
         T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
         T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
-        T c = -(dx * dx + dy * dy - rr * rr);
+        T c = circle_value(dx, dy, rr);
         T lam = C.lam(r0 + i);
         T lp = dual_proj(1, lam - rho * c);
         a += lp * lp;
@@ -992,7 +1000,7 @@ ALTRO_DEV T knot_cost_fast(const Ctx& C, const ProblemDesc* pd, const KnotClass&
           T dx = x[0] - C.par(cd.per_instance, cd.param_off, 3 * i);
           T dy = x[1] - C.par(cd.per_instance, cd.param_off, 3 * i + 1);
           T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
-          T c = -(dx * dx + dy * dy - rr * rr);
+          T c = circle_value(dx, dy, rr);
           T lam = C.lam(r0 + i);
           T lp = dual_proj(1, lam - rho * c);
           a += lp * lp;
@@ -1193,7 +1201,7 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
         T cy = C.par(cd.per_instance, cd.param_off, 3 * i + 1);
         T rr = C.par(cd.per_instance, cd.param_off, 3 * i + 2);
         T dx = x[0] - cx, dy = x[1] - cy;
-        T c = -(dx * dx + dy * dy - rr * rr);
+        T c = circle_value(dx, dy, rr);
         T lam = C.lam(r0 + i);
         T v = lam - rho * c;
         T lp = dual_proj(1, v);

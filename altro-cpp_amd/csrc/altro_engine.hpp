@@ -865,7 +865,7 @@ class Engine final : public EngineBase {
         auto is_full_bound = [&](const ConDesc& c) {
           return c.kind == ALTRO_CON_CONTROL_BOUND && c.lo_mask == full && c.hi_mask == full;
         };
-        auto is_circle = [&](const ConDesc& c) { return c.kind == ALTRO_CON_CIRCLE; };
+        auto is_circle = [&](const ConDesc& c) { return c.kind == ALTRO_CON_CIRCLE && c.p <= kMaxFastCircles; };  // (cost_consumer_run keeps them in registers)
         run.fast = kFastGeneric;
         if (pd_.grp[kc.cost_group].q_diag && pd_.grp[kc.cost_group].r_diag) {
           if (kc.ncon == 0) run.fast = kFastNone;
@@ -1059,8 +1059,12 @@ class Engine final : public EngineBase {
       }
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
-          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M>),
+        {
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
+          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
+        }
       }
     }
     uploaded_ = true;
@@ -1150,8 +1154,16 @@ class Engine final : public EngineBase {
         if constexpr (kMfmaBackward) {
           A.next_list = nullptr;  // nobody comes after this launch
           A.next_count = nullptr;
-          hipLaunchKernelGGL((k_sweep_fused<T, M>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_, pd_, d,
-                             mode, 1, d_counter_ + max_sweeps + 2);
+          // (the variant without the circle layouts for problems that have no circle constraint: see forward2_body)
+          bool circles = false;
+          for (int r = 0; r < pd_.nruns; ++r)
+            circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
+          if (circles)
+            hipLaunchKernelGGL((k_sweep_fused<T, M, true>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_,
+                               pd_, d, mode, 1, d_counter_ + max_sweeps + 2);
+          else
+            hipLaunchKernelGGL((k_sweep_fused<T, M, false>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_,
+                               pd_, d, mode, 1, d_counter_ + max_sweeps + 2);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
         persistent_launched = true;

@@ -1745,7 +1745,7 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
             T dx = xb[0] - C.par(c_pi, c_off, 3 * i);
             T dy = xb[1] - C.par(c_pi, c_off, 3 * i + 1);
             T rr = C.par(c_pi, c_off, 3 * i + 2);
-            T c = -(dx * dx + dy * dy - rr * rr);
+            T c = circle_value(dx, dy, rr);
             T lam = C.lam(rb + c_row + i);
             T lp = dual_proj(1, lam - rho * c);
             a += lp * lp;
@@ -2239,7 +2239,10 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
   }
 }
 
-template <class T, class M, int FK>
+// HOIST (the persistent kernel of problems with circle constraints: one workgroup per CU, registers are free): the
+// circles' centres and radii in registers, their multipliers fetched one knot ahead.  The batched sweeps keep the
+// runtime loop: the 30 VGPRs would cost them a wave per SIMD.
+template <class T, class M, int FK, bool HOIST>
 ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
                                  int kend, const T* xch, int lane, double& J) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -2289,15 +2292,37 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   // multipliers of the bound rows: fetched one knot AHEAD, before the barrier (they do not depend on the hand-off),
   // so that behind the barrier only the slot itself has to make the LDS round trip
   T blam[2 * m], brho = T(1);
-  auto fetch_bound_rows = [&](int k, T* lam_out, T& rho_out) __attribute__((always_inline)) {
+  // the circles of the run (obstacle_constraints.hpp:69-127): centres and radii are the same at every knot -- hoisted
+  // into registers -- and their multipliers are fetched one knot ahead with the bound rows.  (A runtime loop over the
+  // circles with its LDS reads in the body cost three dependent LDS round trips per knot and trial: the cost wave was
+  // the critical wave of the knot loop on the obstacle problems.)
+  constexpr bool kHoistC = HOIST && kHasC;
+  constexpr int kFC = kHoistC ? kMaxFastCircles : 1;
+  T ccx[kFC], ccy[kFC], crr[kFC], clam[kFC], crho = T(1);
+#pragma unroll
+  for (int i = 0; i < kFC; ++i) {
+    ccx[i] = ccy[i] = crr[i] = clam[i] = T(0);
+    if (kHoistC && i < c_p) {
+      ccx[i] = C.par(c_pi, c_off, 3 * i);
+      ccy[i] = C.par(c_pi, c_off, 3 * i + 1);
+      crr[i] = C.par(c_pi, c_off, 3 * i + 2);
+    }
+  }
+  auto fetch_bound_rows = [&](int k, T* lam_out, T& rho_out, T* clam_out, T& crho_out) __attribute__((always_inline)) {
+    const int rb = rowbase + (k - k_begin) * nrows;
     if (kHasB) {
-      const int rb = rowbase + (k - k_begin) * nrows;
       rho_out = C.pen(rb + b_row);
 #pragma unroll
       for (int j = 0; j < 2 * m; ++j) lam_out[j] = C.lam(rb + b_row + j);
     }
+    if (kHoistC) {
+      crho_out = C.pen(rb + c_row);
+#pragma unroll
+      for (int i = 0; i < kFC; ++i)
+        if (i < c_p) clam_out[i] = C.lam(rb + c_row + i);
+    }
   };
-  fetch_bound_rows(k_begin, blam, brho);
+  fetch_bound_rows(k_begin, blam, brho, clam, crho);
   for (int k = k_begin; k < kend; ++k) {
     if (consumer_syncs_before(k)) lds_barrier();  // publishes (xbar, ubar) of knots k, k+1 of every trial
     const T* slot = xch + fwd_slot(k) * (nm * kBlock);
@@ -2309,8 +2334,10 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
     const int rb = rowbase + (k - k_begin) * nrows;
     // this knot's multipliers are in registers; the next knot's are requested now (the last request of a run is
     // clamped to its own knot and unused)
-    T blam_next[2 * m], brho_next = T(1);
-    fetch_bound_rows(k + 1 < kend ? k + 1 : k, blam_next, brho_next);
+    T blam_next[2 * m], brho_next = T(1), clam_next[kFC], crho_next = T(1);
+#pragma unroll
+    for (int i = 0; i < kFC; ++i) clam_next[i] = T(0);
+    fetch_bound_rows(k + 1 < kend ? k + 1 : k, blam_next, brho_next, clam_next, crho_next);
     if (FK == kFastGeneric) {
       J += (double)knot_cost_fast<T, n, m>(C, pd, kc, RC, rb, xb, ub);
     } else {
@@ -2327,17 +2354,32 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
       }
       T Jk = T(0.5) * xQx + T(0.5) * uRu + qx + ru + RC.c;
       auto circle_term = [&]() {
-        const T rho = C.pen(rb + c_row);
+        const T rho = kHoistC ? crho : C.pen(rb + c_row);
         T a = T(0), bsum = T(0);
-        for (int i = 0; i < c_p; ++i) {
-          T dx = xb[0] - C.par(c_pi, c_off, 3 * i);
-          T dy = xb[1] - C.par(c_pi, c_off, 3 * i + 1);
-          T rr = C.par(c_pi, c_off, 3 * i + 2);
-          T c = -(dx * dx + dy * dy - rr * rr);
-          T lam = C.lam(rb + c_row + i);
-          T lp = dual_proj(1, lam - rho * c);
-          a += lp * lp;
-          bsum += lam * lam;
+        if constexpr (kHoistC) {
+#pragma unroll
+          for (int i = 0; i < kFC; ++i)
+            if (i < c_p) {  // wave-uniform
+              T dx = xb[0] - ccx[i];
+              T dy = xb[1] - ccy[i];
+              T rr = crr[i];
+              T c = circle_value(dx, dy, rr);
+              T lam = clam[i];
+              T lp = dual_proj(1, lam - rho * c);
+              a += lp * lp;
+              bsum += lam * lam;
+            }
+        } else {
+          for (int i = 0; i < c_p; ++i) {
+            T dx = xb[0] - C.par(c_pi, c_off, 3 * i);
+            T dy = xb[1] - C.par(c_pi, c_off, 3 * i + 1);
+            T rr = C.par(c_pi, c_off, 3 * i + 2);
+            T c = circle_value(dx, dy, rr);
+            T lam = C.lam(rb + c_row + i);
+            T lp = dual_proj(1, lam - rho * c);
+            a += lp * lp;
+            bsum += lam * lam;
+          }
         }
         T Jc = a - bsum;
         Jk += div_2rho(Jc, rho);
@@ -2377,6 +2419,11 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
       brho = brho_next;
 #pragma unroll
       for (int j = 0; j < 2 * m; ++j) blam[j] = blam_next[j];
+    }
+    if (kHoistC) {
+      crho = crho_next;
+#pragma unroll
+      for (int i = 0; i < kFC; ++i) clam[i] = clam_next[i];
     }
   }
 }
@@ -2506,7 +2553,11 @@ ALTRO_DEV void load_elems(const T* p, T* out) {
 #define ALTRO_RG_AHEAD 2
 #endif
 constexpr int kRgAhead = ALTRO_RG_AHEAD;  // knots of prefetch distance of the kSrcGlb rollout wave (register sets - 1)
-template <class T, class M, bool FUSED, int SRC = kSrcLds>
+// HOISTC: the circle layouts of the cost wave keep centres, radii and multipliers in registers (cost_consumer_run).
+// Only the persistent kernel's variant for problems that HAVE circle constraints is built that way: the kernel sits at
+// the register limit, and code of constraint kinds a problem does not have still moves the allocation of its hot
+// loops (measured: +4 % per iteration on the obstacle-free config 2 when its circle arms grew).
+template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr) {
@@ -2719,7 +2770,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   for (int r = 0; r < pd->nruns; ++r) {
     const KnotRun run = pd->runs[r];
     const int kend = run.k_end < N ? run.k_end : N;
-#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK>(C, pd, A, run, kend, xch, lane, J)
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK, HOISTC>(C, pd, A, run, kend, xch, lane, J)
     switch (run.fast) {
       case kFastNone: ALTRO_RUN(kFastNone); break;
       case kFastB: ALTRO_RUN(kFastB); break;
@@ -2877,7 +2928,7 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // instance is finished (the AL state machine of phase 3 says so) -- no further launches, no host in
 // the loop; *sweeps_out receives the largest number of iterations any workgroup ran.
 // -------------------------------------------------------------------------------------------------
-template <class T, class M>
+template <class T, class M, bool CIRC>
 __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                             const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
                                                             int* sweeps_out) {
@@ -2945,7 +2996,7 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     }
     __syncthreads();
     // ---- F ----
-    forward2_body<T, M, true>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
+    forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
     ++loops;
     __syncthreads();
     if (!persistent || *active_flag == 0) break;
