@@ -183,7 +183,7 @@ class Engine final : public EngineBase {
   altro_status UpdateExpansions(const altro_options&) override {
     if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
+    hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 1, (int*)nullptr, (int*)nullptr);
     return Sync();
   }
   altro_status BackwardPass(const altro_options& o) override {
@@ -1121,10 +1121,10 @@ class Engine final : public EngineBase {
     // stays one sweep ahead of the device, and sizes each grid with the newest count it knows --
     // counts only shrink, so it is an upper bound -- so tail sweeps launch a handful of workgroups.
     {
-      altro_status rs = ReserveCounters(max_sweeps + 4);
+      altro_status rs = ReserveCounters(2 * (max_sweeps + 4));  // second half: cursors of the list rebuilds (dense sweeps)
       if (rs != ALTRO_OK) return rs;
     }
-    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(max_sweeps + 4) * sizeof(int), stream_));
+    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(2 * (max_sweeps + 4)) * sizeof(int), stream_));
     for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
     int known_count = B_;
     std::vector<char> fused_flag;
@@ -1173,7 +1173,17 @@ class Engine final : public EngineBase {
       }
       fused_flag.push_back(0);
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
-      hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0);
+      // (small models only: their expansions are HBM-bound; the 12-state model's are compute-bound and pay for the idle
+      //  lanes of a dense launch: config 4 +13 %)
+      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= B_) {
+        // a good part of the batch is still iterating: lane = instance (coalesced rows and records), and the list is
+        // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions)
+        hipLaunchKernelGGL((k_expansions<T, M>), dim3((B_ + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 2,
+                           d_list_[i % 2], d_counter_ + (max_sweeps + 4) + i);
+      } else {
+        hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0, (int*)nullptr,
+                           (int*)nullptr);
+      }
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
       LaunchBackward(A, d, 0, ninst);
       if (prof) hipEventRecord(ProfEvent(nev++), stream_);
@@ -1274,6 +1284,7 @@ class Engine final : public EngineBase {
   }
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
+  bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
   bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., kSrcKdg>)
   bool rg_ = false;   // ... all of the rollout wave's per-knot inputs (k_forward2<.., kSrcGlb>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;

@@ -41,9 +41,11 @@ constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost 
 // record base of knot k for this lane's instance: arr + (k*Bp + b)*EP
 #define RECP(arr, k, EP) ((arr) + ((size_t)(unsigned)(k) * (unsigned)Bp + (unsigned)b) * (unsigned)(EP))
 
-// Instance handled by slot `idx` of this launch (-1: none).  `all` launches cover every instance.
+// Instance handled by slot `idx` of this launch (-1: none).  `all` = 1: launches that cover every instance; 2: every
+// instance that is still iterating (phase == 1), addressed by its own index (k_expansions' dense mode).
 template <class T>
 ALTRO_DEV int instance_of_slot(const DevArrays<T>& A, int idx, int all) {
+  if (all == 2) return (idx < A.B && A.phase[idx] == 1) ? idx : -1;
   if (all) return idx < A.B ? idx : -1;
   const int cnt = A.act_count ? *A.act_count : A.act_count_const;
   if (idx >= cnt) return -1;
@@ -110,11 +112,26 @@ ALTRO_DEV void publish_count(const DevArrays<T>& A) {
     __hip_atomic_store(A.host_count, A.act_count ? *A.act_count : A.act_count_const, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// all = 2 (dense mode, while a good part of the batch is still iterating): lane = instance index instead of a slot of
+// the active list -- the list is appended to by atomics in arbitrary order, so a wavefront's instances are scattered
+// over the batch and every 8-byte row / 32-byte record access of a lane pulls its own cache line (this kernel is
+// HBM-bound).  The blocks of knot 0 also REBUILD the list for the backward and forward kernels of the sweep: runs of
+// up to 64 instances in index order (the runs themselves land in arbitrary order), so that the instances of a
+// workgroup are neighbours there too.
 template <class T, class M>
 __global__ __launch_bounds__(kBlock) void k_expansions(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
-                                                       int all) {
+                                                       int all, int* order_list = nullptr, int* order_count = nullptr) {
   const int b = instance_of_slot(A, blockIdx.x * kBlock + threadIdx.x, all);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) publish_count(A);
+  if (all == 2 && blockIdx.y == 0) {
+    const unsigned long long mask = __ballot(b >= 0);
+    if (mask != 0ull) {
+      int base = 0;
+      if (threadIdx.x == 0) base = atomicAdd(order_count, (int)__popcll(mask));
+      base = __shfl(base, 0);
+      if (b >= 0) order_list[base + (int)__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = b;
+    }
+  }
   if (b < 0) return;
   expansion_body<T, M>(A, pd, b, blockIdx.y);
 }
