@@ -1175,7 +1175,7 @@ class Engine final : public EngineBase {
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
       // (small models only: their expansions are HBM-bound; the 12-state model's are compute-bound and pay for the idle
       //  lanes of a dense launch: config 4 +13 %)
-      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= B_) {
+      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= B_) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
         // a good part of the batch is still iterating: lane = instance (coalesced rows and records), and the list is
         // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions)
         hipLaunchKernelGGL((k_expansions<T, M>), dim3((B_ + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 2,
