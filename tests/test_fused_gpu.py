@@ -87,3 +87,40 @@ def test_stall_fast_forward_is_bit_identical(tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+_SCRIPT_SW = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+for name, s in (("turn90", P.batch_turn90(make, batch=700)), ("obstacles", P.batch_three_obstacles(make, batch=700, dtype=A.F32))):
+    s.solve()
+    X, U = s.get_trajectory()
+    st = s.get_stats()
+    out[name + "_X"] = X; out[name + "_U"] = U; out[name + "_K"] = s.get_gains()[0]; out[name + "_lam"] = s.get_duals()
+    out[name + "_it"] = st["iterations_total"]; out[name + "_status"] = st["status"]; out[name + "_cost"] = st["cost"]
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.parametrize("switch", [{"ALTRO_HIP_NO_DENSE_EXPANSIONS": "1"}, {"ALTRO_HIP_FWD_SRC": "global"},
+                                    {"ALTRO_HIP_FWD_SRC": "lds"}, {"ALTRO_HIP_FWD_PER_WAVE": "1"}],
+                         ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
+def test_launch_variants_are_bit_identical(tmp_path, switch):
+    """The batched sweeps have several launch variants chosen by measurements (dense / list-addressed expansions with
+    the list rebuilt in neighbour order, rollout inputs staged in LDS or read from global memory, instances per
+    workgroup): none of them may change a bit of the result."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, env_extra):
+        out = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_SW % root, out], check=True, env=dict(os.environ, **env_extra), timeout=600)
+        return np.load(out)
+
+    a, b = run("default", {}), run("switch", switch)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
