@@ -988,7 +988,8 @@ class Engine final : public EngineBase {
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
       fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
-                         (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T);  // + the candidates of one instance
+                         (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T) +  // + the candidates of one instance
+                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);  // + the speculative pass (gains, hand-over)
       kdg_ = false;
       rg_ = false;
       if constexpr (kRgEligible) {
@@ -1060,10 +1061,12 @@ class Engine final : public EngineBase {
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
         {
-          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
-          ALTRO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<T, M, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
+          const void* variants[4] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, false>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, false>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, true>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, true>)};
+          for (const void* fn : variants)
+            ALTRO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
         }
       }
     }
@@ -1158,12 +1161,17 @@ class Engine final : public EngineBase {
           bool circles = false;
           for (int r = 0; r < pd_.nruns; ++r)
             circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
-          if (circles)
-            hipLaunchKernelGGL((k_sweep_fused<T, M, true>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_,
-                               pd_, d, mode, 1, d_counter_ + max_sweeps + 2);
+          // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
+          int* const out = d_counter_ + max_sweeps + 2;
+          const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
+          if (circles && speculate_)
+            hipLaunchKernelGGL((k_sweep_fused<T, M, true, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
+          else if (circles)
+            hipLaunchKernelGGL((k_sweep_fused<T, M, true, false>), g, b3, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
+          else if (speculate_)
+            hipLaunchKernelGGL((k_sweep_fused<T, M, false, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
           else
-            hipLaunchKernelGGL((k_sweep_fused<T, M, false>), dim3(ninst), dim3(kFwdWaves * kBlock), fused_lds_bytes_, stream_, A, d_pd_,
-                               pd_, d, mode, 1, d_counter_ + max_sweeps + 2);
+            hipLaunchKernelGGL((k_sweep_fused<T, M, false, false>), g, b3, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
         persistent_launched = true;
@@ -1285,6 +1293,7 @@ class Engine final : public EngineBase {
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
   bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
+  bool speculate_ = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
   bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., kSrcKdg>)
   bool rg_ = false;   // ... all of the rollout wave's per-knot inputs (k_forward2<.., kSrcGlb>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;

@@ -35,6 +35,8 @@ namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
 constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost wave, auxiliary wave
+// workgroup barrier that only waits for this wave's LDS traffic (not for its global loads / stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // constraint rows and per-instance scalars: arr[row*Bp + b]
 #define SOA(arr, row) (arr)[(unsigned)(row) * (unsigned)Bp + (unsigned)b]
@@ -594,9 +596,22 @@ constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bu
 // A.KD at the end; the running cost J0 is summed by the other wave; dV0 / dV1 are handed over in fh[1..2].
 // T is the STORAGE type of the engine (records, gains, costs); the recursion itself always runs in fp64 on
 // the fp64 matrix cores -- an fp32 engine reads float tiles, converts exactly, and rounds the gains once.
-template <class T, class M, bool CTG, bool FUSED>
+// SPEC (the fourth wave of k_sweep_fused): the backward pass of the NEXT iteration, run beside the forward pass of
+// this one on the assumption that the line search rejects every trial -- then the trajectory and the multipliers do
+// not change, the expansions of the next iteration are the ones in memory, and the only input that differs is the
+// regularisation (spec_rho, spec_drho = what phase 3 will set).  Nothing is written to global memory: the gains go to
+// a second LDS block (sKDf), the hand-over values to fh[1], [2], [4], [5], the regularisation that was used to fh[6]
+// and fh[7] = 1 if the pass went through without a Cholesky failure (a failure simply invalidates the speculation).
+// The wave takes part in the workgroup barriers of the forward pass: one after every knot with even index (the
+// forward waves sync once per pair of knots), counted in *nbar for the caller to top up.  Plain s_barrier: nothing
+// this wave writes is read before the kernel's own __syncthreads.  (Schedules that decouple the two paces -- 70 % or
+// 88 % of the recursion's knots spread over the loop's barriers, the rest behind barriers A / S / V -- measured
+// 4 - 9 % slower than this lock step: profiles/r02_experiments_not_kept.txt.)
+template <class T, class M, bool CTG, bool FUSED, bool SPEC = false>
 ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int all, int lane, int slot_base,
-                                  double* sKD, T* sKDf, int fused_junk, double* fh) {
+                                  double* sKD, T* sKDf, int fused_junk, double* fh, double spec_rho = 0.0,
+                                  double spec_drho = 0.0, int* nbar = nullptr) {
+  static_assert(!SPEC || FUSED, "the speculative pass is a variant of the fused one");
   static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
   constexpr int n = 3, m = 2;
   using R = Rec<T, n, m>;
@@ -641,7 +656,8 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   struct Tiles {
     double tA, tB, t1, t2, t3;
   };
-  double rho = A.rho_reg[b], drho = A.drho[b];
+  double rho = SPEC ? spec_rho : A.rho_reg[b], drho = SPEC ? spec_drho : A.drho[b];
+  bool spec_bad = false;
   double dV0 = 0.0, dV1 = 0.0;  // zeroed once, NOT per retry (quirk Q4)
   int max_reg_count = 0;
   int status = A.status[b];
@@ -769,6 +785,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       running = commit;
       bool gave_up = false;
       if (__ballot(failed) != 0ull) {
+        spec_bad = true;
         // ilqr.hpp:409-427: raise the regularisation and restart the sweep (next round)
         double rho2 = rho, drho2 = drho;
         increase_reg(o, &rho2, &drho2);
@@ -801,6 +818,10 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
       need = need && !gave_up;
       slot++;
+      if (SPEC && (k & 1) == 0) {  // the forward waves' barrier of this pair of knots
+        __builtin_amdgcn_s_barrier();
+        ++*nbar;
+      }
     };
     int k = N - 1;
     // one block of H knots from `Cur`; false once knot 0 has been processed
@@ -824,6 +845,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
     }
     need = need && !running;  // instances that reached knot 0 are done
     if (!FUSED) flush();
+    if (SPEC) need = false;  // one sweep only: a failed factorisation invalidates the speculation
   }
   {
     double a0, a1;
@@ -834,14 +856,24 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   }
   if (!inst_on || r != 0) return;
   if (c == 3) {  // the lane that holds row 0 of the vector column
-    A.dV0[b] = dV0;
-    A.dV1[b] = 0.5 * dV1;
+    if (!SPEC) {
+      A.dV0[b] = dV0;
+      A.dV1[b] = 0.5 * dV1;
+    }
     if (FUSED) {
       fh[1] = dV0;
       fh[2] = 0.5 * dV1;
     }
   }
   if (c != 0) return;
+  if (SPEC) {
+    fh[6] = rho;  // stats_.Log("reg", rho_) of the speculated iteration
+    decrease_reg(o, &rho, &drho);
+    fh[4] = rho;
+    fh[5] = drho;
+    fh[7] = spec_bad ? 0.0 : 1.0;
+    return;
+  }
   if (!FUSED) {
     A.J0[b] = J0;
     if (A.need_init_cost[b]) {
@@ -2133,7 +2165,6 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
   return viol;
 }
 
-ALTRO_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The rollout wave hands (xbar_k, ubar_k) to the two consumer waves through a ring of kFwdSlots LDS slots and
 // the workgroup barrier is taken once per PAIR of knots: the producer syncs after the odd knots (and after the
@@ -2574,10 +2605,20 @@ constexpr int kRgAhead = ALTRO_RG_AHEAD;  // knots of prefetch distance of the k
 // Only the persistent kernel's variant for problems that HAVE circle constraints is built that way: the kernel sits at
 // the register limit, and code of constraint kinds a problem does not have still moves the allocation of its hot
 // loops (measured: +4 % per iteration on the obstacle-free config 2 when its circle arms grew).
+// spec != nullptr (k_sweep_fused with a fourth wave): that wave runs the speculative backward pass of the next
+// iteration (backward_mfma_body<.., SPEC>) beside the three forward waves and joins every workgroup barrier of theirs.
+template <class T>
+struct FwdSpec {
+  T* sKD2;        // second gain block (LDS)
+  int junk2;      // junk slots behind it, relative to sKD2
+  double* fh2;    // hand-over values of the speculative pass
+  double* inbox;  // {rho, drho} the pass assumed
+};
 template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
-                             const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr) {
+                             const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
+                             const FwdSpec<T>* spec = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -2773,6 +2814,25 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     return;
   }
 
+  if constexpr (FUSED && M::n == 3 && M::m == 2) {
+    if (wave == 3) {
+      // ============ fourth wave: the backward pass of the NEXT iteration, assuming this line search fails ============
+      // (ilqr.hpp:550: a rejected step raises the regularisation; nothing else changes)
+      double rho_in = fh[4], drho_in = fh[5];
+      increase_reg(o, &rho_in, &drho_in);
+      if (lane == 0) {
+        spec->inbox[0] = rho_in;
+        spec->inbox[1] = drho_in;
+        spec->fh2[7] = 0.0;
+      }
+      int nbar = 0;
+      backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
+                                                  rho_in, drho_in, &nbar);
+      // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V)
+      for (const int bars = N / 2 + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
+      return;
+    }
+  }
   // ===================== cost wave: iLQR::Cost per trial + everything after ======================
   CtxL<T> C(A, b, sPool, sIp, sLam, sPen);
   const double J0 = FUSED ? fh[0] : A.J0[b];
@@ -2945,10 +3005,20 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // instance is finished (the AL state machine of phase 3 says so) -- no further launches, no host in
 // the loop; *sweeps_out receives the largest number of iterations any workgroup ran.
 // -------------------------------------------------------------------------------------------------
-template <class T, class M, bool CIRC>
-__global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
-                                                            const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
-                                                            int* sweeps_out) {
+// SPEC: a FOURTH wave (the CU has four SIMDs, the three forward waves occupy three) runs the backward pass of the
+// next iteration beside the forward pass of this one, on the assumption that the line search rejects every trial:
+// then trajectory, multipliers and expansions stay what they are and only the regularisation -- known in advance --
+// changes.  If the forward pass does end that way (and the inner solve goes on), the next iteration recomputes its
+// expansions as always, takes the gains and the expected decrease from the speculative pass instead of running the
+// recursion again, and goes straight to its forward pass; otherwise the speculation is dropped.  Every straggler of
+// the tail sits in exactly that regime (a line search that rejects all 20 trials, iteration after iteration), so the
+// two serial chains of an iteration overlap: 64 -> ~40 us.  Same arithmetic on the same inputs: same bits
+// (ALTRO_HIP_NO_SPECULATION runs the three-wave kernel).
+template <class T, class M, bool CIRC, bool SPEC>
+__global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
+    DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
+    int* sweeps_out) {
+  constexpr int kThreads = (SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock;
   using R = Rec<T, M::n, M::m>;
   constexpr int nm = M::n + M::m;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2973,6 +3043,11 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
   int* active_flag = reinterpret_cast<int*>(fh + 6 + kBlock);
   double* ff = fh + 6 + kBlock + 2;                          // {rejected, rho, drho, inner_done} of the last iteration
   T* sCand = reinterpret_cast<T*>(fh + 6 + kBlock + 2 + 16);  // [N+1][20][n+m] line-search candidates (128-byte phase kept)
+  // the speculative backward pass: second gain block + junk slots, hand-over values, assumed regularisation
+  T* sKD2 = sCand + (size_t)(N + 1) * kLineSearchLanes * nm;
+  double* fh2 = reinterpret_cast<double*>(sKD2 + N * R::KP + kBlock);
+  const FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8};
+  bool adopt = false;
   bool prev_rej = false;
   double prev_rho = -1.0, prev_drho = -1.0;
   int skipped = 0;
@@ -2981,21 +3056,39 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
     //      forward pass keep the LDS copies current from then on ----
     if (loops == 0) {
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kFwdWaves * kBlock, kKdNone);
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kThreads, kKdNone);
       __syncthreads();
     }
     // ---- E: expansions from the LDS block ----
     {
       const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
                        sm + L.nX + L.nU + L.nKD + L.rowsP());
-      expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kFwdWaves * kBlock);
+      expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kThreads);
     }
-    __syncthreads();  // drains the stores: the records are in L2 for the backward wave, the costs in LDS
+    // drains the stores: the records are in L2 for the backward wave, the costs in LDS.  (A speculated iteration runs
+    // no backward pass of its own, and the records it just rewrote are bit for bit the ones the fourth wave will read:
+    // only the LDS traffic has to settle -- the two microseconds of store acknowledgements stay off the chain.)
+    if (SPEC && adopt) lds_barrier(); else __syncthreads();
 
-    if (wave == 0) {
+    if (SPEC && adopt) {
+      // ---- B was run ahead by the fourth wave during the previous forward pass: take its results ----
+      for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = sKD2[i];
+      if (tid == 0) {
+        fh[1] = fh2[1];
+        fh[2] = fh2[2];
+        fh[4] = fh2[4];
+        fh[5] = fh2[5];
+        A.dV0[b] = fh2[1];
+        A.dV1[b] = fh2[2];
+        A.reg_log[b] = fh2[6];  // stats_.Log("reg", rho_)
+        A.rho_reg[b] = fh2[4];
+        A.drho[b] = fh2[5];
+      }
+    } else if (wave == 0) {
       // ---- B ----
       backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
-    } else if (wave == 1) {
+    }
+    if (wave == 1) {
       // running cost in knot order (ilqr.hpp:326-334)
       double J0 = 0.0;
       for (int k = 0; k <= N; ++k) J0 += (double)xch[k];
@@ -3011,12 +3104,18 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
         fh[3] = ic;
       }
     }
-    __syncthreads();
+    if (SPEC && adopt) lds_barrier(); else __syncthreads();
     // ---- F ----
-    forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff);
+    forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
+                                             SPEC ? &spec : nullptr);
     ++loops;
-    __syncthreads();
+    // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
+    //  backward pass of the next iteration would read from global memory: see the end of the loop)
+    if (SPEC) lds_barrier(); else __syncthreads();
     if (!persistent || *active_flag == 0) break;
+    // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
+    // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
+    if (SPEC) adopt = fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
     if (o.fast_forward_stalls) {
       // OPT-IN, off by default.  A rejected line search leaves the trajectory, the multipliers and -- once
       // the regularisation has settled into its increase/decrease cycle -- the whole state of the instance
@@ -3045,10 +3144,12 @@ __global__ __launch_bounds__(kFwdWaves * kBlock) void k_sweep_fused(DevArrays<T>
     }
     // (waves of a workgroup share the CU's vector L1, which stores write through and keep coherent,
     // so what this iteration wrote -- trajectory, multipliers, records -- is what the next one reads)
-    __syncthreads();  // everyone has read the flag before phase 3 of the next iteration rewrites it
+    // everyone has read the flag before phase 3 of the next iteration rewrites it; without a speculated backward pass
+    // the next iteration reads this one's scalars from global memory: drain the stores
+    if (SPEC && adopt) lds_barrier(); else __syncthreads();
   }
   // the gains for the getters (nothing inside the sweep reads them from global memory)
-  for (int i = tid; i < N * R::KP; i += kFwdWaves * kBlock) {
+  for (int i = tid; i < N * R::KP; i += kThreads) {
     const int k = i / R::KP, e = i - k * R::KP;
     using RS = rec_scalar_t<T, M>;
     if (e < (Rec<RS, M::n, M::m>::KP)) RECP((RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[e] = (RS)sKDf[i];
