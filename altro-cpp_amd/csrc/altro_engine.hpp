@@ -987,7 +987,8 @@ class Engine final : public EngineBase {
       fwd_lds_bytes_ = shared_bytes + fwd_per_wave_ * per_inst;
       fwd_shared_bytes_ = shared_bytes;
       fwd_per_inst_bytes_ = per_inst;
-      fused_lds_bytes_ = (shared_bytes + per_inst + 15) / 16 * 16 + (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
+      fused_lds_bytes_ = (shared_bytes + (2 * kSyncFused - kFwdSlots) * (size_t)nm * kBlock * sizeof(T) + per_inst + 15) / 16 * 16 +
+                         (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T) +  // + the candidates of one instance
                          ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);  // + the speculative pass (gains, hand-over)
       kdg_ = false;

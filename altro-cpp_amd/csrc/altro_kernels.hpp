@@ -35,6 +35,12 @@ namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
 constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost wave, auxiliary wave
+// knots per workgroup barrier of the persistent kernel's knot loop (the batched sweeps: 2), see producer_syncs_after.
+// (4 was measured: persistent launch 5.24 -> 5.30 ms on config 2, 5.03 -> 4.74 ms on config 3; the headline keeps 2.)
+#ifndef ALTRO_SYNC_FUSED
+#define ALTRO_SYNC_FUSED 2
+#endif
+constexpr int kSyncFused = ALTRO_SYNC_FUSED;
 // workgroup barrier that only waits for this wave's LDS traffic (not for its global loads / stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -818,7 +824,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
       need = need && !gave_up;
       slot++;
-      if (SPEC && (k & 1) == 0) {  // the forward waves' barrier of this pair of knots
+      if (SPEC && (k & (kSyncFused - 1)) == 0) {  // the forward waves' barrier of this stretch of knots
         __builtin_amdgcn_s_barrier();
         ++*nbar;
       }
@@ -2170,10 +2176,13 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 // the workgroup barrier is taken once per PAIR of knots: the producer syncs after the odd knots (and after the
 // terminal one), the consumers before the even ones.  Barrier j publishes knots 2j, 2j+1; the producer overwrites
 // their slots with knots 2j+4, 2j+5 only after barrier j+1, which the consumers reach after finishing pair j.
+// G = knots per barrier: 2 in the batched sweeps (kFwdSlots = 4 slots), kSyncFused in the persistent kernel, whose
+// knot loop runs in lock step with the speculative backward pass of the fourth wave: the longer the stretch between
+// two barriers, the less the slowest of four waves per stretch costs (and the fewer barriers the recursion pays).
 constexpr int kFwdSlots = 4;
-ALTRO_DEV bool producer_syncs_after(int k, int N) { return (k & 1) != 0 || k == N; }
-ALTRO_DEV bool consumer_syncs_before(int k) { return (k & 1) == 0; }
-ALTRO_DEV int fwd_slot(int k) { return k & (kFwdSlots - 1); }
+ALTRO_DEV bool producer_syncs_after(int k, int N, int G = 2) { return (k & (G - 1)) == G - 1 || k == N; }
+ALTRO_DEV bool consumer_syncs_before(int k, int G = 2) { return (k & (G - 1)) == 0; }
+ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
 
 
 // iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the auxiliary wave so that they
@@ -2224,6 +2233,7 @@ ALTRO_DEV double from_upper_half(double x) {
 template <class T, class M, bool PAIRED>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
                             bool valid, T* cand_inst, int* flags, double* gsx, bool grad) {
+  constexpr int G = PAIRED ? kSyncFused : 2;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   const bool check = o.check_forwardpass_bounds != 0;
@@ -2236,10 +2246,10 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
   double gs = 0.0;
   constexpr int kStep = PAIRED ? 2 : 1;
   for (int k0 = 0; k0 <= N; k0 += kStep) {
-    if (consumer_syncs_before(k0)) lds_barrier();  // publishes (xbar, ubar) of knots k0, k0+1 of every trial
+    if (consumer_syncs_before(k0, G)) lds_barrier();  // publishes (xbar, ubar) of knots k0 .. k0+G-1 of every trial
     const int k = k0 + half;                       // k <= N + 1; N is the terminal knot (a state only)
     const bool inner = k < N;
-    const T* slot = xch + fwd_slot(k) * (nm * kBlock);
+    const T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
     T xb[n], ub[m], d[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + col];
@@ -2292,7 +2302,7 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
 // runtime loop: the 30 VGPRs would cost them a wave per SIMD.
 template <class T, class M, int FK, bool HOIST>
 ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
-                                 int kend, const T* xch, int lane, double& J) {
+                                 int kend, const T* xch, int lane, double& J, int G) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   const KnotClass& kc = pd->cls[run.cls];
   RunConsts<T, n, m> RC;
@@ -2372,8 +2382,8 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   };
   fetch_bound_rows(k_begin, blam, brho, clam, crho);
   for (int k = k_begin; k < kend; ++k) {
-    if (consumer_syncs_before(k)) lds_barrier();  // publishes (xbar, ubar) of knots k, k+1 of every trial
-    const T* slot = xch + fwd_slot(k) * (nm * kBlock);
+    if (consumer_syncs_before(k, G)) lds_barrier();  // publishes (xbar, ubar) of knots k .. k+G-1 of every trial
+    const T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
     T xb[n], ub[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xb[i] = slot[i * kBlock + lane];
@@ -2647,7 +2657,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T* sIp = sPen + L.rowsP();
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
-  int* flags = reinterpret_cast<int*>(xch + kFwdSlots * nm * kBlock);  // [2][64]: ok, status of each trial
+  constexpr int G = FUSED ? kSyncFused : 2;  // knots per workgroup barrier of the knot loop (2 G hand-off slots)
+  int* flags = reinterpret_cast<int*>(xch + 2 * G * nm * kBlock);  // [2][64]: ok, status of each trial
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
     forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock,
@@ -2659,7 +2670,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   // knot by the auxiliary wave for every trial -- its two half-waves have the slack.  Batched sweeps, where that wave
   // is the critical one: only for the winner, in phase 2 -- each knot's term into the hand-off slots (free by then),
   // summed in knot order afterwards: the same additions in the same order.
-  const bool grad_in_loop = FUSED || (!RG && 16 + per_wave * N > kFwdSlots * nm * kBlock);  // (RG: the engine checked)
+  const bool grad_in_loop = FUSED || (!RG && 16 + per_wave * N > 2 * G * nm * kBlock);  // (RG: the engine checked)
   T* const rk = grad_in_loop ? nullptr : xch + 16 + (grp < per_wave ? grp : 0) * N;
 
   T x0[R::nP];
@@ -2721,7 +2732,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         for (int l = 0; l < n; ++l) sacc += (T)cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
         ub[i] = cur.uk[i] + sacc + (T)cur.kd[R::oD + i] * alpha;
       }
-      T* slot = xch + fwd_slot(k) * (nm * kBlock);
+      T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
 #pragma unroll
       for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
 #pragma unroll
@@ -2735,7 +2746,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
-      if (producer_syncs_after(k, N)) lds_barrier();
+      if (producer_syncs_after(k, N, G)) lds_barrier();
     };
     if constexpr (RG && kRgAhead == 2) {
       // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
@@ -2761,7 +2772,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (k < N) knot(k, qa, qb);
     }
     // final hand-off: x_N
-    T* slot = xch + fwd_slot(N) * (nm * kBlock);
+    T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
     lds_barrier();  // barrier N (producer_syncs_after(N, N))
@@ -2829,7 +2840,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
                                                   rho_in, drho_in, &nbar);
       // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V)
-      for (const int bars = N / 2 + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
+      for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
       return;
     }
   }
@@ -2847,7 +2858,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   for (int r = 0; r < pd->nruns; ++r) {
     const KnotRun run = pd->runs[r];
     const int kend = run.k_end < N ? run.k_end : N;
-#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK, HOISTC>(C, pd, A, run, kend, xch, lane, J)
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK, HOISTC>(C, pd, A, run, kend, xch, lane, J, G)
     switch (run.fast) {
       case kFastNone: ALTRO_RUN(kFastNone); break;
       case kFastB: ALTRO_RUN(kFastB); break;
@@ -2858,9 +2869,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
 #undef ALTRO_RUN
   }
-  if (consumer_syncs_before(N)) lds_barrier();  // barrier N: terminal state and rollout outcome
+  if (consumer_syncs_before(N, G)) lds_barrier();  // barrier N: terminal state and rollout outcome
   {
-    const T* slot = xch + fwd_slot(N) * (nm * kBlock);
+    const T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
     T xN[n], uz[m];
 #pragma unroll
     for (int i = 0; i < n; ++i) xN[i] = slot[i * kBlock + lane];
@@ -3036,7 +3047,7 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
   T* sKDf = sm + L.nX + L.nU;
   T* sPool = sm + L.total();
   T* xch = sPool + L.padv(pd->npool);
-  int* flags = reinterpret_cast<int*>(xch + kFwdSlots * nm * kBlock);
+  int* flags = reinterpret_cast<int*>(xch + 2 * kSyncFused * nm * kBlock);
   double* fh = reinterpret_cast<double*>(flags + 2 * kBlock) + kBlock;  // behind the gradient slots
   const int fused_junk = (int)(reinterpret_cast<T*>(fh + 6) - sKDf);  // one junk slot per lane, in units of T
 
