@@ -76,6 +76,8 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     persist_at_ = num_cus_;
     if (const char* e = std::getenv("ALTRO_HIP_PERSIST_AT")) persist_at_ = atoi(e);
@@ -516,6 +518,8 @@ class Engine final : public EngineBase {
     if (d_counter_) hipFree(d_counter_);
     if (h_counter_) hipHostFree((void*)h_counter_);
     for (auto& e : prof_ev_) hipEventDestroy(e);
+    if (stream2_) hipStreamDestroy(stream2_);
+    if (spec_ev_) hipEventDestroy(spec_ev_);
     if (stream_) hipStreamDestroy(stream_);
   }
   altro_status DownloadVec(const double* dev, double* out) {
@@ -925,6 +929,13 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(d_tmp_, bp);
     ALTRO_ALLOC(d_list_[0], bp);
     ALTRO_ALLOC(d_list_[1], bp);
+    if constexpr (kMfmaBackward) {
+      if (spec_mode_ == kSpecHelper) {  // hand-over buffers of the helper workgroups (SpecRemote)
+        ALTRO_ALLOC(d_spec_go_, 2 * (size_t)bp);
+        ALTRO_ALLOC(d_spec_io_, 10 * (size_t)bp);
+        ALTRO_ALLOC(d_spec_kd_, (size_t)bp * N_ * R::KP);
+      }
+    }
     ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * R::nP * bp);
     ALTRO_ALLOC(U_init_, (size_t)N_ * R::mP * bp);
     T* dpool = nullptr;
@@ -1062,10 +1073,12 @@ class Engine final : public EngineBase {
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
         {
-          const void* variants[4] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, false>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, false>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, true>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, true>)};
+          const void* variants[6] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecOff>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecWave>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecHelper>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecHelper>)};
           for (const void* fn : variants)
             ALTRO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
         }
@@ -1165,14 +1178,29 @@ class Engine final : public EngineBase {
           // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
           int* const out = d_counter_ + max_sweeps + 2;
           const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
-          if (circles && speculate_)
-            hipLaunchKernelGGL((k_sweep_fused<T, M, true, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
-          else if (circles)
-            hipLaunchKernelGGL((k_sweep_fused<T, M, true, false>), g, b3, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
-          else if (speculate_)
-            hipLaunchKernelGGL((k_sweep_fused<T, M, false, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
-          else
-            hipLaunchKernelGGL((k_sweep_fused<T, M, false, false>), g, b3, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out);
+          SpecRemote<T> rs{};
+          if (spec_mode_ == kSpecHelper) {
+            // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
+            rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
+            hipMemsetAsync(d_spec_go_, 0, 2 * (size_t)Bp_ * sizeof(int), stream_);
+            hipEventRecord(spec_ev_, stream_);
+            hipStreamWaitEvent(stream2_, spec_ev_, 0);
+            const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
+            hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, stream2_, A, d, rs);
+            spec_helper_running_ = true;
+          }
+#define ALTRO_FUSED(C, S, BLK) \
+  hipLaunchKernelGGL((k_sweep_fused<T, M, C, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs)
+          if (circles) {
+            if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
+            else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
+            else ALTRO_FUSED(true, kSpecOff, b3);
+          } else {
+            if (spec_mode_ == kSpecHelper) ALTRO_FUSED(false, kSpecHelper, b3);
+            else if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
+            else ALTRO_FUSED(false, kSpecOff, b3);
+          }
+#undef ALTRO_FUSED
         }
         if (prof) hipEventRecord(ProfEvent(nev++), stream_);
         persistent_launched = true;
@@ -1243,6 +1271,10 @@ class Engine final : public EngineBase {
       if (known_count == 0) finished = true;
     }
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+    if (spec_helper_running_) {
+      ALTRO_HIP_CHECK(hipStreamSynchronize(stream2_));
+      spec_helper_running_ = false;
+    }
     ALTRO_HIP_CHECK(hipGetLastError());
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
     if (persistent_launched) {
@@ -1294,7 +1326,21 @@ class Engine final : public EngineBase {
   bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
   bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
-  bool speculate_ = std::getenv("ALTRO_HIP_NO_SPECULATION") == nullptr;
+  // speculative backward pass of the persistent kernel: on its fourth wave (default), in helper workgroups
+  // (ALTRO_HIP_SPECULATION=helper), or not at all (ALTRO_HIP_NO_SPECULATION / =off)
+  int spec_mode_ = [] {
+    if (std::getenv("ALTRO_HIP_NO_SPECULATION")) return (int)kSpecOff;
+    const char* e = std::getenv("ALTRO_HIP_SPECULATION");
+    if (e && std::string(e) == "helper") return (int)kSpecHelper;
+    if (e && std::string(e) == "off") return (int)kSpecOff;
+    return (int)kSpecWave;
+  }();
+  hipStream_t stream2_ = nullptr;
+  hipEvent_t spec_ev_ = nullptr;
+  bool spec_helper_running_ = false;
+  int* d_spec_go_ = nullptr;      // [2][Bp]: request tags, delivered tags
+  double* d_spec_io_ = nullptr;   // [Bp][2] in, [Bp][8] out
+  T* d_spec_kd_ = nullptr;        // [Bp][N * KP]
   bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., kSrcKdg>)
   bool rg_ = false;   // ... all of the rollout wave's per-knot inputs (k_forward2<.., kSrcGlb>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;

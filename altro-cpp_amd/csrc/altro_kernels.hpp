@@ -824,7 +824,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       if (CTG) *((commit && offCT >= 0) ? RECP(A.CTG, k, R::CP) + offCT : sink) = (T)Pn;
       need = need && !gave_up;
       slot++;
-      if (SPEC && (k & (kSyncFused - 1)) == 0) {  // the forward waves' barrier of this stretch of knots
+      if (SPEC && nbar && (k & (kSyncFused - 1)) == 0) {  // the forward waves' barrier of this stretch of knots
         __builtin_amdgcn_s_barrier();
         ++*nbar;
       }
@@ -2623,6 +2623,7 @@ struct FwdSpec {
   int junk2;      // junk slots behind it, relative to sKD2
   double* fh2;    // hand-over values of the speculative pass
   double* inbox;  // {rho, drho} the pass assumed
+  bool armed;     // speculate in this forward pass (the previous line search was rejected: a streak is likely)
 };
 template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
@@ -2837,8 +2838,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         spec->fh2[7] = 0.0;
       }
       int nbar = 0;
-      backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
-                                                  rho_in, drho_in, &nbar);
+      // (not armed: the fourth wave just keeps the barrier count)
+      if (spec->armed)
+        backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
+                                                    rho_in, drho_in, &nbar);
       // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V)
       for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
       return;
@@ -3025,11 +3028,27 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // the tail sits in exactly that regime (a line search that rejects all 20 trials, iteration after iteration), so the
 // two serial chains of an iteration overlap: 64 -> ~40 us.  Same arithmetic on the same inputs: same bits
 // (ALTRO_HIP_NO_SPECULATION runs the three-wave kernel).
-template <class T, class M, bool CIRC, bool SPEC>
-__global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
+// SPEC = kSpecHelper: the speculative pass runs in a workgroup of its own (k_spec_helper, one wave, any CU with a free
+// SIMD) at its own pace instead of in lock step with the forward waves' barriers; regularisation in, gains and
+// hand-over values out travel through global memory with release / acquire flags at agent scope.  Neither side ever
+// blocks on the other: this kernel waits a bounded number of polls for a result and otherwise runs the recursion
+// itself, the helper gives up after a bounded number of idle polls.
+enum SpecMode { kSpecOff = 0, kSpecWave = 1, kSpecHelper = 2 };
+template <class T>
+struct SpecRemote {
+  int* go;      // [Bp] tag of the pass requested by the instance's workgroup (-1: finished)
+  int* done;    // [Bp] tag of the pass the helper has delivered
+  double* in;   // [Bp][2] regularisation to assume
+  double* out;  // [Bp][8] dV0, dV1 / 2, rho, drho after DecreaseRegularization, rho used, ok
+  T* kd;        // [Bp][N * KP] gains
+};
+constexpr int kSpecPolls = 400;  // polls of the result flag before the recursion is run locally (~0.1 us each)
+
+template <class T, class M, bool CIRC, int SPEC>
+__global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
     DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
-    int* sweeps_out) {
-  constexpr int kThreads = (SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock;
+    int* sweeps_out, SpecRemote<T> rs) {
+  constexpr int kThreads = (SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * kBlock;
   using R = Rec<T, M::n, M::m>;
   constexpr int nm = M::n + M::m;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -3057,7 +3076,19 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
   // the speculative backward pass: second gain block + junk slots, hand-over values, assumed regularisation
   T* sKD2 = sCand + (size_t)(N + 1) * kLineSearchLanes * nm;
   double* fh2 = reinterpret_cast<double*>(sKD2 + N * R::KP + kBlock);
-  const FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8};
+  FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8, false};
+  int* const remote_ok = reinterpret_cast<int*>(fh2 + 10);  // helper mode: the poll's verdict for the workgroup
+  int tag = 0;
+  // helper mode: ask for the backward pass of the next iteration under the regularisation a rejected step will set
+  auto request = [&]() __attribute__((always_inline)) {
+    double rho_in = fh[4], drho_in = fh[5];
+    increase_reg(o, &rho_in, &drho_in);
+    fh2[8] = rho_in;
+    fh2[9] = drho_in;
+    rs.in[2 * (size_t)b] = rho_in;
+    rs.in[2 * (size_t)b + 1] = drho_in;
+    __hip_atomic_store(rs.go + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
   bool adopt = false;
   bool prev_rej = false;
   double prev_rho = -1.0, prev_drho = -1.0;
@@ -3081,23 +3112,42 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
     // only the LDS traffic has to settle -- the two microseconds of store acknowledgements stay off the chain.)
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
 
+    if (SPEC != kSpecOff) ++tag;  // (wave-uniform: every thread counts)
+    // speculate only in a streak of rejections (ff: phase 3 of the previous iteration, rewritten by this one's): a
+    // converging instance accepts its steps, a recursion beside its forward pass would only slow that down, and the
+    // release fence of a request to the helper is not free
+    const bool armed = SPEC != kSpecOff && loops > 0 && ff[0] != 0.0;
     if (SPEC && adopt) {
-      // ---- B was run ahead by the fourth wave during the previous forward pass: take its results ----
-      for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = sKD2[i];
+      // ---- B was run ahead (fourth wave / helper workgroup) during the previous forward pass: take its results ----
+      if (SPEC == kSpecHelper) {
+        const T* src = rs.kd + (size_t)b * (size_t)(N * R::KP);
+        for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = src[i];
+      } else {
+        for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = sKD2[i];
+      }
       if (tid == 0) {
-        fh[1] = fh2[1];
-        fh[2] = fh2[2];
-        fh[4] = fh2[4];
-        fh[5] = fh2[5];
-        A.dV0[b] = fh2[1];
-        A.dV1[b] = fh2[2];
-        A.reg_log[b] = fh2[6];  // stats_.Log("reg", rho_)
-        A.rho_reg[b] = fh2[4];
-        A.drho[b] = fh2[5];
+        double h[6];
+        if (SPEC == kSpecHelper) {
+          for (int q = 0; q < 5; ++q) h[q] = rs.out[8 * (size_t)b + q];
+        } else {
+          h[0] = fh2[1]; h[1] = fh2[2]; h[2] = fh2[4]; h[3] = fh2[5]; h[4] = fh2[6];
+        }
+        fh[1] = h[0];
+        fh[2] = h[1];
+        fh[4] = h[2];
+        fh[5] = h[3];
+        A.dV0[b] = h[0];
+        A.dV1[b] = h[1];
+        A.reg_log[b] = h[4];  // stats_.Log("reg", rho_)
+        A.rho_reg[b] = h[2];
+        A.drho[b] = h[3];
+        if (SPEC == kSpecHelper) request();  // (adopted = in a streak of rejections)
       }
     } else if (wave == 0) {
       // ---- B ----
       backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+      // (its own LDS writes of fh[4], fh[5]: program order)
+      if (SPEC == kSpecHelper && lane == 0 && armed) request();
     }
     if (wave == 1) {
       // running cost in knot order (ilqr.hpp:326-334)
@@ -3117,8 +3167,9 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
     }
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
     // ---- F ----
+    spec.armed = armed;
     forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
-                                             SPEC ? &spec : nullptr);
+                                             SPEC == kSpecWave ? &spec : nullptr);
     ++loops;
     // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
     //  backward pass of the next iteration would read from global memory: see the end of the loop)
@@ -3126,7 +3177,25 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
     if (!persistent || *active_flag == 0) break;
     // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
     // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
-    if (SPEC) adopt = fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
+    if (SPEC == kSpecWave) adopt = armed && fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
+    if (SPEC == kSpecHelper) {
+      const bool mine = armed && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
+      if (tid == 0) {
+        int ok = 0;
+        if (mine) {
+          for (int tries = 0; tries < kSpecPolls; ++tries) {
+            if (__hip_atomic_load(rs.done + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+              ok = rs.out[8 * (size_t)b + 5] != 0.0 ? 1 : 0;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        *remote_ok = ok;
+      }
+      lds_barrier();
+      adopt = *remote_ok != 0;
+    }
     if (o.fast_forward_stalls) {
       // OPT-IN, off by default.  A rejected line search leaves the trajectory, the multipliers and -- once
       // the regularisation has settled into its increase/decrease cycle -- the whole state of the instance
@@ -3165,9 +3234,58 @@ __global__ __launch_bounds__((SPEC ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k
     using RS = rec_scalar_t<T, M>;
     if (e < (Rec<RS, M::n, M::m>::KP)) RECP((RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[e] = (RS)sKDf[i];
   }
+  if (SPEC == kSpecHelper && tid == 0) __hip_atomic_store(rs.go + b, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (sweeps_out && tid == 0) {
     atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations
     atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
+  }
+}
+
+// The speculative backward passes of k_sweep_fused<.., kSpecHelper>: one wavefront per straggler, on whatever CU has
+// a SIMD to spare.  Polls the instance's request tag, runs backward_mfma_body<.., SPEC> (no barriers: nbar = nullptr)
+// under the regularisation it is handed, publishes gains and hand-over values, repeats; leaves when the instance's
+// workgroup says so (tag -1) or after kSpecIdlePolls polls without a new request (never a hang).
+constexpr long long kSpecIdlePolls = 4000000;
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts o, SpecRemote<T> rs) {
+  using R = Rec<T, M::n, M::m>;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int b = instance_of_slot(A, blockIdx.x, 0);
+  if (b < 0) return;
+  const int N = A.N;
+  T* sKD = reinterpret_cast<T*>(smem_raw);  // [N * KP] gains + one junk slot per lane
+  double* fh2 = reinterpret_cast<double*>(sKD + N * R::KP + kBlock);
+  int last = 0;
+  for (long long idle = 0; idle < kSpecIdlePolls;) {
+    int tag = 0;
+    if (lane == 0) tag = __hip_atomic_load(rs.go + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    tag = __shfl(tag, 0);
+    if (tag < 0) break;
+    if (tag == last) {
+      __builtin_amdgcn_s_sleep(8);
+      ++idle;
+      continue;
+    }
+    idle = 0;
+    last = tag;
+    const double rho_in = rs.in[2 * (size_t)b], drho_in = rs.in[2 * (size_t)b + 1];
+    if (lane == 0) fh2[7] = 0.0;
+    backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, sKD, N * R::KP, fh2, rho_in, drho_in, nullptr);
+    __syncthreads();
+    T* dst = rs.kd + (size_t)b * (size_t)(N * R::KP);
+    for (int i = lane; i < N * R::KP; i += kBlock) dst[i] = sKD[i];
+    if (lane == 0) {
+      double* out = rs.out + 8 * (size_t)b;
+      out[0] = fh2[1];
+      out[1] = fh2[2];
+      out[2] = fh2[4];
+      out[3] = fh2[5];
+      out[4] = fh2[6];
+      out[5] = fh2[7];
+    }
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(rs.done + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -109,7 +109,7 @@ np.savez(sys.argv[1], **out)
 
 @pytest.mark.parametrize("switch", [{"ALTRO_HIP_NO_DENSE_EXPANSIONS": "1"}, {"ALTRO_HIP_FWD_SRC": "global"},
                                     {"ALTRO_HIP_FWD_SRC": "lds"}, {"ALTRO_HIP_FWD_PER_WAVE": "1"},
-                                    {"ALTRO_HIP_NO_SPECULATION": "1"}],
+                                    {"ALTRO_HIP_NO_SPECULATION": "1"}, {"ALTRO_HIP_SPECULATION": "helper"}],
                          ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
 def test_launch_variants_are_bit_identical(tmp_path, switch):
     """The batched sweeps have several launch variants chosen by measurements (dense / list-addressed expansions with
