@@ -1001,7 +1001,7 @@ class Engine final : public EngineBase {
       fused_lds_bytes_ = (shared_bytes + (2 * kSyncFused - kFwdSlots) * (size_t)nm * kBlock * sizeof(T) + per_inst + 15) / 16 * 16 +
                          (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T) +  // + the candidates of one instance
-                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);  // + the speculative pass (gains, hand-over)
+                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 40 * sizeof(double);  // + the speculative pass (gains, hand-over), step-length table
       kdg_ = false;
       rg_ = false;
       if constexpr (kRgEligible) {

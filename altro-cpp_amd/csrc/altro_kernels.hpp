@@ -2629,7 +2629,7 @@ template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
-                             const FwdSpec<T>* spec = nullptr) {
+                             const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -2674,13 +2674,20 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const bool grad_in_loop = FUSED || (!RG && 16 + per_wave * N > 2 * G * nm * kBlock);  // (RG: the engine checked)
   T* const rk = grad_in_loop ? nullptr : xch + 16 + (grp < per_wave ? grp : 0) * N;
 
+  // (the persistent kernel keeps the serial chain free of what does not change between its iterations: the initial
+  //  state is knot 0 of the LDS-resident trajectory -- a rollout never moves it -- and the step lengths, 19 dependent
+  //  divisions for the last lane, come from a table the kernel fills once)
   T x0[R::nP];
-  load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0);
+  load_rec<T, R::nP>(FUSED ? sX : A.x0 + (size_t)b * R::nP, x0);
   const T hh = T(pd->hstep);
   const int ls_max = o.line_search_max_iterations;
   // this lane's step length: alpha /= decrease_factor, t times (ilqr.hpp:544)
   T alpha = T(1);
-  for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
+  if (FUSED && alpha_tab) {
+    alpha = alpha_tab[t];
+  } else {
+    for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
+  }
 
   if (wave == 0) {
     // ================= rollout wave: iLQR::RolloutClosedLoop (ilqr.hpp:468-499) =================
@@ -3078,6 +3085,12 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
   double* fh2 = reinterpret_cast<double*>(sKD2 + N * R::KP + kBlock);
   FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8, false};
   int* const remote_ok = reinterpret_cast<int*>(fh2 + 10);  // helper mode: the poll's verdict for the workgroup
+  T* const alpha_tab = reinterpret_cast<T*>(fh2 + 12);      // [20] step lengths of the line-search lanes (ilqr.hpp:544)
+  if (tid < kLineSearchLanes) {
+    T alpha = T(1);
+    for (int i = 0; i < tid; ++i) alpha /= T(o.line_search_decrease_factor);
+    alpha_tab[tid] = alpha;
+  }
   int tag = 0;
   // helper mode: ask for the backward pass of the next iteration under the regularisation a rejected step will set
   auto request = [&]() __attribute__((always_inline)) {
@@ -3100,6 +3113,14 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
     if (loops == 0) {
       forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kThreads, kKdNone);
       __syncthreads();
+    }
+    // (the two per-instance scalars the running-cost wave needs after E: requested now, their memory latency -- two
+    //  dependent round trips -- runs beside the expansions instead of behind them)
+    double ic_early = 0.0;
+    int need_ic_early = 0;
+    if (wave == 1 && lane == 0) {
+      ic_early = A.initial_cost[b];
+      need_ic_early = A.need_init_cost[b];
     }
     // ---- E: expansions from the LDS block ----
     {
@@ -3155,8 +3176,8 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
       for (int k = 0; k <= N; ++k) J0 += (double)xch[k];
       if (lane == 0) {
         A.J0[b] = J0;
-        double ic = A.initial_cost[b];
-        if (A.need_init_cost[b]) {
+        double ic = ic_early;
+        if (need_ic_early) {
           ic = J0;
           A.initial_cost[b] = J0;
           A.need_init_cost[b] = 0;
@@ -3169,7 +3190,7 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
     // ---- F ----
     spec.armed = armed;
     forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
-                                             SPEC == kSpecWave ? &spec : nullptr);
+                                             SPEC == kSpecWave ? &spec : nullptr, alpha_tab);
     ++loops;
     // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
     //  backward pass of the next iteration would read from global memory: see the end of the loop)
