@@ -80,6 +80,11 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     persist_at_ = num_cus_;
+    if (const char* e = std::getenv("ALTRO_HIP_DEBUG_POISON")) {
+      poison_on_ = true;
+      poison_pattern_ = (unsigned)strtoul(e, nullptr, 16);
+      poison_mix_ = std::strchr(e, ',') != nullptr;
+    }
     if (const char* e = std::getenv("ALTRO_HIP_PERSIST_AT")) persist_at_ = atoi(e);
     return ReserveCounters(1024);
   }
@@ -124,7 +129,7 @@ class Engine final : public EngineBase {
     altro_status st = Sync();
     if (st != ALTRO_OK) return st;
     pd_.hstep = hstep;
-    ALTRO_HIP_CHECK(hipMemcpy(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
   altro_status ResetTrajectory() override {
@@ -146,7 +151,7 @@ class Engine final : public EngineBase {
   altro_status SetPenaltyScaling(double phi) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     std::vector<double> v(kMaxClasses * kMaxConPerKnot, phi);
-    ALTRO_HIP_CHECK(hipMemcpy(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
 
@@ -269,7 +274,7 @@ class Engine final : public EngineBase {
     altro_status sst = Sync();
     if (sst != ALTRO_OK) return sst;
     std::vector<RS> h((size_t)RR::EP * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), (const RS*)A_.EXP + (size_t)k * Bp_ * RR::EP, h.size() * sizeof(RS), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(h.data(), (const RS*)A_.EXP + (size_t)k * Bp_ * RR::EP, h.size() * sizeof(RS), hipMemcpyDeviceToHost));
     auto take = [&](double* out, int off, int E, bool stage_only) {
       if (!out || (stage_only && k >= N_)) return;
       for (int b = 0; b < B_; ++b)
@@ -299,7 +304,7 @@ class Engine final : public EngineBase {
       altro_status st = Sync();
       if (st != ALTRO_OK) return st;
     }
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), src, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(h.data(), src, h.size() * sizeof(T), hipMemcpyDeviceToHost));
     for (int b = 0; b < B_; ++b)
       for (int r = 0; r < R; ++r) out[(size_t)b * R + r] = (double)h[(size_t)r * Bp_ + b];
     return ALTRO_OK;
@@ -315,7 +320,7 @@ class Engine final : public EngineBase {
       altro_status st = Sync();
       if (st != ALTRO_OK) return st;
     }
-    ALTRO_HIP_CHECK(hipMemcpy(A_.lam, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(A_.lam, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
   altro_status GetStats(altro_stats* st, bool ilqr_mode) override {
@@ -326,8 +331,8 @@ class Engine final : public EngineBase {
     }
     std::vector<double> f((size_t)kNumScalarT * Bp_);
     std::vector<int> iv((size_t)kNumScalarI * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(f.data(), d_scalarT_, f.size() * sizeof(double), hipMemcpyDeviceToHost));
-    ALTRO_HIP_CHECK(hipMemcpy(iv.data(), d_scalarI_, iv.size() * sizeof(int), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(f.data(), d_scalarT_, f.size() * sizeof(double), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(iv.data(), d_scalarI_, iv.size() * sizeof(int), hipMemcpyDeviceToHost));
     auto F = [&](double* p, int b) { return f[(size_t)(p - d_scalarT_) + b]; };
     auto I = [&](int* p, int b) { return iv[(size_t)(p - d_scalarI_) + b]; };
     for (int b = 0; b < B_; ++b) {
@@ -356,7 +361,7 @@ class Engine final : public EngineBase {
       altro_status sst = Sync();
       if (sst != ALTRO_OK) return sst;
       std::vector<int> it(Bp_);
-      ALTRO_HIP_CHECK(hipMemcpy(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
+      ALTRO_HIP_CHECK(CopySync(it.data(), A_.it_total, (size_t)Bp_ * sizeof(int), hipMemcpyDeviceToHost));
       long long tot = 0;
       for (int b = 0; b < B_; ++b) tot += it[b];
       timing_.instance_iterations = tot;
@@ -376,7 +381,7 @@ class Engine final : public EngineBase {
     if (capacity > 0) {
       ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist, (size_t)kHistFields * capacity * Bp_ * sizeof(double)));
       ALTRO_HIP_CHECK(hipMalloc((void**)&A_.hist_len, (size_t)Bp_ * sizeof(int)));
-      ALTRO_HIP_CHECK(hipMemset(A_.hist_len, 0, (size_t)Bp_ * sizeof(int)));
+      ALTRO_HIP_CHECK(ZeroSync(A_.hist_len, 0, (size_t)Bp_ * sizeof(int)));
       A_.hist_cap = capacity;
     }
     return ALTRO_OK;
@@ -386,7 +391,7 @@ class Engine final : public EngineBase {
     if (hipSetDevice(desc_.device_id) != hipSuccess) return -1;
     if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
     int len = 0;
-    if (hipMemcpy(&len, A_.hist_len + instance, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (CopySync(&len, A_.hist_len + instance, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     // the reference's vectors also hold the row opened by the last NewIteration: a copy of the last
     const int cnt = std::min(std::min(len, A_.hist_cap), cap);
     if (cnt <= 0) return 0;
@@ -428,7 +433,16 @@ class Engine final : public EngineBase {
   // rollout inputs from global memory, two knots ahead in three register sets: small records only
   static constexpr bool kRgEligible = !kKdgEligible && R::KP + R::nP + R::mP <= 16;
   static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
+  // ALTRO_HIP_DEBUG_POISON=<hex pattern>[,mix]: before every kernel of a solve, fill the LDS of every CU with the pattern
+  // (and the line-search candidates once, at upload), to flush out reads of memory the solve has not written.
+  void PoisonLds() {
+    if (!poison_on_) return;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_poison_lds<0>), dim3(num_cus_ * 8), dim3(256), 160 * 1024, stream_, poison_pattern_, 160 * 1024 / 4,
+                       poison_mix_, (int*)nullptr);
+  }
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
+    PoisonLds();
     if constexpr (kMfmaBackward) {
       if (!force_valu_backward_ && mfma_offsets_ok_) {
         if (A.record_ctg)
@@ -465,6 +479,7 @@ class Engine final : public EngineBase {
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
+    PoisonLds();
     if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
       // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
@@ -502,10 +517,21 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     return ALTRO_OK;
   }
+  // Every copy and fill of the engine runs on the engine's own stream and is waited for: that stream is non-blocking, so
+  // work on the null stream (where a plain hipMemcpy / hipMemset goes -- and a device-to-device hipMemcpy or a hipMemset
+  // may return before it has run) would not be ordered against the kernels and the asynchronous copies of the solves.
+  hipError_t CopySync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, stream_);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream_);
+  }
+  hipError_t ZeroSync(void* dst, int value, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, stream_);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream_);
+  }
   template <class U>
   altro_status Alloc(U** p, size_t count) {
     ALTRO_HIP_CHECK(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(U)));
-    ALTRO_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(U)));
+    ALTRO_HIP_CHECK(ZeroSync(*p, 0, std::max<size_t>(count, 1) * sizeof(U)));
     allocs_.push_back((void*)*p);
     return ALTRO_OK;
   }
@@ -523,7 +549,7 @@ class Engine final : public EngineBase {
     if (stream_) hipStreamDestroy(stream_);
   }
   altro_status DownloadVec(const double* dev, double* out) {
-    ALTRO_HIP_CHECK(hipMemcpy(out, dev, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(out, dev, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   }
   // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]
@@ -533,7 +559,7 @@ class Engine final : public EngineBase {
     altro_status sst = Sync();  // the stream is non-blocking: order this null-stream copy after its work
     if (sst != ALTRO_OK) return sst;
     std::vector<E_> h((size_t)knots * EP * Bp_);
-    ALTRO_HIP_CHECK(hipMemcpy(h.data(), dev, h.size() * sizeof(E_), hipMemcpyDeviceToHost));
+    ALTRO_HIP_CHECK(CopySync(h.data(), dev, h.size() * sizeof(E_), hipMemcpyDeviceToHost));
     for (int k = 0; k < knots; ++k)
       for (int b = 0; b < B_; ++b) {
         const E_* src = &h[((size_t)k * Bp_ + b) * EP + off];
@@ -552,7 +578,7 @@ class Engine final : public EngineBase {
           T* dst = &h[((size_t)k * Bp_ + b) * EP];
           for (int e = 0; e < E; ++e) dst[e] = T(s0[e]);
         }
-    ALTRO_HIP_CHECK(hipMemcpy(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
 
@@ -578,8 +604,8 @@ class Engine final : public EngineBase {
     if (st != ALTRO_OK) return st;
     st = UploadRec(A_.U, N_, R::mP, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
-    ALTRO_HIP_CHECK(hipMemcpy(X_init_, A_.X, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
-    ALTRO_HIP_CHECK(hipMemcpy(U_init_, A_.U, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    ALTRO_HIP_CHECK(CopySync(X_init_, A_.X, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
+    ALTRO_HIP_CHECK(CopySync(U_init_, A_.U, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
     return ALTRO_OK;
   }
 
@@ -923,6 +949,11 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
     ALTRO_HIP_CHECK(hipMalloc((void**)&A_.trial, (size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T)));
     allocs_.push_back((void*)A_.trial);
+    if (poison_on_) {
+      std::vector<unsigned> junk((size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T) / 4);
+      for (size_t i = 0; i < junk.size(); ++i) junk[i] = poison_mix_ ? (poison_pattern_ ^ ((unsigned)i * 2654435761u)) : poison_pattern_;
+      ALTRO_HIP_CHECK(CopySync(A_.trial, junk.data(), junk.size() * 4, hipMemcpyHostToDevice));
+    }
     ALTRO_ALLOC(A_.lam, (size_t)rows * bp);
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
@@ -943,30 +974,30 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(dpool, pool.size());
     ALTRO_ALLOC(dipool, ip.size() * bp);
     if (!pool.empty())
-      ALTRO_HIP_CHECK(hipMemcpy(dpool, pool.data(), pool.size() * sizeof(T), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(CopySync(dpool, pool.data(), pool.size() * sizeof(T), hipMemcpyHostToDevice));
     if (!ip.empty()) {
       std::vector<T> flat(ip.size() * bp, T(0));
       for (size_t sl = 0; sl < ip.size(); ++sl)
         for (int b = 0; b < B_; ++b) flat[sl * bp + b] = ip[sl][b];
-      ALTRO_HIP_CHECK(hipMemcpy(dipool, flat.data(), flat.size() * sizeof(T), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(CopySync(dipool, flat.data(), flat.size() * sizeof(T), hipMemcpyHostToDevice));
     }
     A_.pool = dpool;
     A_.ipool = dipool;
     int *dkc = nullptr, *dkr = nullptr;
     ALTRO_ALLOC(dkc, N_ + 1);
     ALTRO_ALLOC(dkr, N_ + 1);
-    ALTRO_HIP_CHECK(hipMemcpy(dkc, knot_class_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
-    ALTRO_HIP_CHECK(hipMemcpy(dkr, knot_rowbase_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(dkc, knot_class_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(dkr, knot_rowbase_.data(), (N_ + 1) * sizeof(int), hipMemcpyHostToDevice));
     A_.knot_class = dkc;
     A_.knot_rowbase = dkr;
     ALTRO_ALLOC(d_phi_, kMaxClasses * kMaxConPerKnot);
     {
       std::vector<double> v(kMaxClasses * kMaxConPerKnot, s.phi >= 1.0 ? s.phi : 10.0);  // constraint_values.hpp:30
-      ALTRO_HIP_CHECK(hipMemcpy(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(CopySync(d_phi_, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     A_.phi = d_phi_;
     ALTRO_ALLOC(d_pd_, 1);
-    ALTRO_HIP_CHECK(hipMemcpy(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
     // per-instance scalar state, one slab each so GetStats is two copies
     ALTRO_ALLOC(d_scalarT_, (size_t)kNumScalarT * bp);
     ALTRO_ALLOC(d_scalarI_, (size_t)kNumScalarI * bp);
@@ -979,8 +1010,8 @@ class Engine final : public EngineBase {
     for (int i = 0; i < kNumScalarI; ++i) *ipn[i] = d_scalarI_ + (size_t)i * bp;
     {
       std::vector<int> ones(bp, ALTRO_UNSOLVED);
-      ALTRO_HIP_CHECK(hipMemcpy(A_.status, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
-      ALTRO_HIP_CHECK(hipMemcpy(A_.status_al, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(CopySync(A_.status, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
+      ALTRO_HIP_CHECK(CopySync(A_.status_al, ones.data(), bp * sizeof(int), hipMemcpyHostToDevice));
     }
     {
       // LDS plan of the forward pass: up to 3 instances per wavefront, at most 80 KiB per workgroup
@@ -1163,6 +1194,7 @@ class Engine final : public EngineBase {
       A.next_count = d_counter_ + i;
       const int ninst = std::max(1, known_count);
       if (fused_ok && i > 0 && ninst <= persist_at_) {
+        PoisonLds();
         // the tail: every instance gets a workgroup that runs the whole iteration (k_sweep_fused)
         if (prof) {
           hipEventRecord(ProfEvent(nev++), stream_);
@@ -1210,6 +1242,7 @@ class Engine final : public EngineBase {
       }
       fused_flag.push_back(0);
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
+      PoisonLds();
       // (small models only: their expansions are HBM-bound; the 12-state model's are compute-bound and pay for the idle
       //  lanes of a dense launch: config 4 +13 %)
       if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= B_) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
@@ -1279,7 +1312,7 @@ class Engine final : public EngineBase {
     const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
     if (persistent_launched) {
       int extra[2] = {0, 0};
-      ALTRO_HIP_CHECK(hipMemcpy(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
       timing_.fused_sweeps = extra[0];
       timing_.fused_instance_iterations = extra[1];
       sweeps += extra[0] - 1;
@@ -1347,6 +1380,9 @@ class Engine final : public EngineBase {
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
   bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
+  bool poison_on_ = false;
+  unsigned poison_pattern_ = 0;
+  int poison_mix_ = 0;
   int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;

@@ -41,6 +41,15 @@ constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost 
 #define ALTRO_SYNC_FUSED 2
 #endif
 constexpr int kSyncFused = ALTRO_SYNC_FUSED;
+// Debugging aid (ALTRO_HIP_DEBUG_POISON): fills the LDS of the CU it lands on with a pattern, so that a kernel that reads
+// LDS it has not written computes with the pattern instead of with whatever the previous kernel happened to leave there.
+template <int kDummy>
+__global__ __launch_bounds__(256) void k_poison_lds(unsigned pattern, int words, int mix, int* sink) {
+  extern __shared__ unsigned poison_smem[];
+  for (int i = threadIdx.x; i < words; i += 256) poison_smem[i] = mix ? (pattern ^ ((unsigned)i * 2654435761u)) : pattern;
+  __syncthreads();
+  if (sink && poison_smem[(threadIdx.x * 97 + blockIdx.x) % words] == 0x13572468u && mix == 7) sink[0] = 1;
+}
 // workgroup barrier that only waits for this wave's LDS traffic (not for its global loads / stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

@@ -314,6 +314,35 @@ def main():
                 "single_thread_value": round(float((o1st["status"] == 0).sum()) / cdt1, 2),
                 "single_thread_ms_per_ilqr_iter": round(1e3 * cdt1 / float(o1st["iterations_total"].sum()), 4),
             }
+        # ---- the same step with the problem handed over as HOST buffers (the C-ABI boundary of an MPC caller: a new
+        #      initial state and a warm start per instance go up, trajectories and statistics come back), PCIe and
+        #      the host-side layout conversion included.  Reported beside `value`, never as `value`. ----
+        host = None
+        if args.pipeline == 1:
+            solver.reset_trajectory()
+            X0, U0 = solver.get_trajectory()
+            x0 = np.ascontiguousarray(X0[:, 0, :])
+            hreps = max(1, min(args.steps, 3))
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            for _ in range(hreps):
+                solver.set_initial_state(x0)
+                solver.set_trajectory(None, U0)
+                if cfg["mode"] == "ilqr":
+                    solver.reset_stats()
+                    solver.solve_ilqr()
+                else:
+                    solver.solve()
+                Xs, Us = solver.get_trajectory()
+                hst = solver.get_stats()
+            hdt = (time.perf_counter() - h0) / hreps
+            host = {
+                "value": round(float((hst["status"] == 0).sum()) / hdt, 1), "unit": "trajectories/s",
+                "ms_per_step": round(1e3 * hdt, 3), "steps": hreps,
+                "bytes_up": int(x0.nbytes + U0.nbytes), "bytes_down": int(Xs.nbytes + Us.nbytes),
+                "note": "altro_set_initial_state + altro_set_trajectory from pageable host arrays, solve, "
+                        "altro_get_trajectory + altro_get_stats into host arrays",
+            }
         name, cus = solver.device_info()
         out = {
             "metric": "trajectories solved/sec (AL-iLQR to tol), unicycle 101 knots, batched" if args.config in (2, 3)
@@ -340,6 +369,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "host_boundary": host,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

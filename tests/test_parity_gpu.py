@@ -365,3 +365,26 @@ def test_horizon_lengths_and_ragged_batches(P, A, oracle_make, hip_make, no_fuse
         o, g = both(P, P.batch_three_obstacles, oracle_make, hip_make, batch=batch, N=N, dtype=A.F64)
         o.solve(); g.solve()
         _compare_full(o, g, xtol=(1e-6, 1e-8), gtol=1e-5)
+
+
+def test_setters_are_ordered_against_the_solver_stream(P, A, hip_make):
+    """The engine's stream does not synchronise with the null stream: a trajectory handed over with SetTrajectory must be
+    the one ResetTrajectory restores and the one the next solve starts from, however soon those calls follow (a
+    device-to-device copy left on the null stream used to race with them: a rare solve from a half-copied guess)."""
+    B, N = 4096, 100
+    s = P.batch_turn90(hip_make, batch=B, dtype=A.F64)
+    rng = np.random.default_rng(7)
+    for rep in range(12):
+        U = rng.uniform(-0.5, 0.5, size=(B, N, 2))
+        s.set_trajectory(None, U)
+        s.reset_trajectory()
+        _, Ug = s.get_trajectory()
+        assert np.array_equal(Ug, U)
+    # the first solve of a fresh solver, issued right behind the setters, equals a later solve from the same guess
+    s = P.batch_turn90(hip_make, batch=B, dtype=A.F64)
+    s.solve()
+    first = (s.get_trajectory()[0], s.get_stats()["iterations_total"].copy())
+    s.reset_trajectory()
+    s.solve()
+    assert np.array_equal(first[1], s.get_stats()["iterations_total"])
+    assert np.array_equal(first[0], s.get_trajectory()[0])
