@@ -541,6 +541,9 @@ class Engine final : public EngineBase {
     allocs_.clear();
     if (A_.hist) hipFree(A_.hist);
     if (A_.hist_len) hipFree(A_.hist_len);
+    if (d_stage_) hipFree(d_stage_);
+    d_stage_ = nullptr;
+    stage_cap_ = 0;
     if (d_counter_) hipFree(d_counter_);
     if (h_counter_) hipHostFree((void*)h_counter_);
     for (auto& e : prof_ev_) hipEventDestroy(e);
@@ -552,34 +555,42 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(CopySync(out, dev, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   }
-  // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]
+  // Staging buffer of the host boundary: the caller's row layout on the device (see k_rec_to_rows / k_rows_to_rec).
+  altro_status EnsureStage(size_t doubles) {
+    if (doubles <= stage_cap_) return ALTRO_OK;
+    if (d_stage_) ALTRO_HIP_CHECK(hipFree(d_stage_));
+    d_stage_ = nullptr;
+    stage_cap_ = 0;
+    ALTRO_HIP_CHECK(hipMalloc((void**)&d_stage_, doubles * sizeof(double)));
+    stage_cap_ = doubles;
+    return ALTRO_OK;
+  }
+  // device records [knots][Bp][EP] (fields at off..off+E) -> host [B][knots][E]: converted on the device, one contiguous
+  // copy straight into the caller's buffer
   template <class E_>
   altro_status DownloadRec(const E_* dev, int knots, int EP, int off, int E, double* out) {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    altro_status sst = Sync();  // the stream is non-blocking: order this null-stream copy after its work
+    const size_t count = (size_t)B_ * knots * E;
+    altro_status sst = EnsureStage(count);
     if (sst != ALTRO_OK) return sst;
-    std::vector<E_> h((size_t)knots * EP * Bp_);
-    ALTRO_HIP_CHECK(CopySync(h.data(), dev, h.size() * sizeof(E_), hipMemcpyDeviceToHost));
-    for (int k = 0; k < knots; ++k)
-      for (int b = 0; b < B_; ++b) {
-        const E_* src = &h[((size_t)k * Bp_ + b) * EP + off];
-        double* dst = out + ((size_t)b * knots + k) * E;
-        for (int e = 0; e < E; ++e) dst[e] = (double)src[e];
-      }
+    hipLaunchKernelGGL((k_rec_to_rows<E_>), dim3((B_ + kBlock - 1) / kBlock, knots), dim3(kBlock), 0, stream_, dev, d_stage_, knots,
+                       EP, off, E, B_, Bp_);
+    ALTRO_HIP_CHECK(hipGetLastError());
+    ALTRO_HIP_CHECK(CopySync(out, d_stage_, count * sizeof(double), hipMemcpyDeviceToHost));
     return ALTRO_OK;
   }
-  // host [B][knots][E] (or shared [knots][E]) -> device records [knots][Bp][EP] (padding zeroed)
+  // host [B][knots][E] (or shared [knots][E]; nullptr: zeros) -> device records [knots][Bp][EP] (padding zeroed)
   altro_status UploadRec(T* dev, int knots, int EP, int E, const double* src, bool per_instance) {
-    std::vector<T> h((size_t)knots * EP * Bp_, T(0));
-    if (src)
-      for (int k = 0; k < knots; ++k)
-        for (int b = 0; b < B_; ++b) {
-          const double* s0 = src + ((per_instance ? (size_t)b * knots : 0) + k) * E;
-          T* dst = &h[((size_t)k * Bp_ + b) * EP];
-          for (int e = 0; e < E; ++e) dst[e] = T(s0[e]);
-        }
-    ALTRO_HIP_CHECK(CopySync(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    return ALTRO_OK;
+    const size_t count = (size_t)(per_instance ? B_ : 1) * knots * E;
+    if (src) {
+      altro_status sst = EnsureStage(count);
+      if (sst != ALTRO_OK) return sst;
+      ALTRO_HIP_CHECK(hipMemcpyAsync(d_stage_, src, count * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    hipLaunchKernelGGL((k_rows_to_rec<T>), dim3(Bp_ / kBlock, knots), dim3(kBlock), 0, stream_, src ? (const double*)d_stage_ : nullptr,
+                       dev, knots, EP, E, B_, Bp_, per_instance ? 1 : 0);
+    ALTRO_HIP_CHECK(hipGetLastError());
+    return Sync();
   }
 
   altro_status SetInitialStateImpl(const ProblemSpec& s) {
@@ -1380,6 +1391,8 @@ class Engine final : public EngineBase {
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
   bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
+  double* d_stage_ = nullptr;
+  size_t stage_cap_ = 0;
   bool poison_on_ = false;
   unsigned poison_pattern_ = 0;
   int poison_mix_ = 0;

@@ -3319,6 +3319,29 @@ __global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts 
   }
 }
 
+// The two layout conversions of the host boundary, on the device so that the host only copies contiguous buffers:
+// device records [knots][Bp][EP] (fields off .. off+E) -> the caller's rows [B][knots][E] of doubles, and back
+// (padding elements and padding instances zeroed; `per_instance` = 0: one [knots][E] block shared by the batch).
+template <class E_>
+__global__ __launch_bounds__(kBlock) void k_rec_to_rows(const E_* __restrict__ dev, double* __restrict__ out, int knots, int EP,
+                                                        int off, int E, int B, int Bp) {
+  const int b = blockIdx.x * kBlock + threadIdx.x, k = blockIdx.y;
+  if (b >= B) return;
+  const E_* src = dev + ((size_t)k * Bp + b) * EP + off;
+  double* dst = out + ((size_t)b * knots + k) * E;
+  for (int e = 0; e < E; ++e) dst[e] = (double)src[e];
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_rows_to_rec(const double* __restrict__ src, T* __restrict__ dev, int knots, int EP,
+                                                        int E, int B, int Bp, int per_instance) {
+  const int b = blockIdx.x * kBlock + threadIdx.x, k = blockIdx.y;
+  if (b >= Bp) return;
+  T* dst = dev + ((size_t)k * Bp + b) * EP;
+  const bool live = src != nullptr && b < B;
+  const double* s0 = live ? src + ((per_instance ? (size_t)b * knots : 0) + k) * E : nullptr;
+  for (int e = 0; e < EP; ++e) dst[e] = (live && e < E) ? T(s0[e]) : T(0);
+}
+
 // gather {cost, violation, iterations_total, status} as 4 fp64 per instance (RCCL payload)
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_pack_results(DevArrays<T> A, double* dst, int ilqr_mode) {
