@@ -109,13 +109,17 @@ np.savez(sys.argv[1], **out)
 
 @pytest.mark.parametrize("switch", [{"ALTRO_HIP_NO_DENSE_EXPANSIONS": "1"}, {"ALTRO_HIP_FWD_SRC": "global"},
                                     {"ALTRO_HIP_FWD_SRC": "lds"}, {"ALTRO_HIP_FWD_PER_WAVE": "1"},
-                                    {"ALTRO_HIP_NO_SPECULATION": "1"}, {"ALTRO_HIP_SPECULATION": "helper"}],
+                                    {"ALTRO_HIP_NO_SPECULATION": "1"}, {"ALTRO_HIP_SPECULATION": "helper"},
+                                    {"ALTRO_HIP_PERSIST_AT": "600"}, {"ALTRO_HIP_DEBUG_POISON": "ffffffff"},
+                                    {"ALTRO_HIP_DEBUG_POISON": "12345678,mix"}],
                          ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
 def test_launch_variants_are_bit_identical(tmp_path, switch):
     """The batched sweeps have several launch variants chosen by measurements (dense / list-addressed expansions with
     the list rebuilt in neighbour order, rollout inputs staged in LDS or read from global memory, instances per
     workgroup, the persistent kernel with and without the speculative backward pass of its fourth wave): none of them may
-    change a bit of the result."""
+    change a bit of the result.  The same holds for the point where the persistent kernel takes over, and for the content
+    of the LDS and of the candidate buffer before each kernel (ALTRO_HIP_DEBUG_POISON: NaN words, mixed words): no kernel
+    may compute with memory the solve has not written."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(tag, env_extra):
