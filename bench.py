@@ -284,7 +284,7 @@ def main():
             })
         # ---- CPU baseline: the oracle (a port, see oracle/altro_oracle.cpp) on the host cores --------
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
             lib = ctypes.CDLL(lib_path)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -318,7 +318,7 @@ def main():
         #      initial state and a warm start per instance go up, trajectories and statistics come back), PCIe and
         #      the host-side layout conversion included.  Reported beside `value`, never as `value`. ----
         host = None
-        if args.pipeline == 1:
+        if args.pipeline == 1 and world == 1:
             solver.reset_trajectory()
             X0, U0 = solver.get_trajectory()
             x0 = np.ascontiguousarray(X0[:, 0, :])
