@@ -76,7 +76,9 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    // (the second stream only where it is used -- the helper workgroups of ALTRO_HIP_SPECULATION=helper: the streams of
+    //  a process share four hardware queues, and a persistent kernel blocks whatever queues up behind it)
+    if (spec_mode_ == kSpecHelper) ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     persist_at_ = num_cus_;

@@ -10,7 +10,7 @@ P = importlib.import_module("altro_cpp_amd.problems")
 hm = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
 which = sys.argv[1] if len(sys.argv) > 1 else "turn90"
 B = 4096
-for S in (1, 2, 3, 4, 1, 2, 3, 4):
+for S in (1, 2, 3, 4, 8, 1, 2, 3, 4, 8):
     os.environ["ALTRO_HIP_PERSIST_AT"] = str(256 // S)
     edges = [B * i // S for i in range(S + 1)]
     if which == "turn90":
