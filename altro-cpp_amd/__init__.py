@@ -73,7 +73,7 @@ assert STATS_DTYPE.itemsize == C.sizeof(Stats)
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("init_ms", C.c_double), ("expansions_ms", C.c_double),
                 ("backward_pass_ms", C.c_double), ("forward_pass_ms", C.c_double), ("fused_ms", C.c_double),
-                ("sweeps", C.c_int), ("fused_sweeps", C.c_int), ("launches", C.c_int),
+                ("sweeps", C.c_int), ("fused_sweeps", C.c_int), ("launches", C.c_int), ("sweep_launches", C.c_int),
                 ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong)]
 
 

@@ -207,6 +207,12 @@ struct DevArrays {
   int* hist_len;
   int hist_cap;
   int record_ctg;
+  // chains of sweeps (the engine runs the batched sweeps of a large batch as up to four independent chains, one stream
+  // each): the instance range of this launch's chain for the dense mode of k_expansions (chain_hi = 0: the whole
+  // batch), and for the persistent kernel the number of batched sweeps each chain ran before it (chain_size = 0: [0])
+  int chain_lo, chain_hi;
+  int chain_size;
+  int chain_base[4];
 };
 
 template <class T>

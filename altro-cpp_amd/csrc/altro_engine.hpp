@@ -9,6 +9,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -34,6 +35,12 @@ namespace altro_hip {
       return ALTRO_HIP_ERROR;                                                                  \
     }                                                                                          \
   } while (0)
+
+// engines of this process (all models and dtypes) that run their sweeps as chains on streams of their own
+inline std::atomic<int>& ChainedEngines() {
+  static std::atomic<int> n{0};
+  return n;
+}
 
 inline DevOpts ToDevOpts(const altro_options& o) {
   DevOpts d{};
@@ -80,6 +87,8 @@ class Engine final : public EngineBase {
     //  a process share four hardware queues, and a persistent kernel blocks whatever queues up behind it)
     if (spec_mode_ == kSpecHelper) ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
+    ALTRO_HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
+    cur_ = stream_;
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     persist_at_ = num_cus_;
     if (const char* e = std::getenv("ALTRO_HIP_DEBUG_POISON")) {
@@ -196,11 +205,13 @@ class Engine final : public EngineBase {
     return Sync();
   }
   altro_status BackwardPass(const altro_options& o) override {
+    cur_ = stream_;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     LaunchBackward(A_, ToDevOpts(o), 1, B_);
     return Sync();
   }
   altro_status ForwardPass(const altro_options& o) override {
+    cur_ = stream_;
     if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     LaunchForward(A_, ToDevOpts(o), (int)kFwdStepOnly, 1, B_);
@@ -440,7 +451,7 @@ class Engine final : public EngineBase {
   void PoisonLds() {
     if (!poison_on_) return;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_poison_lds<0>), dim3(num_cus_ * 8), dim3(256), 160 * 1024, stream_, poison_pattern_, 160 * 1024 / 4,
+    hipLaunchKernelGGL((k_poison_lds<0>), dim3(num_cus_ * 8), dim3(256), 160 * 1024, cur_, poison_pattern_, 160 * 1024 / 4,
                        poison_mix_, (int*)nullptr);
   }
   void LaunchBackward(const DevArrays<T>& A, const DevOpts& d, int all, int ninst) {
@@ -448,28 +459,28 @@ class Engine final : public EngineBase {
     if constexpr (kMfmaBackward) {
       if (!force_valu_backward_ && mfma_offsets_ok_) {
         if (A.record_ctg)
-          hipLaunchKernelGGL((k_backward_mfma<T, M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma<T, M, true>), dim3((ninst + 3) / 4), dim3(kBlock), 0, cur_, A, d, all);
         else
-          hipLaunchKernelGGL((k_backward_mfma<T, M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma<T, M, false>), dim3((ninst + 3) / 4), dim3(kBlock), 0, cur_, A, d, all);
         return;
       }
     }
     if constexpr (kMfma16Backward) {
       if (!force_valu_backward_ && !force_coop_backward_ && mfma_offsets_ok_) {
         if (A.record_ctg)
-          hipLaunchKernelGGL((k_backward_mfma16<T, M, true>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma16<T, M, true>), dim3(ninst), dim3(kBlock), 0, cur_, A, d, all);
         else
-          hipLaunchKernelGGL((k_backward_mfma16<T, M, false>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
+          hipLaunchKernelGGL((k_backward_mfma16<T, M, false>), dim3(ninst), dim3(kBlock), 0, cur_, A, d, all);
         return;
       }
     }
     if constexpr (kCoopBackward) {
       if (!force_valu_backward_) {
-        hipLaunchKernelGGL((k_backward_coop<T, M>), dim3(ninst), dim3(kBlock), 0, stream_, A, d, all);
+        hipLaunchKernelGGL((k_backward_coop<T, M>), dim3(ninst), dim3(kBlock), 0, cur_, A, d, all);
         return;
       }
     }
-    hipLaunchKernelGGL((k_backward<T, M>), dim3((ninst + kBlock - 1) / kBlock), dim3(kBlock), 0, stream_, A, d, all);
+    hipLaunchKernelGGL((k_backward<T, M>), dim3((ninst + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_, A, d, all);
   }
   // The fused sweep kernel needs the MFMA backward pass, the LDS-staged forward pass with one instance
   // per workgroup, no cost-to-go recording and at most 20 line-search trials.
@@ -480,25 +491,25 @@ class Engine final : public EngineBase {
   }
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
-  void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst) {
+  void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst, int ninst_all_chains = -1) {
     PoisonLds();
     if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
       // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
       // epilogue of the kernel (staging, winner copy) shrink with the instances per workgroup.
-      const int per_wave = (ninst <= num_cus_) ? 1 : fwd_per_wave_;
+      const int per_wave = (std::max(ninst, ninst_all_chains) <= num_cus_) ? 1 : fwd_per_wave_;
       const size_t lds = fwd_shared_bytes_ + (size_t)per_wave * fwd_per_inst_bytes_;
       const dim3 grid2((ninst + per_wave - 1) / per_wave);
       if (kdg_) {
         if constexpr (kKdgEligible)
-          hipLaunchKernelGGL((k_forward2<T, M, kSrcKdg>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+          hipLaunchKernelGGL((k_forward2<T, M, kSrcKdg>), grid2, dim3(kFwdWaves * kBlock), lds, cur_, A, d_pd_, pd_, d, mode,
                              all, per_wave);
       } else if (rg_) {
         if constexpr (kRgEligible)
-          hipLaunchKernelGGL((k_forward2<T, M, kSrcGlb>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+          hipLaunchKernelGGL((k_forward2<T, M, kSrcGlb>), grid2, dim3(kFwdWaves * kBlock), lds, cur_, A, d_pd_, pd_, d, mode,
                              all, per_wave);
       } else {
-        hipLaunchKernelGGL((k_forward2<T, M, kSrcLds>), grid2, dim3(kFwdWaves * kBlock), lds, stream_, A, d_pd_, pd_, d, mode,
+        hipLaunchKernelGGL((k_forward2<T, M, kSrcLds>), grid2, dim3(kFwdWaves * kBlock), lds, cur_, A, d_pd_, pd_, d, mode,
                            all, per_wave);
       }
       return;
@@ -506,7 +517,7 @@ class Engine final : public EngineBase {
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     {
       // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)
-      hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, stream_, A, d_pd_, d, mode, all, fwd_per_wave_);
+      hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, cur_, A, d_pd_, d, mode, all, fwd_per_wave_);
     }
   }
   bool StepOk() {
@@ -549,6 +560,15 @@ class Engine final : public EngineBase {
     if (d_counter_) hipFree(d_counter_);
     if (h_counter_) hipHostFree((void*)h_counter_);
     for (auto& e : prof_ev_) hipEventDestroy(e);
+    if (counted_chained_) ChainedEngines().fetch_sub(1);
+    counted_chained_ = false;
+    for (int c = 1; c < kMaxChains; ++c) {
+      if (chain_stream_[c]) hipStreamDestroy(chain_stream_[c]);
+      if (chain_ev_[c]) hipEventDestroy(chain_ev_[c]);
+      chain_stream_[c] = nullptr;
+      chain_ev_[c] = nullptr;
+    }
+    if (start_ev_) hipEventDestroy(start_ev_);
     if (stream2_) hipStreamDestroy(stream2_);
     if (spec_ev_) hipEventDestroy(spec_ev_);
     if (stream_) hipStreamDestroy(stream_);
@@ -973,6 +993,33 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(d_tmp_, bp);
     ALTRO_ALLOC(d_list_[0], bp);
     ALTRO_ALLOC(d_list_[1], bp);
+    {
+      // chains of batched sweeps: four for a batch that fills the GPU several times over (measured on 4096 instances:
+      // config 2 -5 %, config 3 -14 %; a quarter of a 1024-instance batch no longer fills the CUs)
+      chains_ = B_ >= 2048 ? kMaxChains : 1;
+      // (the streams of a process share four hardware queues: a second engine with chains of its own would queue up
+      //  behind this one's persistent kernel -- only the first large engine of a process gets them)
+      if (chains_ > 1 && ChainedEngines().load() > 0) chains_ = 1;
+      if (const char* e = std::getenv("ALTRO_HIP_CHAINS")) chains_ = std::max(1, std::min(kMaxChains, atoi(e)));
+      for (;;) {
+        chain_size_ = ((B_ + chains_ - 1) / chains_ + kBlock - 1) / kBlock * kBlock;
+        if (chains_ == 1 || chain_size_ * (chains_ - 1) < B_) break;
+        chains_--;  // (the last chain would be empty)
+      }
+      if (chains_ > 1) {
+        ChainedEngines().fetch_add(1);
+        counted_chained_ = true;
+        ALTRO_ALLOC(d_iota_, bp);
+        ALTRO_ALLOC(d_merged_, bp);
+        std::vector<int> iota(bp);
+        for (int i = 0; i < bp; ++i) iota[i] = i;
+        ALTRO_HIP_CHECK(CopySync(d_iota_, iota.data(), (size_t)bp * sizeof(int), hipMemcpyHostToDevice));
+        for (int c = 1; c < chains_; ++c) {
+          ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&chain_stream_[c], hipStreamNonBlocking));
+          ALTRO_HIP_CHECK(hipEventCreateWithFlags(&chain_ev_[c], hipEventDisableTiming));
+        }
+      }
+    }
     if constexpr (kMfmaBackward) {
       if (spec_mode_ == kSpecHelper) {  // hand-over buffers of the helper workgroups (SpecRemote)
         ALTRO_ALLOC(d_spec_go_, 2 * (size_t)bp);
@@ -1150,6 +1197,23 @@ class Engine final : public EngineBase {
     return prof_ev_[i];
   }
 
+  // One chain of batched sweeps: the instances [lo, hi) of the batch, swept on a stream of their own.  A large batch runs
+  // as up to four chains (chains_): the three kernels of a sweep follow each other on one stream -- a latency-bound
+  // backward launch, as long as its unluckiest instance, between two throughput-bound ones, and a forward launch whose
+  // last round of workgroups leaves most CUs idle -- and chains that drift out of phase fill each other's gaps.  The
+  // persistent tail kernel takes the lists all chains leave behind in ONE launch.
+  struct Chain {
+    int lo = 0, hi = 0;
+    hipStream_t st = nullptr;
+    int* d_cnt = nullptr;            // this chain's block of device counters (one per sweep; cursors of the list rebuilds)
+    volatile int* h_cnt = nullptr;   // ... of host-mapped words (the counts the sweeps publish)
+    int* h_cnt_dev = nullptr;
+    int sweeps = 0;                  // sweeps enqueued
+    int known = 0;                   // newest count the host knows (an upper bound of what the next sweep works on)
+    bool waiting = false, done = false, tail = false;
+    std::vector<size_t> ev;          // profiler events: chain start, then three per sweep
+  };
+
   altro_status Solve(const altro_options& o, int mode) {
     if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
@@ -1160,6 +1224,7 @@ class Engine final : public EngineBase {
     last_mode_ilqr_ = (mode == kFwdILQR);
     std::memset(&timing_, 0, sizeof(timing_));
     size_t nev = 0;
+    cur_ = stream_;
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
     hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, d, 1);
@@ -1174,124 +1239,154 @@ class Engine final : public EngineBase {
                                   (long long)std::max(1, (mode == kFwdAL) ? o.max_iterations_outer : 1);
     const int max_sweeps =
         (int)std::max<long long>(1, std::min<long long>({(long long)o.max_iterations_total, inner_outer, 1LL << 20})) + 2;
-    int sweeps = 0;
-    bool finished = false;
-    // Sweep i works on the instances that sweep i-1 left active: a dense list built by the forward
+    // Sweep i of a chain works on the instances that its sweep i-1 left active: a dense list built by the forward
     // kernel (two list buffers, one counter per sweep).  Sweep i+1's first kernel publishes the
     // length of its list (= what sweep i left) to pinned host memory; the host polls that word,
     // stays one sweep ahead of the device, and sizes each grid with the newest count it knows --
     // counts only shrink, so it is an upper bound -- so tail sweeps launch a handful of workgroups.
+    const int C = chains_;
+    const int cstride = 2 * (max_sweeps + 8);  // per chain: counts [0, max_sweeps + 2), results of the persistent kernel
+                                               // [max_sweeps + 2, + 3), cursors of the list rebuilds (dense sweeps) in the second half
     {
-      altro_status rs = ReserveCounters(2 * (max_sweeps + 4));  // second half: cursors of the list rebuilds (dense sweeps)
+      altro_status rs = ReserveCounters(C * cstride + 16);
       if (rs != ALTRO_OK) return rs;
     }
-    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(2 * (max_sweeps + 4)) * sizeof(int), stream_));
-    for (int i = 0; i < max_sweeps + 2; ++i) h_counter_[i] = -1;
-    int known_count = B_;
-    std::vector<char> fused_flag;
-    bool persistent_launched = false;
+    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+    Chain chain[kMaxChains];
+    for (int c = 0; c < C; ++c) {
+      Chain& ch = chain[c];
+      ch.lo = C > 1 ? std::min(B_, c * chain_size_) : 0;
+      ch.hi = C > 1 ? std::min(B_, (c + 1) * chain_size_) : B_;
+      ch.st = c == 0 ? stream_ : chain_stream_[c];
+      ch.d_cnt = d_counter_ + (size_t)c * cstride;
+      ch.h_cnt = h_counter_ + (size_t)c * cstride;
+      ch.h_cnt_dev = h_counter_dev_ + (size_t)c * cstride;
+      ch.known = ch.hi - ch.lo;
+      for (int i = 0; i < max_sweeps + 2; ++i) ch.h_cnt[i] = -1;
+    }
+    if (C > 1) {
+      // the other chains start behind the initialisation (and the counter reset) on the engine's stream
+      hipEventRecord(start_ev_, stream_);
+      for (int c = 1; c < C; ++c) hipStreamWaitEvent(chain[c].st, start_ev_, 0);
+    }
+    for (int c = 0; c < C; ++c) {
+      if (!prof) break;
+      if (c == 0) {
+        chain[c].ev.push_back(nev - 1);
+      } else {
+        hipEventRecord(ProfEvent(nev), chain[c].st);
+        chain[c].ev.push_back(nev++);
+      }
+    }
     const bool fused_ok = FusedOk(d);
-    auto enqueue_sweep = [&](int i) -> altro_status {
+    bool tail_mode = false;  // the persistent kernel takes over: every chain stops at its next sweep boundary
+    auto total_known = [&]() {
+      long long t = 0;
+      for (int c = 0; c < C; ++c) t += chain[c].done ? 0 : chain[c].known;
+      return (int)std::min<long long>(t, B_);
+    };
+    auto rec = [&](Chain& ch) {
+      if (!prof) return;
+      hipEventRecord(ProfEvent(nev), ch.st);
+      ch.ev.push_back(nev++);
+    };
+    // lists of a chain: its own slice [lo, ...) of the two list buffers (a chain never holds more than hi - lo instances)
+    auto enqueue_sweep = [&](Chain& ch, int i) -> altro_status {
       DevArrays<T> A = A_;
+      A.chain_lo = ch.lo;
+      A.chain_hi = C > 1 ? ch.hi : 0;
       if (i == 0) {
-        A.act_list = nullptr;
+        A.act_list = C > 1 ? d_iota_ + ch.lo : nullptr;
         A.act_count = nullptr;
-        A.act_count_const = B_;
+        A.act_count_const = ch.hi - ch.lo;
         A.host_count = nullptr;
       } else {
-        A.act_list = d_list_[i % 2];
-        A.act_count = d_counter_ + (i - 1);
-        A.host_count = h_counter_dev_ + (i - 1);
+        A.act_list = d_list_[i % 2] + ch.lo;
+        A.act_count = ch.d_cnt + (i - 1);
+        A.host_count = ch.h_cnt_dev + (i - 1);
       }
-      A.next_list = d_list_[(i + 1) % 2];
-      A.next_count = d_counter_ + i;
-      const int ninst = std::max(1, known_count);
-      if (fused_ok && i > 0 && ninst <= persist_at_) {
-        PoisonLds();
-        // the tail: every instance gets a workgroup that runs the whole iteration (k_sweep_fused)
-        if (prof) {
-          hipEventRecord(ProfEvent(nev++), stream_);
-          hipEventRecord(ProfEvent(nev++), stream_);
-        }
-        if constexpr (kMfmaBackward) {
-          A.next_list = nullptr;  // nobody comes after this launch
-          A.next_count = nullptr;
-          // (the variant without the circle layouts for problems that have no circle constraint: see forward2_body)
-          bool circles = false;
-          for (int r = 0; r < pd_.nruns; ++r)
-            circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
-          // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
-          int* const out = d_counter_ + max_sweeps + 2;
-          const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
-          SpecRemote<T> rs{};
-          if (spec_mode_ == kSpecHelper) {
-            // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
-            rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
-            hipMemsetAsync(d_spec_go_, 0, 2 * (size_t)Bp_ * sizeof(int), stream_);
-            hipEventRecord(spec_ev_, stream_);
-            hipStreamWaitEvent(stream2_, spec_ev_, 0);
-            const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
-            hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, stream2_, A, d, rs);
-            spec_helper_running_ = true;
-          }
-#define ALTRO_FUSED(C, S, BLK) \
-  hipLaunchKernelGGL((k_sweep_fused<T, M, C, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs)
-          if (circles) {
-            if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
-            else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
-            else ALTRO_FUSED(true, kSpecOff, b3);
-          } else {
-            if (spec_mode_ == kSpecHelper) ALTRO_FUSED(false, kSpecHelper, b3);
-            else if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
-            else ALTRO_FUSED(false, kSpecOff, b3);
-          }
-#undef ALTRO_FUSED
-        }
-        if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-        persistent_launched = true;
-        fused_flag.push_back(1);
-        timing_.launches += 1;
+      A.next_list = d_list_[(i + 1) % 2] + ch.lo;
+      A.next_count = ch.d_cnt + i;
+      const int ninst = std::max(1, ch.known);
+      if (fused_ok && i > 0 && (tail_mode || total_known() <= persist_at_)) {
+        // the tail: every instance left gets a workgroup that runs whole iterations (k_sweep_fused, launched below
+        // for all chains together); this chain's list is the one sweep i would have worked on
+        tail_mode = true;
+        ch.tail = true;
         return ALTRO_OK;
       }
-      fused_flag.push_back(0);
+      cur_ = ch.st;
+      const int span = ch.hi - ch.lo;
       const dim3 gridB((ninst + kBlock - 1) / kBlock);
       PoisonLds();
       // (small models only: their expansions are HBM-bound; the 12-state model's are compute-bound and pay for the idle
       //  lanes of a dense launch: config 4 +13 %)
-      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= B_) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
-        // a good part of the batch is still iterating: lane = instance (coalesced rows and records), and the list is
+      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= span) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
+        // a good part of the chain is still iterating: lane = instance (coalesced rows and records), and the list is
         // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions)
-        hipLaunchKernelGGL((k_expansions<T, M>), dim3((B_ + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 2,
-                           d_list_[i % 2], d_counter_ + (max_sweeps + 4) + i);
+        hipLaunchKernelGGL((k_expansions<T, M>), dim3((span + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 2,
+                           d_list_[i % 2] + ch.lo, ch.d_cnt + (max_sweeps + 8) + i);
       } else {
-        hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, stream_, A, d_pd_, 0, (int*)nullptr,
+        hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 0, (int*)nullptr,
                            (int*)nullptr);
       }
-      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+      rec(ch);
       LaunchBackward(A, d, 0, ninst);
-      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-      LaunchForward(A, d, mode, 0, ninst);
-      if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+      rec(ch);
+      LaunchForward(A, d, mode, 0, ninst, total_known());
+      rec(ch);
+      cur_ = stream_;
       timing_.launches += 3;
+      timing_.sweep_launches += 1;
       return ALTRO_OK;
     };
-    // count left by sweep j, published by sweep j+1 (which must already be enqueued)
-    auto wait_count = [&](int j, int* out) -> altro_status {
-      unsigned spins = 0;
-      for (;;) {
-        const int v = __atomic_load_n(&h_counter_[j], __ATOMIC_ACQUIRE);
-        if (v >= 0) {
-          *out = v;
-          return ALTRO_OK;
+    for (int c = 0; c < C; ++c) {
+      altro_status st = enqueue_sweep(chain[c], 0);
+      if (st != ALTRO_OK) return st;
+      chain[c].sweeps = 1;
+    }
+    // Every chain: enqueue sweep s, then wait for the count sweep s-1 left (published by sweep s, which is already
+    // enqueued), then enqueue sweep s+1 ... -- the chains polled in turn, none of them ever blocking the others.
+    unsigned spins = 0;
+    for (;;) {
+      bool any = false, progressed = false;
+      for (int c = 0; c < C; ++c) {
+        Chain& ch = chain[c];
+        if (ch.done || ch.tail) continue;
+        any = true;
+        if (ch.waiting) {
+          const int v = __atomic_load_n(&ch.h_cnt[ch.sweeps - 2], __ATOMIC_ACQUIRE);
+          if (v < 0) continue;
+          ch.known = v;
+          ch.waiting = false;
+          progressed = true;
+          if (v == 0) {
+            ch.done = true;
+            continue;
+          }
         }
-        if ((++spins & 0x3ff) == 0) {
-          const hipError_t q = hipStreamQuery(stream_);
+        if (ch.sweeps >= max_sweeps) {  // the iteration caps bound the sweeps; nothing left to learn
+          ch.done = true;
+          progressed = true;
+          continue;
+        }
+        altro_status st = enqueue_sweep(ch, ch.sweeps);  // publishes the count left by sweep (sweeps - 1)
+        if (st != ALTRO_OK) return st;
+        progressed = true;
+        if (ch.tail) continue;  // (not enqueued: the persistent kernel comes instead)
+        ch.sweeps++;
+        ch.waiting = true;
+      }
+      if (!any) break;
+      if (progressed) {
+        spins = 0;
+      } else if ((++spins & 0x3ff) == 0) {
+        for (int c = 0; c < C; ++c) {
+          Chain& ch = chain[c];
+          if (ch.done || ch.tail || !ch.waiting) continue;
+          const hipError_t q = hipStreamQuery(ch.st);
           if (q == hipSuccess) {  // stream drained: the word must be there, or the launch failed
-            const int v2 = __atomic_load_n(&h_counter_[j], __ATOMIC_ACQUIRE);
-            if (v2 >= 0) {
-              *out = v2;
-              return ALTRO_OK;
-            }
+            if (__atomic_load_n(&ch.h_cnt[ch.sweeps - 2], __ATOMIC_ACQUIRE) >= 0) continue;
             ALTRO_HIP_CHECK(hipGetLastError());
             err_ = "sweep counter was never published";
             return ALTRO_HIP_ERROR;
@@ -1299,53 +1394,117 @@ class Engine final : public EngineBase {
           if (q != hipErrorNotReady) ALTRO_HIP_CHECK(q);
         }
       }
-    };
-    altro_status st = enqueue_sweep(0);
-    if (st != ALTRO_OK) return st;
-    sweeps = 1;
-    while (!finished) {
-      if (sweeps >= max_sweeps) {  // the iteration caps bound the sweeps; nothing left to learn
-        finished = true;
-        break;
-      }
-      st = enqueue_sweep(sweeps);  // publishes the count left by sweep (sweeps - 1)
-      if (st != ALTRO_OK) return st;
-      sweeps++;
-      if (persistent_launched) break;  // that launch iterates every remaining instance to the end
-      st = wait_count(sweeps - 2, &known_count);
-      if (st != ALTRO_OK) return st;
-      if (known_count == 0) finished = true;
     }
+    bool persistent_launched = false;
+    size_t fused_ev = 0;
+    if (tail_mode) {
+      if constexpr (kMfmaBackward) {
+        DevArrays<T> A = A_;
+        ChainLists lists{};
+        long long ninst_l = 0;
+        A.chain_size = C > 1 ? chain_size_ : 0;
+        for (int c = 0; c < C; ++c) {
+          Chain& ch = chain[c];
+          A.chain_base[c] = ch.sweeps;  // batched sweeps this chain ran (0 .. sweeps-1)
+          if (!ch.tail) continue;
+          lists.list[lists.n] = d_list_[ch.sweeps % 2] + ch.lo;
+          lists.count[lists.n] = ch.d_cnt + (ch.sweeps - 1);
+          lists.n++;
+          ninst_l += std::max(1, ch.known);
+          if (ch.st != stream_) {  // the engine's stream continues behind this chain's last sweep
+            hipEventRecord(chain_ev_[c], ch.st);
+            hipStreamWaitEvent(stream_, chain_ev_[c], 0);
+          }
+        }
+        const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), B_);
+        if (lists.n == 1) {
+          A.act_list = lists.list[0];
+          A.act_count = lists.count[0];
+        } else {
+          int* const merged_count = d_counter_ + (size_t)C * cstride;
+          hipLaunchKernelGGL((k_merge_lists<0>), dim3(1), dim3(256), 0, stream_, lists, d_merged_, merged_count);
+          A.act_list = d_merged_;
+          A.act_count = merged_count;
+          timing_.launches += 1;
+        }
+        A.host_count = nullptr;
+        A.next_list = nullptr;  // nobody comes after this launch
+        A.next_count = nullptr;
+        PoisonLds();
+        if (prof) {
+          fused_ev = nev;
+          hipEventRecord(ProfEvent(nev++), stream_);
+        }
+        // (the variant without the circle layouts for problems that have no circle constraint: see forward2_body)
+        bool circles = false;
+        for (int r = 0; r < pd_.nruns; ++r)
+          circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
+        // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
+        int* const out = d_counter_ + max_sweeps + 2;
+        const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
+        SpecRemote<T> rs{};
+        if (spec_mode_ == kSpecHelper) {
+          // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
+          rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
+          hipMemsetAsync(d_spec_go_, 0, 2 * (size_t)Bp_ * sizeof(int), stream_);
+          hipEventRecord(spec_ev_, stream_);
+          hipStreamWaitEvent(stream2_, spec_ev_, 0);
+          const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
+          hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, stream2_, A, d, rs);
+          spec_helper_running_ = true;
+        }
+#define ALTRO_FUSED(CC, S, BLK) \
+  hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs)
+        if (circles) {
+          if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
+          else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
+          else ALTRO_FUSED(true, kSpecOff, b3);
+        } else {
+          if (spec_mode_ == kSpecHelper) ALTRO_FUSED(false, kSpecHelper, b3);
+          else if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
+          else ALTRO_FUSED(false, kSpecOff, b3);
+        }
+#undef ALTRO_FUSED
+        if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+        persistent_launched = true;
+        timing_.launches += 1;
+      }
+    }
+    for (int c = 1; c < C; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(chain[c].st));
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     if (spec_helper_running_) {
       ALTRO_HIP_CHECK(hipStreamSynchronize(stream2_));
       spec_helper_running_ = false;
     }
     ALTRO_HIP_CHECK(hipGetLastError());
-    const int launched_sweeps = sweeps;  // sweeps with their own launch (and profiler events)
+    int sweeps = 0;  // longest chain of iterations, the look-ahead sweep of a chain that ran dry included
+    for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
-      int extra[2] = {0, 0};
+      int extra[3] = {0, 0, 0};
       ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
       timing_.fused_sweeps = extra[0];
       timing_.fused_instance_iterations = extra[1];
-      sweeps += extra[0] - 1;
+      sweeps = std::max(sweeps, extra[2]);
     }
     timing_.sweeps = sweeps;
     if (prof) {
       float ms = 0;
       hipEventElapsedTime(&ms, prof_ev_[0], prof_ev_[1]);
       timing_.init_ms = ms;
-      for (int i = 0; i < launched_sweeps; ++i) {
-        const size_t e0 = 1 + (size_t)i * 3;
-        hipEventElapsedTime(&ms, prof_ev_[e0], prof_ev_[e0 + 1]);
-        timing_.expansions_ms += ms;
-        hipEventElapsedTime(&ms, prof_ev_[e0 + 1], prof_ev_[e0 + 2]);
-        timing_.backward_pass_ms += ms;
-        hipEventElapsedTime(&ms, prof_ev_[e0 + 2], prof_ev_[e0 + 3]);
-        if (fused_flag[i])
-          timing_.fused_ms += ms;
-        else
+      for (int c = 0; c < C; ++c) {
+        const std::vector<size_t>& ev = chain[c].ev;
+        for (size_t e0 = 0; e0 + 3 < ev.size(); e0 += 3) {
+          hipEventElapsedTime(&ms, prof_ev_[ev[e0]], prof_ev_[ev[e0 + 1]]);
+          timing_.expansions_ms += ms;
+          hipEventElapsedTime(&ms, prof_ev_[ev[e0 + 1]], prof_ev_[ev[e0 + 2]]);
+          timing_.backward_pass_ms += ms;
+          hipEventElapsedTime(&ms, prof_ev_[ev[e0 + 2]], prof_ev_[ev[e0 + 3]]);
           timing_.forward_pass_ms += ms;
+        }
+      }
+      if (persistent_launched) {
+        hipEventElapsedTime(&ms, prof_ev_[fused_ev], prof_ev_[fused_ev + 1]);
+        timing_.fused_ms += ms;
       }
     }
     timing_.instance_iterations = -1;  // summed on demand (GetTiming): keeps a copy out of every solve
@@ -1395,6 +1554,16 @@ class Engine final : public EngineBase {
   bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
   double* d_stage_ = nullptr;
   size_t stage_cap_ = 0;
+  static constexpr int kMaxChains = 4;
+  bool counted_chained_ = false;
+  int chains_ = 1;      // chains of batched sweeps (see Chain); ALTRO_HIP_CHAINS overrides
+  int chain_size_ = 0;  // instances per chain (a multiple of the wavefront size)
+  hipStream_t chain_stream_[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t chain_ev_[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t start_ev_ = nullptr;
+  int* d_iota_ = nullptr;    // 0, 1, 2, ...: the active list of a chain's first sweep
+  int* d_merged_ = nullptr;  // the lists of all chains, concatenated for the persistent kernel
+  hipStream_t cur_ = nullptr;  // the stream the launch helpers enqueue on (a chain's, otherwise the engine's)
   bool poison_on_ = false;
   unsigned poison_pattern_ = 0;
   int poison_mix_ = 0;

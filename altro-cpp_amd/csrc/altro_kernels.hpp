@@ -62,7 +62,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // instance that is still iterating (phase == 1), addressed by its own index (k_expansions' dense mode).
 template <class T>
 ALTRO_DEV int instance_of_slot(const DevArrays<T>& A, int idx, int all) {
-  if (all == 2) return (idx < A.B && A.phase[idx] == 1) ? idx : -1;
+  if (all == 2) {
+    const int b = idx + A.chain_lo, hi = A.chain_hi ? A.chain_hi : A.B;
+    return (b < hi && A.phase[b] == 1) ? b : -1;
+  }
   if (all) return idx < A.B ? idx : -1;
   const int cnt = A.act_count ? *A.act_count : A.act_count_const;
   if (idx >= cnt) return -1;
@@ -3266,8 +3269,10 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
   }
   if (SPEC == kSpecHelper && tid == 0) __hip_atomic_store(rs.go + b, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (sweeps_out && tid == 0) {
-    atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations
+    atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations of this launch
     atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
+    const int chain = A.chain_size ? (b / A.chain_size < 3 ? b / A.chain_size : 3) : 0;
+    atomicMax(sweeps_out + 2, A.chain_base[chain] + loops + skipped);  // ... counted from the first sweep of the solve
   }
 }
 
@@ -3317,6 +3322,23 @@ __global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts 
     __threadfence();
     if (lane == 0) __hip_atomic_store(rs.done + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// Concatenates the active lists the chains of batched sweeps leave behind into the list of the persistent kernel.
+struct ChainLists {
+  const int* list[4];
+  const int* count[4];
+  int n;
+};
+template <int kDummy>
+__global__ __launch_bounds__(256) void k_merge_lists(ChainLists in, int* __restrict__ out_list, int* __restrict__ out_count) {
+  int off = 0;
+  for (int q = 0; q < in.n; ++q) {
+    const int c = *in.count[q];
+    for (int i = threadIdx.x; i < c; i += 256) out_list[off + i] = in.list[q][i];
+    off += c;
+  }
+  if (threadIdx.x == 0) *out_count = off;
 }
 
 // The two layout conversions of the host boundary, on the device so that the host only copies contiguous buffers:

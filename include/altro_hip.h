@@ -160,6 +160,7 @@ typedef struct altro_timing {
   int sweeps;              /* batched iLQR sweeps = longest chain of iterations             */
   int fused_sweeps;        /* how many of them ran inside the persistent launch             */
   int launches;            /* number of kernel launches                                     */
+  int sweep_launches;      /* batched sweeps launched (all chains of sweeps together)       */
   long long instance_iterations; /* sum over instances of iterations_total                  */
   long long fused_instance_iterations; /* (instance, iteration) units run by the fused launch */
 } altro_timing;

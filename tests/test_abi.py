@@ -49,10 +49,11 @@ def test_struct_layouts_match_the_header(A):
     assert [f for f, _ in A.Options._fields_][:5] == ["max_iterations_total", "max_iterations_outer",
                                                       "max_iterations_inner", "cost_tolerance", "gradient_tolerance"]
     assert ctypes.sizeof(A.Options) % 8 == 0
-    # altro_timing: 6 doubles, 3 ints (+ padding), 2 long longs
-    assert ctypes.sizeof(A.Timing) == 6 * 8 + 3 * 4 + 4 + 2 * 8
+    # altro_timing: 6 doubles, 4 ints, 2 long longs
+    assert ctypes.sizeof(A.Timing) == 6 * 8 + 4 * 4 + 2 * 8
     assert [f for f, _ in A.Timing._fields_] == ["total_ms", "init_ms", "expansions_ms", "backward_pass_ms", "forward_pass_ms",
-                                                "fused_ms", "sweeps", "fused_sweeps", "launches", "instance_iterations",
+                                                "fused_ms", "sweeps", "fused_sweeps", "launches", "sweep_launches",
+                                                "instance_iterations",
                                                 "fused_instance_iterations"]
 
 
