@@ -409,8 +409,9 @@ class Engine final : public EngineBase {
     const int cnt = std::min(std::min(len, A_.hist_cap), cap);
     if (cnt <= 0) return 0;
     // column `instance` of the [field][row][Bp] block: one strided copy
-    if (hipMemcpy2D(out, sizeof(double), A_.hist + (size_t)field * A_.hist_cap * Bp_ + instance, (size_t)Bp_ * sizeof(double),
-                    sizeof(double), (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy2DAsync(out, sizeof(double), A_.hist + (size_t)field * A_.hist_cap * Bp_ + instance, (size_t)Bp_ * sizeof(double),
+                         sizeof(double), (size_t)cnt, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess)
       return -1;
     return cnt;
   }
