@@ -388,3 +388,24 @@ def test_setters_are_ordered_against_the_solver_stream(P, A, hip_make):
     s.solve()
     assert np.array_equal(first[1], s.get_stats()["iterations_total"])
     assert np.array_equal(first[0], s.get_trajectory()[0])
+
+
+@pytest.mark.parametrize("opts", [dict(max_iterations_total=7), dict(max_iterations_inner=4, max_iterations_outer=3), dict()],
+                         ids=["total-cap", "inner-outer-caps", "defaults"])
+def test_chains_of_sweeps_against_oracle(P, A, oracle_make, hip_make, opts, monkeypatch):
+    """A batch of >= 2048 instances is swept as four chains on streams of their own, with one joint persistent launch
+    (Engine::Chain): ragged chains (2304 + 37 instances: 640, 640, 640, 421), chains that run into the iteration caps
+    before the persistent kernel takes over (the caps bound the sweeps of every chain), and the default schedule."""
+    B = 2341
+    monkeypatch.setenv("ALTRO_HIP_CHAINS", "4")  # (the default of the first large engine of a process: forced, other tests' handles may be alive)
+    o, g = both(P, P.batch_turn90, oracle_make, hip_make, batch=B)
+    for s in (o, g):
+        s.set_options(**opts)
+    o.solve(); g.solve()
+    so, sg = _compare_full(o, g)
+    if "max_iterations_total" in opts:
+        assert so["iterations_total"].max() <= 7 and (so["status"] != 0).any()
+    # a second solve from the same guess through the same handle (the chains' counters, lists and events are reused)
+    g.reset_trajectory(); g.solve()
+    assert np.array_equal(g.get_stats()["iterations_total"], sg["iterations_total"])
+    assert np.array_equal(g.get_stats()["status"], sg["status"])
