@@ -83,9 +83,6 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    // (the second stream only where it is used -- the helper workgroups of ALTRO_HIP_SPECULATION=helper: the streams of
-    //  a process share four hardware queues, and a persistent kernel blocks whatever queues up behind it)
-    if (spec_mode_ == kSpecHelper) ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
     cur_ = stream_;
@@ -1020,6 +1017,11 @@ class Engine final : public EngineBase {
           ALTRO_HIP_CHECK(hipEventCreateWithFlags(&chain_ev_[c], hipEventDisableTiming));
         }
       }
+      // (a stream for the helper workgroups of ALTRO_HIP_SPECULATION=helper only where no chain stream is there to carry
+      //  them -- the chains are idle during the tail: the streams of a process share four hardware queues, and a
+      //  persistent kernel blocks whatever queues up behind it)
+      if (spec_mode_ == kSpecHelper && chains_ == 1 && !stream2_)
+        ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     }
     if constexpr (kMfmaBackward) {
       if (spec_mode_ == kSpecHelper) {  // hand-over buffers of the helper workgroups (SpecRemote)
@@ -1449,9 +1451,9 @@ class Engine final : public EngineBase {
           rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
           hipMemsetAsync(d_spec_go_, 0, 2 * (size_t)Bp_ * sizeof(int), stream_);
           hipEventRecord(spec_ev_, stream_);
-          hipStreamWaitEvent(stream2_, spec_ev_, 0);
+          hipStreamWaitEvent(HelperStream(), spec_ev_, 0);
           const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
-          hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, stream2_, A, d, rs);
+          hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, HelperStream(), A, d, rs);
           spec_helper_running_ = true;
         }
 #define ALTRO_FUSED(CC, S, BLK) \
@@ -1474,7 +1476,7 @@ class Engine final : public EngineBase {
     for (int c = 1; c < C; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(chain[c].st));
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     if (spec_helper_running_) {
-      ALTRO_HIP_CHECK(hipStreamSynchronize(stream2_));
+      ALTRO_HIP_CHECK(hipStreamSynchronize(HelperStream()));
       spec_helper_running_ = false;
     }
     ALTRO_HIP_CHECK(hipGetLastError());
@@ -1542,6 +1544,7 @@ class Engine final : public EngineBase {
     return (int)kSpecWave;
   }();
   hipStream_t stream2_ = nullptr;
+  hipStream_t HelperStream() const { return chains_ > 1 ? chain_stream_[1] : stream2_; }
   hipEvent_t spec_ev_ = nullptr;
   bool spec_helper_running_ = false;
   int* d_spec_go_ = nullptr;      // [2][Bp]: request tags, delivered tags
