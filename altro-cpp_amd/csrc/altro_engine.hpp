@@ -1017,6 +1017,34 @@ class Engine final : public EngineBase {
           ALTRO_HIP_CHECK(hipEventCreateWithFlags(&chain_ev_[c], hipEventDisableTiming));
         }
       }
+      if (chains_ > 1 && !std::getenv("ALTRO_HIP_CHAINS")) {
+        // Do the chains' streams run side by side?  The streams of a process share a few hardware queues (four unless
+        // GPU_MAX_HW_QUEUES says otherwise), handed out in order of creation: with other streams around (another
+        // handle, a framework's stream pool, RCCL) two chains can land on one queue and take turns -- slower than one
+        // chain.  One wavefront spinning for 200 us on every chain stream: side by side they take 200 us together.
+        const long long ticks = 20000;  // of the 100 MHz constant clock
+        ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
+        double best = 1e30;
+        for (int rep = 0; rep < 2; ++rep) {  // (the first round also loads the kernel)
+          const auto c0 = std::chrono::steady_clock::now();
+          for (int c = 0; c < chains_; ++c)
+            hipLaunchKernelGGL((k_spin<0>), dim3(1), dim3(kBlock), 0, c == 0 ? stream_ : chain_stream_[c], ticks, (int*)nullptr);
+          for (int c = 0; c < chains_; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(c == 0 ? stream_ : chain_stream_[c]));
+          best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count());
+        }
+        if (best > 1.6 * 200.0) {  // two of them ran one after the other
+          for (int c = 1; c < chains_; ++c) {
+            hipStreamDestroy(chain_stream_[c]);
+            hipEventDestroy(chain_ev_[c]);
+            chain_stream_[c] = nullptr;
+            chain_ev_[c] = nullptr;
+          }
+          chains_ = 1;
+          chain_size_ = Bp_;
+          ChainedEngines().fetch_sub(1);
+          counted_chained_ = false;
+        }
+      }
       // (a stream for the helper workgroups of ALTRO_HIP_SPECULATION=helper only where no chain stream is there to carry
       //  them -- the chains are idle during the tail: the streams of a process share four hardware queues, and a
       //  persistent kernel blocks whatever queues up behind it)

@@ -31,6 +31,10 @@ import os
 import sys
 import time
 
+# The solver runs the batched sweeps of a large batch on four streams of its own; the HIP runtime maps the streams of a
+# process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in order of creation.  Room for the framework's own streams:
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
@@ -115,9 +119,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
@@ -135,6 +136,10 @@ def main():
         return s_
 
     solver = new_solver()
+    solver.num_constraints()  # (creates the device state, and with it the solver's streams, before RCCL's and torch's)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = f"cuda:{local_rank}"
     packed = torch.empty((B, 4), dtype=torch.float64, device=dev)
     gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else packed
