@@ -503,10 +503,17 @@ altro_status altro_set_trajectory(altro_handle h, const double* X, const double*
   const size_t mult = per_instance ? d.batch : 1;
   h->spec.has_X = X != nullptr;
   h->spec.has_U = U != nullptr;
+  h->spec.traj_per_instance = per_instance;
+  if (h->uploaded) {  // (no copy into the recorded definition: nothing reads it after the upload)
+    h->spec.X_view = X;
+    h->spec.U_view = U;
+    const altro_status st = h->engine->SetTrajectory(h->spec, &h->err);
+    h->spec.X_view = nullptr;
+    h->spec.U_view = nullptr;
+    return st;
+  }
   if (X) h->spec.X.assign(X, X + mult * (d.N + 1) * d.n);
   if (U) h->spec.U.assign(U, U + mult * d.N * d.m);
-  h->spec.traj_per_instance = per_instance;
-  if (h->uploaded) return h->engine->SetTrajectory(h->spec, &h->err);
   return ALTRO_OK;
 }
 altro_status altro_reset_trajectory(altro_handle h) {

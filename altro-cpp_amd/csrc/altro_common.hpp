@@ -41,6 +41,9 @@ struct ProblemSpec {
   std::vector<double> x0;  // [n] or [B][n]
   int x0_per_instance = 0;
   std::vector<double> X, U;  // host layout, instance-major
+  // after the upload a new trajectory goes from the caller's buffers straight to the device: views for that one call
+  const double* X_view = nullptr;
+  const double* U_view = nullptr;
   bool has_X = false, has_U = false;
   int traj_per_instance = 0;
   double penalty = -1.0;  // SetPenalty issued before the device state exists

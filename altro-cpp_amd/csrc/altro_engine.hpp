@@ -631,9 +631,11 @@ class Engine final : public EngineBase {
       altro_status st0 = Sync();  // ResetTrajectory may still be copying on the (non-blocking) stream
       if (st0 != ALTRO_OK) return st0;
     }
-    altro_status st = UploadRec(A_.X, N_ + 1, R::nP, n, s.has_X ? s.X.data() : nullptr, s.traj_per_instance != 0);
+    const double* Xh = !s.has_X ? nullptr : (s.X_view ? s.X_view : s.X.data());
+    const double* Uh = !s.has_U ? nullptr : (s.U_view ? s.U_view : s.U.data());
+    altro_status st = UploadRec(A_.X, N_ + 1, R::nP, n, Xh, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
-    st = UploadRec(A_.U, N_, R::mP, m, s.has_U ? s.U.data() : nullptr, s.traj_per_instance != 0);
+    st = UploadRec(A_.U, N_, R::mP, m, Uh, s.traj_per_instance != 0);
     if (st != ALTRO_OK) return st;
     ALTRO_HIP_CHECK(CopySync(X_init_, A_.X, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
     ALTRO_HIP_CHECK(CopySync(U_init_, A_.U, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice));
