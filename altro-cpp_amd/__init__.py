@@ -328,9 +328,16 @@ class BatchSolver:
         return out
 
     # -- results ----------------------------------------------------------------------------------
-    def get_trajectory(self):
-        X = np.empty((self.batch, self.N + 1, self.n))
-        U = np.empty((self.batch, self.N, self.m))
+    def get_trajectory(self, X=None, U=None):
+        """X [batch][N+1][n], U [batch][N][m]; pass C-contiguous float64 arrays of these shapes to have them filled in
+        place (a caller that solves in a loop keeps its buffers: fresh pages cost more than the copy)."""
+        if X is None:
+            X = np.empty((self.batch, self.N + 1, self.n))
+        if U is None:
+            U = np.empty((self.batch, self.N, self.m))
+        for a_, shape in ((X, (self.batch, self.N + 1, self.n)), (U, (self.batch, self.N, self.m))):
+            if a_.dtype != np.float64 or a_.shape != shape or not a_.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"get_trajectory needs C-contiguous float64 arrays of shape {shape}")
         self._call("get_trajectory", _dp(X), _dp(U))
         return X, U
 

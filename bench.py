@@ -338,6 +338,7 @@ def main():
             solver.reset_trajectory()
             X0, U0 = solver.get_trajectory()
             x0 = np.ascontiguousarray(X0[:, 0, :])
+            Uout = np.empty_like(U0)
             hreps = max(1, min(args.steps, 3))
             h0 = 0.0
             for hi in range(hreps + 1):
@@ -351,7 +352,7 @@ def main():
                     solver.solve_ilqr()
                 else:
                     solver.solve()
-                Xs, Us = solver.get_trajectory()
+                Xs, Us = solver.get_trajectory(X0, Uout)  # (the caller's own buffers, reused every step)
                 hst = solver.get_stats()
             hdt = (time.perf_counter() - h0) / hreps
             host = {
@@ -359,7 +360,7 @@ def main():
                 "ms_per_step": round(1e3 * hdt, 3), "steps": hreps,
                 "bytes_up": int(x0.nbytes + U0.nbytes), "bytes_down": int(Xs.nbytes + Us.nbytes),
                 "note": "altro_set_initial_state + altro_set_trajectory from pageable host arrays, solve, "
-                        "altro_get_trajectory + altro_get_stats into host arrays",
+                        "altro_get_trajectory + altro_get_stats into host arrays (the caller's buffers, reused)",
             }
         name, cus = solver.device_info()
         out = {
