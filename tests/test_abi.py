@@ -102,3 +102,20 @@ def test_no_cpu_fallback(A, P):
 def test_missing_library_fails_loudly(A, tmp_path):
     with pytest.raises(A.AltroError):
         A.load_library(str(tmp_path / "libaltro_hip.so"))
+
+
+def test_get_trajectory_fills_the_callers_buffers(A, P, oracle_make):
+    """The Python mirror of altro_get_trajectory writes into arrays the caller hands in (an MPC loop keeps its buffers) and
+    refuses arrays that are not the C layout the ABI fills."""
+    import numpy as np
+    s = P.batch_turn90(oracle_make, batch=3)
+    s.rollout()
+    X, U = s.get_trajectory()
+    X2, U2 = np.zeros_like(X), np.zeros_like(U)
+    Xr, Ur = s.get_trajectory(X2, U2)
+    assert Xr is X2 and Ur is U2 and np.array_equal(X2, X) and np.array_equal(U2, U)
+    import pytest
+    with pytest.raises(ValueError):
+        s.get_trajectory(np.zeros(X.shape, dtype=np.float32), U2)
+    with pytest.raises(ValueError):
+        s.get_trajectory(np.zeros(X.shape[::-1]).T, U2)
