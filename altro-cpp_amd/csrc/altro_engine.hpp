@@ -88,6 +88,8 @@ class Engine final : public EngineBase {
     cur_ = stream_;
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     persist_at_ = num_cus_;
+    fwd_single_at_ = 2 * num_cus_;  // (measured 1x .. 8x the CUs: config 3 -1.2 % at 2x, config 2 indifferent)
+    if (const char* e = std::getenv("ALTRO_HIP_FWD_SINGLE_AT")) fwd_single_at_ = atoi(e);
     if (const char* e = std::getenv("ALTRO_HIP_DEBUG_POISON")) {
       poison_on_ = true;
       poison_pattern_ = (unsigned)strtoul(e, nullptr, 16);
@@ -495,7 +497,7 @@ class Engine final : public EngineBase {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
       // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
       // epilogue of the kernel (staging, winner copy) shrink with the instances per workgroup.
-      const int per_wave = (std::max(ninst, ninst_all_chains) <= num_cus_) ? 1 : fwd_per_wave_;
+      const int per_wave = (std::max(ninst, ninst_all_chains) <= fwd_single_at_) ? 1 : fwd_per_wave_;
       const size_t lds = fwd_shared_bytes_ + (size_t)per_wave * fwd_per_inst_bytes_;
       const dim3 grid2((ninst + per_wave - 1) / per_wave);
       if (kdg_) {
@@ -1601,6 +1603,7 @@ class Engine final : public EngineBase {
   bool poison_on_ = false;
   unsigned poison_pattern_ = 0;
   int poison_mix_ = 0;
+  int fwd_single_at_ = 512;  // active instances (all chains) below which every instance gets a forward workgroup of its own
   int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;
