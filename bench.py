@@ -19,7 +19,13 @@ for every instance, and the result exchange (``sharding.pack_and_gather``: the r
 device and, with N > 1, ONE RCCL all_gather moves 32 B per instance).  Inputs are resident in HBM before
 the timed region.  ``value`` counts only instances that finished with status kSolved.
 
+Beside the headline the default line (N = 1) carries: ``cpu_baseline`` (the oracle on the host cores, pinned
+threads, instances built outside the timed region), ``host_boundary`` (the same step over host buffers),
+``other_configs`` (BASELINE configs 1, 3, 4: a few steps each after the headline) and ``latency`` (one solve of a
+batch of 1 / 8 / 64 -- the MPC use case -- next to one host core).
+
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--batch B] [--no-cpu-baseline]
+                        [--no-other-configs] [--no-latency]
         (N > 1: launched by torch.distributed.run, one rank per GPU)
 """
 import argparse
@@ -90,6 +96,277 @@ def algorithmic_bytes(n, m, N, p_stage, p_term, itemsize):
 CHAIN_CYCLES_PER_KNOT = {"backward": 310, "forward": 189}
 
 
+def dominant_kernel_roofline(cfg, tm, config_index):
+    """Roofline block of one profiled solve (``tm`` = altro_get_timing after a solve with profiler_enable)."""
+    n, m, N = cfg["n"], cfg["m"], cfg["N"]
+    ab = algorithmic_bytes(n, m, N, cfg["p"][0], cfg["p"][1], cfg["item"])
+    # Kernels of one solve: the three sweep kernels while many instances iterate, then (n = 3, m = 2) ONE
+    # persistent launch of k_sweep_fused that runs every remaining iteration of the stragglers
+    # (expansions + backward + forward of one instance per workgroup, see DESIGN.md section 4).
+    kern_ms = {"expansions": tm["expansions_ms"], "backward_pass": tm["backward_pass_ms"],
+               "forward_pass": tm["forward_pass_ms"], "sweep_fused": tm["fused_ms"]}
+    # kern_ms are sums of launch durations.  A large batch runs its batched sweeps as several chains on streams of
+    # their own (DESIGN.md section 4): their launches overlap, so the three sweep kernels can add up to more than the
+    # wall time.  The dominant kernel is the one with the largest share of the solve's WALL time: the sweep kernels
+    # share what the solve took outside the initialisation and the persistent launch.
+    sweep_sum = kern_ms["expansions"] + kern_ms["backward_pass"] + kern_ms["forward_pass"]
+    sweep_wall = min(sweep_sum, max(0.0, tm["total_ms"] - tm["init_ms"] - tm["fused_ms"]))
+    scale = sweep_wall / sweep_sum if sweep_sum > 0 else 1.0
+    wall_ms = {k: (v if k == "sweep_fused" else v * scale) for k, v in kern_ms.items()}
+    dom = max(wall_ms, key=wall_ms.get)
+    units_total = tm["instance_iterations"]  # (trajectory, iteration) units of the whole solve
+    units_fused = tm["fused_instance_iterations"]
+    if dom == "sweep_fused":
+        launches, units, bytes_per_unit = max(1, tm.get("fused_launches", 1) or 1), units_fused, ab["total"]
+    else:
+        launches = tm.get("sweep_launches") or (tm["sweeps"] - tm["fused_sweeps"])  # all chains of sweeps together
+        units, bytes_per_unit = units_total - units_fused, ab[dom]
+    launches = max(launches, 1)
+    avg_launch_ms = kern_ms[dom] / launches
+    achieved = bytes_per_unit * units / launches / (avg_launch_ms * 1e-3) / 1e9  # GB/s
+    sweep_ms = sum(wall_ms.values())
+    achieved_all = ab["total"] * units_total / (sweep_ms * 1e-3) / 1e9
+    # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
+    # same command (FETCH_SIZE / WRITE_SIZE in separate --pmc runs, gfx950 correction applied --
+    # see profiles/rNN_traffic.json); bench.py itself cannot run the profiler.
+    traffic, traffic_src = None, None
+    key = {"expansions": "k_expansions", "backward_pass": "k_backward", "forward_pass": "k_forward",
+           "sweep_fused": "k_sweep_fused"}[dom]
+    tag = "" if config_index == 2 else f"_config{config_index}"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}_traffic.json")), reverse=True):
+        if config_index == 2 and "_config" in os.path.basename(f):
+            continue
+        try:
+            tj = json.load(open(f))
+            if key in tj:
+                traffic = round(tj[key]["traffic_bytes_per_launch"])
+                traffic_src = os.path.relpath(f, ROOT)
+                break
+        except Exception:
+            pass
+    roofline = {
+        "bound": "hbm", "kernel": key, "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "avg_launch_us": round(1e3 * avg_launch_ms, 2), "launches": launches,
+        "units_per_launch": round(units / launches, 1),
+        "algorithmic_bytes_per_unit": bytes_per_unit,
+        "algorithmic_bytes_per_launch": round(bytes_per_unit * units / launches),
+        "all_kernels_achieved": round(achieved_all, 2),
+        "all_kernels_frac": round(achieved_all / HBM_PEAK_GBS, 5),
+        "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
+        "kernel_wall_ms": {k: round(v, 3) for k, v in wall_ms.items()},
+        "sweep_launches": tm.get("sweep_launches", 0),
+        "concurrent_chains": max(1, round(tm.get("sweep_launches", 0) / max(1, tm["sweeps"] - tm["fused_sweeps"]))),
+        "tail_iterations": tm["fused_sweeps"],
+    }
+    if tm["fused_sweeps"] > 0 and n == 3 and m == 2:
+        # the real limiter of the dominant launch: the dependent chain of one instance's iteration
+        # (chain_floor_us prices the two chains one after the other, as the reference runs them.  The persistent
+        #  kernel overlaps them whenever a line search rejects every trial -- the fourth wave has the next backward
+        #  pass ready by then -- so the floor of such an iteration is the longer chain alone: chain_floor_overlap_us)
+        floor_us = sum(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
+        floor_overlap_us = max(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
+        iter_us = 1e3 * tm["fused_ms"] / tm["fused_sweeps"]
+        roofline.update({
+            "chain_floor_us": round(floor_us, 2), "chain_floor_overlap_us": round(floor_overlap_us, 2),
+            "tail_iteration_us": round(iter_us, 2),
+            "chain_floor_frac": round(floor_us / iter_us, 4),
+            "limiter": "serial dependency chain: the persistent tail kernel carries one straggler instance per "
+                       "workgroup through ~100 iterations x (N Riccati steps + N RK4 steps); chain_floor_us is "
+                       "the dependent-instruction latency of one iteration (measured issue latencies, "
+                       "profiles/r01_microbench.txt), tail_iteration_us what one iteration takes",
+        })
+    return roofline
+
+
+def load_oracle():
+    """The CPU oracle (test infrastructure): ONLY the cpu_baseline / latency legs below call it, as the thing a GPU number
+    is reported beside -- never inside a timed GPU region."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    lib.oracle_bench_seconds.restype = ctypes.c_double
+    lib.oracle_bench_busy.restype = ctypes.c_double
+    return lib
+
+
+def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
+    """The oracle (kind "port": the literal Eigen path cannot be built here) on the host cores, on a
+    bounded sample of the SAME workload.  Sound by construction: the instances are built outside the
+    timed region (oracle_prepare), one warm-up pass touches every array, the threads are pinned (one per physical core
+    first), the clock runs inside the library from the team's start barrier to its last task, and a task is one solve of
+    one instance handed out repetition-major (the tail of the run is one straggler solve).  Two team sizes are timed --
+    one thread per physical core, and every hardware thread -- and the better one is `value`."""
+    lib = load_oracle()
+    factory = getattr(P, cfg["factory"])
+    ilqr = cfg["mode"] == "ilqr"
+    obench = lib.oracle_bench_ilqr if ilqr else lib.oracle_bench_al
+    omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
+    hw = int(lib.oracle_host_threads())
+    phys = int(lib.oracle_host_physical_cores())
+    o = factory(omake, batch=B, dtype=A.F64, seed=seed)
+    lib.oracle_prepare(o._h)
+    # warm-up + calibration: one pass over the batch on every hardware thread (also sizes the per-instance vectors)
+    lib.oracle_set_threads(o._h, ctypes.c_int(hw))
+    obench(o._h, ctypes.c_int(1))
+    pass_s = lib.oracle_bench_seconds(o._h)
+    st = o.get_stats()
+    iters_pass = float(st["iterations_total"].sum())
+    solved_pass = float((st["status"] == 0).sum())
+    # single thread: a slice of the batch with every 64th instance (the stragglers are spread over the batch), so
+    # that per-iteration and per-trajectory cost are those of the same instance mix
+    idx_stride = max(1, B // 64)
+    o1 = factory(omake, batch=B, dtype=A.F64, seed=seed)  # same batch; only the sampled instances are solved
+    lib.oracle_prepare(o1._h)
+    lib.oracle_set_threads(o1._h, ctypes.c_int(1))
+    lib.oracle_set_ilqr_mode(o1._h, ctypes.c_int(1 if ilqr else 0))
+    lib.oracle_bench_subset(o1._h, ctypes.c_int(idx_stride), ctypes.c_int(1))  # warm-up
+    lib.oracle_bench_subset(o1._h, ctypes.c_int(idx_stride), ctypes.c_int(1))
+    t1 = lib.oracle_bench_seconds(o1._h)
+    s1 = o1.get_stats()
+    sel = slice(0, B, idx_stride)
+    iters1 = float(s1["iterations_total"][sel].sum())
+    solved1 = float((s1["status"][sel] == 0).sum())
+    runs = []
+    for nt in sorted({phys, hw}):
+        lib.oracle_set_threads(o._h, ctypes.c_int(nt))
+        # ~budget/2 CPU-seconds per team size: reps from the calibration pass (pass_s wall on hw threads)
+        est_cpu_s_per_pass = t1 * (iters_pass / max(iters1, 1.0))
+        reps = int(max(1, min(512, round(0.5 * budget_cpu_s / max(est_cpu_s_per_pass, 1e-6)))))
+        obench(o._h, ctypes.c_int(reps))
+        sec = lib.oracle_bench_seconds(o._h)
+        runs.append({"threads": nt, "reps": reps, "seconds": round(sec, 4),
+                     "value": round(solved_pass * reps / sec, 2),
+                     "iterations_per_s": round(iters_pass * reps / sec, 1),
+                     "busy_min_s": round(lib.oracle_bench_busy(o._h, 0), 4),
+                     "busy_max_s": round(lib.oracle_bench_busy(o._h, 1), 4)})
+    best = max(runs, key=lambda r: r["value"])
+    it_rate_1 = iters1 / t1
+    return {
+        "value": best["value"], "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
+        "physical_cores": phys, "hardware_threads": hw,
+        "sample": f"the same seeded {B}-instance workload (fp64) solved {best['reps']}x by {best['threads']} pinned host "
+                  f"threads (one solve of one instance per task; instances built and warmed up outside the timed "
+                  f"region; clock inside the library from the team's start barrier to its last task), "
+                  f"{best['seconds']:.2f} s wall = about {best['seconds'] * best['threads']:.0f} CPU-seconds",
+        "single_thread_value": round(solved1 / t1, 2),
+        "single_thread_ms_per_ilqr_iter": round(1e3 / it_rate_1, 4),
+        "single_thread_sample": f"every {idx_stride}th instance of the batch ({len(range(0, B, idx_stride))} solves)",
+        # per-iteration throughput of the team / (one thread's x physical cores): SMT and all-core clocks included
+        "parallel_efficiency": round(best["iterations_per_s"] / (it_rate_1 * phys), 4),
+        "teams": runs,
+    }
+
+
+def solve_once(s_, mode):
+    s_.reset_trajectory()
+    if mode == "ilqr":
+        s_.reset_stats()  # a bare iLQR::Solve accumulates iterations_total across calls (quirk Q11)
+        s_.solve_ilqr()
+    else:
+        s_.solve()
+
+
+def measure_other_config(A, P, S, torch, ci, steps, warmup, device_id):
+    """A few steps of another BASELINE config after the headline (same step definition, one GPU): its own handle,
+    created after the headline's was destroyed (so it gets its chains of sweeps like a fresh process would)."""
+    cfg = CONFIGS[ci]
+    B = cfg["batch"]
+    make = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, device_id=device_id)  # noqa: E731
+    s_ = getattr(P, cfg["factory"])(make, batch=B, dtype=getattr(A, cfg["dtype"]), seed=P.SEED_BASE + cfg["seed"],
+                                     shard=S.shard_range(B, 1, 0))
+    s_.set_options(profiler_enable=0)
+    packed = torch.empty((B, 4), dtype=torch.float64, device=f"cuda:{device_id}")
+    for _ in range(warmup):
+        solve_once(s_, cfg["mode"])
+        S.pack_and_gather(s_, packed, packed, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solve_once(s_, cfg["mode"])
+        S.pack_and_gather(s_, packed, packed, None)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res = packed.cpu().numpy()
+    solved = int((res[:, 3].astype(int) == 0).sum())
+    s_.set_options(profiler_enable=1)
+    solve_once(s_, cfg["mode"])
+    tm = s_.get_timing()
+    rl = dominant_kernel_roofline(cfg, tm, ci)
+    s_.close()
+    return {
+        "workload": cfg["name"], "value": round(solved * steps / el, 1), "unit": "trajectories/s",
+        "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warmup,
+        "solved_fraction": round(solved / B, 5),
+        "dtype": "f64" if cfg["dtype"] == "F64" else "f64 arithmetic, f32 records (ALTRO_F32)",
+        "dominant_kernel": rl["kernel"], "frac": rl["frac"], "achieved_gbs": rl["achieved"],
+        "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"],
+        "all_kernels_frac": rl["all_kernels_frac"], "kernel_wall_ms": rl["kernel_wall_ms"],
+        "concurrent_chains": rl["concurrent_chains"], "sweeps": tm["sweeps"], "tail_iterations": tm["fused_sweeps"],
+    }
+
+
+def measure_latency(A, P, device_id, with_cpu=True):
+    """The MPC use case (reference docs/Overview.dox:48-54, test/augmented_lagrangian/auglag_test.cpp:353-380): wall time
+    of ONE altro_solve_al call for a batch of 1 / 8 / 64 -- cold (the reference problem's initial guess) and warm-started
+    (reset_duals = false, initial_penalty = 0, previous solution kept, the initial state moved a little) -- next to the
+    oracle on one host core for the batch of 1."""
+    import numpy as np
+    lib = load_oracle() if with_cpu else None
+    out = {}
+    for name, factory in (("kTurn90", "batch_turn90"), ("kThreeObstacles", "batch_three_obstacles")):
+        rows = {}
+        for B in (1, 8, 64):
+            make = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, device_id=device_id)  # noqa: E731
+            g = getattr(P, factory)(make, batch=B, dtype=A.F64)
+            g.set_options(profiler_enable=0)
+
+            def timed(s_, fn, reps=5):
+                best = 1e30
+                for _ in range(reps):
+                    fn(s_)
+                    t0 = time.perf_counter()
+                    s_.solve()
+                    best = min(best, time.perf_counter() - t0)
+                return best
+            cold = timed(g, lambda s_: s_.reset_trajectory())
+            st = g.get_stats()
+            # warm start: keep duals, penalties and the solution; the measured state differs a little from the plan
+            g.set_options(reset_duals=0, initial_penalty=0.0)
+            Xs, Us = g.get_trajectory()
+            x0 = np.ascontiguousarray(Xs[:, 0, :])
+            k = [0]
+
+            def nudge(s_):
+                k[0] += 1
+                s_.set_initial_state(x0 + 1e-3 * ((k[0] % 3) - 1))
+            warm = timed(g, nudge)
+            sw = g.get_stats()
+            row = {"cold_ms": round(1e3 * cold, 3), "cold_iterations_max": int(st["iterations_total"].max()),
+                   "warm_ms": round(1e3 * warm, 3), "warm_iterations_max": int(sw["iterations_total"].max())}
+            g.close()
+            if lib is not None and B == 1:
+                omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
+                o = getattr(P, factory)(omake, batch=1, dtype=A.F64)
+                lib.oracle_set_threads(o._h, ctypes.c_int(1))
+                lib.oracle_prepare(o._h)
+                ocold = timed(o, lambda s_: s_.reset_trajectory())
+                o.set_options(reset_duals=0, initial_penalty=0.0)
+                Xo, _ = o.get_trajectory()
+                xo = np.ascontiguousarray(Xo[:, 0, :])
+                k[0] = 0
+
+                def onudge(s_):
+                    k[0] += 1
+                    s_.set_initial_state(xo + 1e-3 * ((k[0] % 3) - 1))
+                owarm = timed(o, onudge)
+                row.update({"cpu_1thread_cold_ms": round(1e3 * ocold, 3), "cpu_1thread_warm_ms": round(1e3 * owarm, 3)})
+            rows[f"batch_{B}"] = row
+        out[name] = rows
+    out["note"] = ("best of 5 blocking altro_solve_al calls through the C-ABI, problem resident on the device; "
+                   "cpu_1thread_* = the oracle (port) on one host core for the same single instance")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +375,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra key with BASELINE configs 1, 3, 4")
+    ap.add_argument("--no-latency", action="store_true", help="skip the extra key with batch-of-1/8/64 solve latencies")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="EXTRA measurement, not the headline: keep this many solver handles in flight (asynchronous "
                          "solves on their own streams), so the latency-bound tail of one batch overlaps the next batch")
@@ -145,12 +424,7 @@ def main():
     gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else packed
 
     def solve(s_):
-        s_.reset_trajectory()
-        if cfg["mode"] == "ilqr":
-            s_.reset_stats()  # a bare iLQR::Solve accumulates iterations_total across calls (quirk Q11)
-            s_.solve_ilqr()
-        else:
-            s_.solve()
+        solve_once(s_, cfg["mode"])
 
     def step():
         solve(solver)
@@ -220,116 +494,11 @@ def main():
         solve(solver)
         tm = solver.get_timing()
         solver.set_options(profiler_enable=0)
-        ab = algorithmic_bytes(n, m, N, cfg["p"][0], cfg["p"][1], cfg["item"])
-        # Kernels of one solve: the three sweep kernels while many instances iterate, then (n = 3, m = 2) ONE
-        # persistent launch of k_sweep_fused that runs every remaining iteration of the stragglers
-        # (expansions + backward + forward of one instance per workgroup).
-        kern_ms = {"expansions": tm["expansions_ms"], "backward_pass": tm["backward_pass_ms"],
-                   "forward_pass": tm["forward_pass_ms"], "sweep_fused": tm["fused_ms"]}
-        # kern_ms are sums of launch durations.  A large batch runs its batched sweeps as several chains on streams of
-        # their own: their launches overlap, so the three sweep kernels can add up to more than the
-        # wall time.  The dominant kernel is the one with the largest share of the solve's WALL time: the sweep kernels
-        # share what the solve took outside the initialisation and the persistent launch.
-        sweep_sum = kern_ms["expansions"] + kern_ms["backward_pass"] + kern_ms["forward_pass"]
-        sweep_wall = min(sweep_sum, max(0.0, tm["total_ms"] - tm["init_ms"] - tm["fused_ms"]))
-        scale = sweep_wall / sweep_sum if sweep_sum > 0 else 1.0
-        wall_ms = {k: (v if k == "sweep_fused" else v * scale) for k, v in kern_ms.items()}
-        dom = max(wall_ms, key=wall_ms.get)
-        units_total = tm["instance_iterations"]  # (trajectory, iteration) units of the whole solve
-        units_fused = tm["fused_instance_iterations"]
-        if dom == "sweep_fused":
-            launches, units, bytes_per_unit = 1, units_fused, ab["total"]
-        else:
-            launches = tm.get("sweep_launches") or (tm["sweeps"] - tm["fused_sweeps"])  # all chains of sweeps together
-            units, bytes_per_unit = units_total - units_fused, ab[dom]
-        launches = max(launches, 1)
-        avg_launch_ms = kern_ms[dom] / launches
-        achieved = bytes_per_unit * units / launches / (avg_launch_ms * 1e-3) / 1e9  # GB/s
-        sweep_ms = sum(wall_ms.values())
-        achieved_all = ab["total"] * units_total / (sweep_ms * 1e-3) / 1e9
-        # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this
-        # same command (FETCH_SIZE / WRITE_SIZE in separate --pmc runs, gfx950 correction applied --
-        # see profiles/rNN_traffic.json); bench.py itself cannot run the profiler.
-        traffic, traffic_src = None, None
-        key = {"expansions": "k_expansions", "backward_pass": "k_backward", "forward_pass": "k_forward",
-               "sweep_fused": "k_sweep_fused"}[dom]
-        tag = "" if args.config == 2 else f"_config{args.config}"
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}_traffic.json")), reverse=True):
-            if args.config == 2 and "_config" in os.path.basename(f):
-                continue
-            try:
-                tj = json.load(open(f))
-                if key in tj:
-                    traffic = round(tj[key]["traffic_bytes_per_launch"])
-                    traffic_src = os.path.relpath(f, ROOT)
-                    break
-            except Exception:
-                pass
-        roofline = {
-            "bound": "hbm", "kernel": key, "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": round(1e3 * avg_launch_ms, 2), "launches": launches,
-            "units_per_launch": round(units / launches, 1),
-            "algorithmic_bytes_per_unit": bytes_per_unit,
-            "algorithmic_bytes_per_launch": round(bytes_per_unit * units / launches),
-            "all_kernels_achieved": round(achieved_all, 2),
-            "all_kernels_frac": round(achieved_all / HBM_PEAK_GBS, 5),
-            "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
-            "kernel_wall_ms": {k: round(v, 3) for k, v in wall_ms.items()},
-            "sweep_launches": tm.get("sweep_launches", 0),
-            "concurrent_chains": max(1, round(tm.get("sweep_launches", 0) / max(1, tm["sweeps"] - tm["fused_sweeps"]))),
-            "tail_iterations": tm["fused_sweeps"],
-        }
-        if tm["fused_sweeps"] > 0 and n == 3 and m == 2:
-            # the real limiter of the dominant launch: the dependent chain of one instance's iteration
-            # (chain_floor_us prices the two chains one after the other, as the reference runs them.  The persistent
-            #  kernel overlaps them whenever a line search rejects every trial -- the fourth wave has the next backward
-            #  pass ready by then -- so the floor of such an iteration is the longer chain alone: chain_floor_overlap_us)
-            floor_us = sum(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
-            floor_overlap_us = max(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
-            iter_us = 1e3 * tm["fused_ms"] / tm["fused_sweeps"]
-            roofline.update({
-                "chain_floor_us": round(floor_us, 2), "chain_floor_overlap_us": round(floor_overlap_us, 2),
-                "tail_iteration_us": round(iter_us, 2),
-                "chain_floor_frac": round(floor_us / iter_us, 4),
-                "limiter": "serial dependency chain: the persistent tail kernel carries one straggler instance per "
-                           "workgroup through ~100 iterations x (N Riccati steps + N RK4 steps); chain_floor_us is "
-                           "the dependent-instruction latency of one iteration (measured issue latencies, "
-                           "profiles/r01_microbench.txt), tail_iteration_us what one iteration takes",
-            })
+        roofline = dominant_kernel_roofline(cfg, tm, args.config)
         # ---- CPU baseline: the oracle (a port, see oracle/altro_oracle.cpp) on the host cores --------
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-            lib = ctypes.CDLL(lib_path)
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
-            osolve = (lambda s_: s_.solve_ilqr()) if cfg["mode"] == "ilqr" else (lambda s_: s_.solve())
-            obench = lib.oracle_bench_ilqr if cfg["mode"] == "ilqr" else lib.oracle_bench_al
-            # single thread first: calibrates how many repetitions make ~10-30 s of CPU work
-            o1 = factory(omake, batch=64, dtype=A.F64, seed=seed)
-            lib.oracle_set_threads(o1._h, ctypes.c_int(1))
-            c1 = time.perf_counter()
-            osolve(o1)
-            cdt1 = time.perf_counter() - c1
-            o1st = o1.get_stats()
-            per_inst = cdt1 / 64
-            reps = int(max(1, min(256, round(20.0 / (per_inst * B)))))  # ~20 CPU-seconds in total
-            o = factory(omake, batch=B, dtype=A.F64, seed=seed)
-            lib.oracle_set_threads(o._h, ctypes.c_int(cores))
-            c0 = time.perf_counter()
-            obench(o._h, ctypes.c_int(reps))
-            cdt = time.perf_counter() - c0
-            ost = o.get_stats()
-            cpu = {
-                "value": round(float((ost["status"] == 0).sum()) * reps / cdt, 2), "unit": "trajectories/s",
-                "cores": cores, "kind": "port",
-                "sample": f"the same seeded {B}-instance workload (fp64) solved {reps}x back to back by {cores} host "
-                          f"threads (one instance per task, one thread team), about {per_inst * B * reps:.0f} CPU-seconds",
-                "single_thread_value": round(float((o1st["status"] == 0).sum()) / cdt1, 2),
-                "single_thread_ms_per_ilqr_iter": round(1e3 * cdt1 / float(o1st["iterations_total"].sum()), 4),
-            }
+            cpu = cpu_baseline(A, P, cfg, B, seed)
         # ---- the same step with the problem handed over as HOST buffers (the C-ABI boundary of an MPC caller: a new
         #      initial state and a warm start per instance go up, trajectories and statistics come back), PCIe and
         #      the host-side layout conversion included.  Reported beside `value`, never as `value`. ----
@@ -363,6 +532,16 @@ def main():
                         "altro_get_trajectory + altro_get_stats into host arrays (the caller's buffers, reused)",
             }
         name, cus = solver.device_info()
+        others, latency = None, None
+        if world == 1 and args.pipeline == 1 and (not args.no_other_configs or not args.no_latency):
+            solver.close()  # (the other workloads get the device to themselves, like the headline had it)
+            if not args.no_other_configs:
+                others = {}
+                for ci in sorted(CONFIGS):
+                    if ci != args.config:
+                        others[f"configs[{ci}]"] = measure_other_config(A, P, S, torch, ci, 3, 1, local_rank)
+            if not args.no_latency:
+                latency = measure_latency(A, P, local_rank, with_cpu=not args.no_cpu_baseline)
         out = {
             "metric": "trajectories solved/sec (AL-iLQR to tol), unicycle 101 knots, batched" if args.config in (2, 3)
                       else "trajectories solved/sec (to tol), batched",
@@ -389,6 +568,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "host_boundary": host,
+            "other_configs": others,
+            "latency": latency,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

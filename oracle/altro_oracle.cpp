@@ -22,15 +22,21 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "../include/altro_hip.h"  // POD structs and enums only
 
@@ -1223,6 +1229,10 @@ struct oracle_solver_s {
   bool ilqr_mode = false;
   std::vector<std::unique_ptr<SolverBase>> inst;
   std::string err;
+  // CPU-baseline runs (oracle_bench_*): wall time between the start barrier of the thread team and its last task,
+  // the threads that ran and the slowest / fastest thread's busy time
+  double bench_seconds = 0.0, bench_busy_min = 0.0, bench_busy_max = 0.0;
+  int bench_threads = 0;
 };
 typedef oracle_solver_s* oracle_handle;
 
@@ -1321,6 +1331,102 @@ altro_status ForAll(oracle_handle h, F f) {
       });
     for (auto& t : th) t.join();
   }
+  return ALTRO_OK;
+}
+
+
+// (cpu, rank among the hardware threads of its physical core) for every CPU of the affinity mask, ordered so that the
+// first hardware thread of every physical core comes before any second one.
+std::vector<std::pair<int, int>> HostTopology() {
+  std::vector<std::pair<int, int>> out;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) != 0) {
+    out.emplace_back(0, 0);
+    return out;
+  }
+  std::map<std::pair<int, int>, int> seen;  // (package, core id) -> hardware threads met so far
+  auto read_int = [](const std::string& path, int dflt) {
+    int v = dflt;
+    if (FILE* f = std::fopen(path.c_str(), "r")) {
+      if (std::fscanf(f, "%d", &v) != 1) v = dflt;
+      std::fclose(f);
+    }
+    return v;
+  };
+  for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+    if (!CPU_ISSET(cpu, &set)) continue;
+    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(cpu) + "/topology/";
+    const int pkg = read_int(base + "physical_package_id", 0);
+    const int core = read_int(base + "core_id", cpu);  // (no sysfs: every CPU counts as its own core)
+    out.emplace_back(cpu, seen[{pkg, core}]++);
+  }
+  std::stable_sort(out.begin(), out.end(),
+                   [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second < b.second; });
+  if (out.empty()) out.emplace_back(0, 0);
+  return out;
+}
+
+template <class F>
+altro_status BenchRun(oracle_handle h, int reps, F solve_one, int stride = 1) {
+  if (!h || reps < 1 || stride < 1) return ALTRO_INVALID_ARG;
+  altro_status st = Build(h);  // (a no-op after oracle_prepare)
+  if (st != ALTRO_OK) return st;
+  const altro_desc& D = h->desc;
+  const int B = D.batch;
+  const int nsub = (B + stride - 1) / stride;  // every stride-th instance
+  const int nt = std::max(1, std::min(h->nthreads, nsub));
+  const std::vector<std::pair<int, int>> topo = HostTopology();
+  const long long tasks = (long long)reps * nsub;
+  std::atomic<long long> next(0);
+  std::atomic<int> arrived(0);
+  std::unique_ptr<std::atomic<int>[]> busy(new std::atomic<int>[B]);
+  for (int b = 0; b < B; ++b) busy[b].store(0);
+  using clk = std::chrono::steady_clock;
+  clk::time_point t_start;
+  std::vector<double> t_end(nt, 0.0), t_busy(nt, 0.0);
+  auto body = [&](int t) {
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(topo[t % topo.size()].first, &one);
+    pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+    if (arrived.fetch_add(1) + 1 == nt) t_start = clk::now();  // the last thread to arrive starts the clock ...
+    while (arrived.load() < nt) std::this_thread::yield();      // ... and releases the team
+    const clk::time_point t0 = clk::now();
+    for (;;) {
+      const long long i = next.fetch_add(1);
+      if (i >= tasks) break;
+      const int b = (int)(i % nsub) * stride;
+      int idle = 0;
+      while (!busy[b].compare_exchange_weak(idle, 1, std::memory_order_acquire)) {  // the previous repetition of b
+        idle = 0;
+        std::this_thread::yield();
+      }
+      const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
+      const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
+      SolverBase& s = *h->inst[b];
+      s.SetTrajectory(Xb, Ub);
+      solve_one(s);
+      busy[b].store(0, std::memory_order_release);
+    }
+    const clk::time_point t1 = clk::now();
+    t_busy[t] = std::chrono::duration<double>(t1 - t0).count();
+    t_end[t] = std::chrono::duration<double>(t1.time_since_epoch()).count();
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+  body(0);
+  for (auto& t : th) t.join();
+  const double start = std::chrono::duration<double>(t_start.time_since_epoch()).count();
+  h->bench_seconds = *std::max_element(t_end.begin(), t_end.end()) - start;
+  h->bench_busy_max = *std::max_element(t_busy.begin(), t_busy.end());
+  h->bench_busy_min = *std::min_element(t_busy.begin(), t_busy.end());
+  h->bench_threads = nt;
+  // (the calling thread was pinned for the run: give it its mask back)
+  cpu_set_t all;
+  CPU_ZERO(&all);
+  for (const auto& c : topo) CPU_SET(c.first, &all);
+  pthread_setaffinity_np(pthread_self(), sizeof(all), &all);
   return ALTRO_OK;
 }
 
@@ -1506,32 +1612,54 @@ altro_status oracle_solve_ilqr(oracle_handle h) {
   h->ilqr_mode = true;
   return ForAll(h, [](SolverBase& s, int) { s.SolveILQR(); });
 }
-// CPU-baseline helper for bench.py: `reps` x (re-install the initial guess, AL solve) per instance
-// inside ONE thread team, so that thread start-up is paid once.
+// CPU-baseline helpers for bench.py (the `cpu_baseline` leg): `reps` x (re-install the initial guess, solve) per
+// instance on a team of PINNED threads.  What the timed region holds is the solver work and nothing else:
+//  * the instances are built (and every per-instance array allocated) by oracle_prepare(), outside;
+//  * thread t is pinned to the t-th hardware thread of the process's affinity mask, one thread per physical core first
+//    (HostTopology), so a team of `physical cores` threads never shares a core;
+//  * the team starts at a barrier; the clock runs from that barrier to the end of the last task
+//    (oracle_bench_seconds), thread creation and join are outside;
+//  * a task is ONE solve of ONE instance, handed out repetition-major by an atomic counter: the tail of the run is
+//    one straggler solve, not `reps` of them (a try-lock per instance keeps two repetitions of one instance apart).
+altro_status oracle_prepare(oracle_handle h) {
+  if (!h) return ALTRO_INVALID_ARG;
+  return Build(h);
+}
+double oracle_bench_seconds(oracle_handle h) { return h ? h->bench_seconds : 0.0; }
+int oracle_bench_threads(oracle_handle h) { return h ? h->bench_threads : 0; }
+// busy time of the slowest (which = 1) / fastest (which = 0) thread of the last run: their ratio is the load balance
+double oracle_bench_busy(oracle_handle h, int which) { return h ? (which ? h->bench_busy_max : h->bench_busy_min) : 0.0; }
+// hardware threads this process may run on / distinct physical cores among them (sysfs topology)
+int oracle_host_threads(void) { return (int)HostTopology().size(); }
+int oracle_host_physical_cores(void) {
+  int n = 0;
+  for (const auto& c : HostTopology()) n += c.second == 0;
+  return std::max(n, 1);
+}
 altro_status oracle_bench_al(oracle_handle h, int reps) {
   h->ilqr_mode = false;
-  const altro_desc& D = h->desc;
-  return ForAll(h, [&](SolverBase& s, int b) {
-    const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
-    const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
-    for (int r = 0; r < reps; ++r) {
-      s.SetTrajectory(Xb, Ub);
-      s.SolveAL();
-    }
-  });
+  return BenchRun(h, reps, [](SolverBase& s) { s.SolveAL(); });
+}
+// every stride-th instance only (the single-thread leg: the same instance mix as the batch in 1/stride of the time);
+// AL or bare iLQR solves according to the handle's last oracle_bench_* / oracle_solve_* call
+altro_status oracle_bench_subset(oracle_handle h, int stride, int reps) {
+  if (h->ilqr_mode)
+    return BenchRun(h, reps, [](SolverBase& s) {
+      s.RawStats().Reset();
+      s.SolveILQR();
+    }, stride);
+  return BenchRun(h, reps, [](SolverBase& s) { s.SolveAL(); }, stride);
+}
+altro_status oracle_set_ilqr_mode(oracle_handle h, int on) {
+  h->ilqr_mode = on != 0;
+  return ALTRO_OK;
 }
 // the same for a bare iLQR solve (BASELINE configs[1]); the statistics are reset between the repetitions
 altro_status oracle_bench_ilqr(oracle_handle h, int reps) {
   h->ilqr_mode = true;
-  const altro_desc& D = h->desc;
-  return ForAll(h, [&](SolverBase& s, int b) {
-    const double* Xb = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * D.n : 0) : nullptr;
-    const double* Ub = h->U.empty() ? nullptr : h->U.data() + (h->traj_per_instance ? (size_t)b * D.N * D.m : 0);
-    for (int r = 0; r < reps; ++r) {
-      s.SetTrajectory(Xb, Ub);
-      s.RawStats().Reset();
-      s.SolveILQR();
-    }
+  return BenchRun(h, reps, [](SolverBase& s) {
+    s.RawStats().Reset();
+    s.SolveILQR();
   });
 }
 altro_status oracle_al_init(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.AlInit(); }); }
