@@ -125,6 +125,17 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
+def user_model_path(kind, _lib=None):
+    """Path of the cached plugin (.so) of a registered user model."""
+    lib = _lib if _lib is not None else load_library()
+    buf = C.create_string_buffer(4096)
+    f = lib.altro_user_model_path
+    f.restype = C.c_int
+    if f(C.c_int(kind), buf, C.c_int(len(buf))) < 0:
+        raise AltroError(f"unknown user model kind {kind}")
+    return buf.value.decode()
+
+
 class BatchSolver:
     """Batched AL-iLQR solver handle (one device, one stream)."""
 
@@ -179,6 +190,22 @@ class BatchSolver:
 
     def set_uniform_step(self, h):
         self._call("set_uniform_step", C.c_float(np.float32(h)))
+
+    def set_steps(self, hk):
+        """Trajectory::SetStep(k, h), k = 0 .. N-1 (trajectory.hpp:120): 32-bit float steps."""
+        hk = np.ascontiguousarray(hk, dtype=np.float32)
+        self._call("set_steps", hk.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(hk.size))
+
+    def set_times(self, tk):
+        """Trajectory::SetTime(k, t), k = 0 .. N (trajectory.hpp:119)."""
+        tk = np.ascontiguousarray(tk, dtype=np.float32)
+        self._call("set_times", tk.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(tk.size))
+
+    def get_steps(self):
+        hk = np.zeros(self.N, dtype=np.float32)
+        tk = np.zeros(self.N + 1, dtype=np.float32)
+        self._call("get_steps", hk.ctypes.data_as(C.POINTER(C.c_float)), tk.ctypes.data_as(C.POINTER(C.c_float)))
+        return hk, tk
 
     def set_lqr_cost(self, k_begin, k_end, Q, R, xref, uref):
         Q, R, xref, uref = _f64(Q), _f64(R), _f64(xref), _f64(uref)

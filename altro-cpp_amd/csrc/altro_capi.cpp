@@ -398,6 +398,14 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   return ALTRO_OK;
 }
 
+int altro_user_model_path(int kind, char* buf, int len) {
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  const int idx = kind - ALTRO_MODEL_USER_BASE;
+  if (idx < 0 || idx >= (int)g_models.size() || !buf || len <= 0) return -1;
+  std::snprintf(buf, (size_t)len, "%s", g_models[idx].so_path.c_str());
+  return (int)g_models[idx].so_path.size();
+}
+
 altro_status altro_set_model(altro_handle h, int kind, const double* params, int nparams) {
   if (!h) return ALTRO_INVALID_ARG;
   if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
@@ -411,11 +419,57 @@ altro_status altro_set_uniform_step(altro_handle h, float hstep) {
   // the step belongs to the trajectory (trajectory.hpp:122-130), not to the problem definition: it may
   // change between solves, also after the device state exists
   h->spec.hstep = hstep;
+  h->spec.hk.clear();  // SetUniformStep overwrites every knot's step and time (trajectory.hpp:122-130)
+  h->spec.tk.clear();
   if (h->uploaded) {
     altro_status st = h->engine->SetStep(hstep);
-    if (st != ALTRO_OK) h->err = h->engine->LastError();
+    if (st == ALTRO_OK) st = h->engine->SetKnotTimes(h->spec, &h->err);
+    else h->err = h->engine->LastError();
     return st;
   }
+  return ALTRO_OK;
+}
+altro_status altro_set_steps(altro_handle h, const float* hk, int count) {
+  if (!h || !hk) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
+  if (count != h->spec.desc.N) {
+    h->err = "altro_set_steps: expected N = " + std::to_string(h->spec.desc.N) + " steps (the terminal knot has none)";
+    return ALTRO_INVALID_ARG;
+  }
+  for (int k = 0; k < count; ++k)
+    if (!(hk[k] > 0.0f)) {
+      h->err = "altro_set_steps: step " + std::to_string(k) + " is not positive";
+      return ALTRO_INVALID_ARG;
+    }
+  if (h->spec.tk.empty() && h->spec.hk.empty() && h->spec.hstep > 0.0f) {
+    // the times an earlier SetUniformStep left stay (Trajectory::SetStep does not touch them)
+    const int N = h->spec.desc.N;
+    h->spec.tk.resize(N + 1);
+    for (int k = 0; k < N; ++k) h->spec.tk[k] = static_cast<float>(k) * h->spec.hstep;
+    h->spec.tk[N] = h->spec.hstep * N;
+  }
+  h->spec.hk.assign(hk, hk + count);
+  if (h->uploaded) return h->engine->SetKnotTimes(h->spec, &h->err);
+  return ALTRO_OK;
+}
+altro_status altro_set_times(altro_handle h, const float* tk, int count) {
+  if (!h || !tk) return ALTRO_INVALID_ARG;
+  if (Busy(h)) return ALTRO_NOT_READY;
+  if (count != h->spec.desc.N + 1) {
+    h->err = "altro_set_times: expected N + 1 = " + std::to_string(h->spec.desc.N + 1) + " times";
+    return ALTRO_INVALID_ARG;
+  }
+  h->spec.tk.assign(tk, tk + count);  // (only a time-varying model reads them; the steps decide which kernels run)
+  if (h->uploaded) return h->engine->SetKnotTimes(h->spec, &h->err);
+  return ALTRO_OK;
+}
+altro_status altro_get_steps(altro_handle h, float* hk, float* tk) {
+  if (!h) return ALTRO_INVALID_ARG;
+  const int N = h->spec.desc.N;
+  for (int k = 0; k < N && hk; ++k) hk[k] = h->spec.hk.empty() ? h->spec.hstep : h->spec.hk[k];
+  for (int k = 0; k <= N && tk; ++k)
+    tk[k] = !h->spec.tk.empty() ? h->spec.tk[k]
+                                : (!h->spec.hk.empty() ? 0.0f : (k < N ? static_cast<float>(k) * h->spec.hstep : h->spec.hstep * N));
   return ALTRO_OK;
 }
 altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const double* Q, const double* R,

@@ -36,6 +36,9 @@ struct ProblemSpec {
   int model_kind = 0;
   int dof = 0;
   float hstep = 0.0f;
+  // Trajectory::SetStep(k, h) / SetTime(k, t) (trajectory.hpp:119-120): per-knot steps hk[N] and times tk[N + 1]; empty =
+  // the uniform step above with t_k = float(k) * h, t_N = h * N (trajectory.hpp:122-130)
+  std::vector<float> hk, tk;
   std::vector<CostSpec> costs;
   std::vector<ConSpec> cons;
   std::vector<double> x0;  // [n] or [B][n]
@@ -121,6 +124,8 @@ class EngineBase {
   virtual altro_status SetInitialState(const ProblemSpec& spec, std::string* err) = 0;
   virtual altro_status SetTrajectory(const ProblemSpec& spec, std::string* err) = 0;
   virtual altro_status SetStep(float hstep) = 0;
+  // per-knot steps / times of the spec (or back to the uniform step when both are empty)
+  virtual altro_status SetKnotTimes(const ProblemSpec& spec, std::string* err) = 0;
   virtual altro_status ResetTrajectory() = 0;
   virtual altro_status ResetStats() = 0;
   virtual altro_status SetPenalty(double rho) = 0;

@@ -213,7 +213,20 @@ struct DevArrays {
   int chain_lo, chain_hi;
   int chain_size;
   int chain_base[4];
+  // per-knot steps h[k] (k < N) and times t[k] (k <= N), 32-bit floats like the reference's KnotPoint (knotpoint.hpp:
+  // 179-180): nullptr for a uniform step and a time-invariant model (the hot kernels then use ProblemDesc::hstep);
+  // set by altro_set_steps / altro_set_times or by a time-varying user model -- see Engine::knot_times_
+  const float *hk, *tk;
 };
+// step and time of knot k (k wave-uniform where it matters: scalar loads)
+template <class T>
+ALTRO_DEV T step_of(const DevArrays<T>& A, const ProblemDesc* pd, int k) {
+  return A.hk ? T(A.hk[k]) : T(pd->hstep);
+}
+template <class T>
+ALTRO_DEV float time_of(const DevArrays<T>& A, int k) {
+  return A.tk ? A.tk[k] : 0.0f;
+}
 
 template <class T>
 ALTRO_DEV void sincos_(T x, T* s, T* c);
@@ -560,36 +573,62 @@ struct Quadrotor12M {
 // -------------------------------------------------------------------------------------------------
 // RK4 (altro/problem/integration.hpp:123-169); h is a 32-bit float promoted to T (quirk Q1)
 // -------------------------------------------------------------------------------------------------
+// Time-varying dynamics (ContinuousDynamics::Evaluate(x, u, t, xdot), altro/problem/dynamics.hpp:59-95): a model that
+// declares `static constexpr bool time_varying = true` takes the time as a 32-bit float, f(x, u, t, xdot) and
+// jac(x, u, t, J); every other model keeps the three-argument form and never sees t.
+template <class M, class = void>
+struct model_time_varying : std::false_type {};
+template <class M>
+struct model_time_varying<M, std::void_t<decltype(M::time_varying)>> : std::integral_constant<bool, M::time_varying> {};
+template <class T, class M>
+ALTRO_DEV void model_f(const T* x, const T* u, float t, T* xd) {
+  if constexpr (model_time_varying<M>::value) M::f(x, u, t, xd);
+  else M::f(x, u, xd);
+}
+template <class T, class M>
+ALTRO_DEV void model_jac(const T* x, const T* u, float t, T* J) {
+  if constexpr (model_time_varying<M>::value) M::jac(x, u, t, J);
+  else M::jac(x, u, J);
+}
+// stage times of RungeKutta4::Integrate (integration.hpp:126-129): `t + 0.5 * h` is evaluated in double (float
+// operands, double literal) and narrowed to the float parameter of Evaluate
+template <class T>
+ALTRO_DEV float stage_time(float t, T hh, double c) {
+  return (float)((double)t + c * (double)hh);
+}
+
 // Generic RK4 step.  Models may provide `rk4_fused` (same arithmetic, shared sub-expressions).
 template <class T, class M>
-ALTRO_DEV void rk4_step_generic(const T* x, const T* u, T hh, T* xn) {
+ALTRO_DEV void rk4_step_generic(const T* x, const T* u, T hh, T* xn, float t = 0.0f) {
   constexpr int n = M::n;
   T k1[n], k2[n], k3[n], k4[n], xt[n];
-  M::f(x, u, k1);
+  model_f<T, M>(x, u, t, k1);
 #pragma unroll
   for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
-  M::f(xt, u, k2);
+  model_f<T, M>(xt, u, stage_time(t, hh, 0.5), k2);
 #pragma unroll
   for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
-  M::f(xt, u, k3);
+  model_f<T, M>(xt, u, stage_time(t, hh, 0.5), k3);
 #pragma unroll
   for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
-  M::f(xt, u, k4);
+  model_f<T, M>(xt, u, stage_time(t, hh, 1.0), k4);
 #pragma unroll
   for (int i = 0; i < n; ++i) xn[i] = x[i] + hh * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
 }
 
 template <class T, class M>
-ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn) {
+ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn, float t = 0.0f) {
   if constexpr (M::kHasFusedRk4) {
     M::rk4_fused(x, u, hh, xn);
   } else {
-    rk4_step_generic<T, M>(x, u, hh, xn);
+    rk4_step_generic<T, M>(x, u, hh, xn, t);
   }
 }
 
+// RungeKutta4::Jacobian (integration.hpp:132-169).  The reference evaluates the two middle Jacobians at time 0.5 * t
+// and the last one at t (not t + h): reproduced for time-varying models (integration.hpp:144-150).
 template <class T, class M>
-ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J) {
+ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   if constexpr (M::kHasFusedJacobian) {
     M::rk4_jac_fused(x, u, hh, J);
@@ -598,15 +637,15 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J) {
   T k1[n], k2[n], k3[n], xt[n];
   T Jc[n * nm];
   T dA[n * n], dB[n * m], sA[n * n], sB[n * m];
-  M::f(x, u, k1);
+  model_f<T, M>(x, u, t, k1);
 #pragma unroll
   for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
-  M::f(xt, u, k2);
+  model_f<T, M>(xt, u, stage_time(t, hh, 0.5), k2);
 #pragma unroll
   for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
-  M::f(xt, u, k3);
+  model_f<T, M>(xt, u, stage_time(t, hh, 0.5), k3);
   // stage 0
-  M::jac(x, u, Jc);
+  model_jac<T, M>(x, u, t, Jc);
 #pragma unroll
   for (int e = 0; e < n * n; ++e) {
     dA[e] = Jc[e] * hh;
@@ -632,7 +671,7 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J) {
 #pragma unroll
       for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
     }
-    M::jac(xt, u, Jc);
+    model_jac<T, M>(xt, u, (s == 3) ? t : (float)(0.5 * (double)t), Jc);
     T Mx[n * n], nA[n * n], nB[n * m];
 #pragma unroll
     for (int j = 0; j < n; ++j)

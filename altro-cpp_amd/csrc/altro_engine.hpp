@@ -142,6 +142,54 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(CopySync(d_pd_, &pd_, sizeof(pd_), hipMemcpyHostToDevice));
     return ALTRO_OK;
   }
+  // Trajectory::SetStep(k, h) / SetTime(k, t) (trajectory.hpp:119-120) and time-varying user models
+  // (ContinuousDynamics::Evaluate(x, u, t, xdot), dynamics.hpp:59-95).  The hot kernels are built around one step for the
+  // whole horizon (ProblemDesc::hstep: a loop invariant of the rollout wave, of the fused RK4 and of the persistent
+  // kernel); a trajectory with its own steps or a model that reads the time takes the general path instead -- the
+  // expansions / initial rollout read h[k], t[k] per knot, the forward pass runs on k_forward (one wave per three
+  // instances, inputs from global memory) and the persistent tail kernel is not used.  Same schedule, same results as
+  // the oracle (tests/test_knot_times_gpu.py); slower per iteration.
+  altro_status SetKnotTimes(const ProblemSpec& s, std::string* err) override {
+    altro_status st = SetKnotTimesImpl(s);
+    if (st != ALTRO_OK && err) *err = err_;
+    return st;
+  }
+  altro_status SetKnotTimesImpl(const ProblemSpec& s) {
+    if (!uploaded_) return ALTRO_OK;  // Upload takes them from the spec
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    const bool per_knot = !s.hk.empty() || kTimeVarying;
+    if (!per_knot) {
+      A_.hk = nullptr;
+      A_.tk = nullptr;
+      return ALTRO_OK;
+    }
+    std::vector<float> hk(N_ + 1, 0.0f), tk(N_ + 1, 0.0f);
+    for (int k = 0; k < N_; ++k) hk[k] = s.hk.empty() ? s.hstep : s.hk[k];
+    if (!s.tk.empty()) {
+      for (int k = 0; k <= N_; ++k) tk[k] = s.tk[k];
+    } else if (s.hk.empty()) {  // SetUniformStep (trajectory.hpp:122-130)
+      for (int k = 0; k < N_; ++k) tk[k] = static_cast<float>(k) * s.hstep;
+      tk[N_] = s.hstep * N_;
+    }  // (steps without times: the times stay zero, as Trajectory::SetStep leaves them)
+    for (int k = 0; k < N_; ++k)
+      if (!(hk[k] > 0.0f)) {
+        err_ = "the integration step of knot " + std::to_string(k) + " is not set (Trajectory::SetStep / SetUniformStep)";
+        return ALTRO_NOT_READY;
+      }
+    if (!d_hk_) {
+      altro_status as = Alloc(&d_hk_, (size_t)N_ + 1);
+      if (as != ALTRO_OK) return as;
+      as = Alloc(&d_tk_, (size_t)N_ + 1);
+      if (as != ALTRO_OK) return as;
+    }
+    ALTRO_HIP_CHECK(CopySync(d_hk_, hk.data(), hk.size() * sizeof(float), hipMemcpyHostToDevice));
+    ALTRO_HIP_CHECK(CopySync(d_tk_, tk.data(), tk.size() * sizeof(float), hipMemcpyHostToDevice));
+    A_.hk = d_hk_;
+    A_.tk = d_tk_;
+    return ALTRO_OK;
+  }
   altro_status ResetTrajectory() override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
@@ -486,14 +534,14 @@ class Engine final : public EngineBase {
   // per workgroup, no cost-to-go recording and at most 20 line-search trials.
   bool FusedOk(const DevOpts& d) const {
     if constexpr (!kMfmaBackward) return false;
-    return !force_valu_backward_ && !no_fused_ && mfma_offsets_ok_ && fwd_lds_bytes_ > 0 && !A_.record_ctg &&
+    return !force_valu_backward_ && !no_fused_ && mfma_offsets_ok_ && fwd_lds_bytes_ > 0 && !A_.record_ctg && !A_.hk &&
            d.line_search_max_iterations <= kLineSearchLanes && fused_lds_bytes_ <= 160 * 1024;
   }
   // Forward pass launch: instances per wavefront and the LDS-staged variant are chosen from the size
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst, int ninst_all_chains = -1) {
     PoisonLds();
-    if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes) {
+    if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes && !A.hk) {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
       // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
       // epilogue of the kernel (staging, winner copy) shrink with the instances per workgroup.
@@ -516,12 +564,13 @@ class Engine final : public EngineBase {
     }
     const dim3 grid((ninst + fwd_per_wave_ - 1) / fwd_per_wave_);
     {
-      // fallback: single wave, reads from HBM (staged block larger than LDS, or > 20 line-search trials)
+      // fallback: single wave, reads from HBM (staged block larger than LDS, > 20 line-search trials, or per-knot
+      // steps / times: SetKnotTimes)
       hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, cur_, A, d_pd_, d, mode, all, fwd_per_wave_);
     }
   }
   bool StepOk() {
-    if (pd_.hstep > 0.0f) return true;
+    if (pd_.hstep > 0.0f || A_.hk) return true;
     err_ = "the integration step is not set (altro_set_uniform_step / Trajectory::SetUniformStep)";
     return false;
   }
@@ -1218,6 +1267,8 @@ class Engine final : public EngineBase {
     if (st != ALTRO_OK) return st;
     st = SetInitialStateImpl(s);
     if (st != ALTRO_OK) return st;
+    st = SetKnotTimesImpl(s);
+    if (st != ALTRO_OK) return st;
     return SetTrajectoryImpl(s);
 #undef ALTRO_ALLOC
   }
@@ -1548,6 +1599,8 @@ class Engine final : public EngineBase {
   }
 
   static constexpr int kNumScalarT = 15, kNumScalarI = 7;
+  static constexpr bool kTimeVarying = model_time_varying<M>::value;
+  float *d_hk_ = nullptr, *d_tk_ = nullptr;  // per-knot steps / times (SetKnotTimes), owned through allocs_
   altro_desc desc_;
   int B_ = 0, Bp_ = 0, N_ = 0;
   bool uploaded_ = false;

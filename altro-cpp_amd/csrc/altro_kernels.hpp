@@ -121,7 +121,7 @@ ALTRO_DEV T expansion_body(const DevArrays<T>& A, const ProblemDesc* __restrict_
   const T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
                                            E + R::oLuu);
   A.costs[(unsigned)k * Bp + (unsigned)b] = J;
-  if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
+  if (k < N) rk4_jacobian<T, M>(xr, ur, step_of(A, pd, k), E + R::oAB, time_of(A, k));
   store_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP((RS*)A.EXP, k, RR::EP), E);
   return J;
 }
@@ -1234,13 +1234,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(DevArrays<T> A, const Proble
   if (b >= A.B) return;
   if (!all && A.phase[b] != 1) return;
   const unsigned Bp = A.Bp;
-  const T hh = T(pd->hstep);
   T x[R::nP], u[R::mP], xn[n];
   load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x);
   for (int k = 0; k < A.N; ++k) {
     store_rec<T, R::nP>(RECP(A.X, k, R::nP), x);
     load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
-    rk4_step<T, M>(x, u, hh, xn);
+    rk4_step<T, M>(x, u, step_of(A, pd, k), xn, time_of(A, k));
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = xn[i];
   }
@@ -1860,7 +1859,7 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
 #pragma unroll
         for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
       }
-      rk4_step<T, M>(xb, ub, hh, xn);
+      rk4_step<T, M>(xb, ub, A.hk ? T(A.hk[k]) : hh, xn, time_of(A, k));  // (per-knot steps / times: this kernel only)
       if (check_bounds) {
         // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2 (ilqr.hpp:484-495), no sqrt needed
         T sx = T(0), su = T(0);

@@ -169,16 +169,37 @@ template <int n, int m>
 class Trajectory {
  public:
   explicit Trajectory(int N, int batch = 1)
-      : N_(N), B_(batch), X_((size_t)batch * (N + 1) * n, 0.0), U_((size_t)batch * N * m, 0.0), h_(0.0f) {}
+      : N_(N), B_(batch), X_((size_t)batch * (N + 1) * n, 0.0), U_((size_t)batch * N * m, 0.0), h_((size_t)N + 1, 0.0f),
+        t_((size_t)N + 1, 0.0f) {}
   int NumSegments() const { return N_; }
   int BatchSize() const { return B_; }
   double* State(int k, int b = 0) { return &X_[((size_t)b * (N_ + 1) + k) * n]; }
   double* Control(int k, int b = 0) { return &U_[((size_t)b * N_ + k) * m]; }
   const double* State(int k, int b = 0) const { return &X_[((size_t)b * (N_ + 1) + k) * n]; }
   const double* Control(int k, int b = 0) const { return &U_[((size_t)b * N_ + k) * m]; }
-  void SetUniformStep(float h) { h_ = h; }                        // trajectory.hpp:122-130
-  float GetStep(int k) const { return k < N_ ? h_ : 0.0f; }       // terminal knot has h = 0
-  float GetTime(int k) const { return k < N_ ? static_cast<float>(k) * h_ : h_ * N_; }
+  void SetUniformStep(float h) {                                  // trajectory.hpp:122-130
+    for (int k = 0; k < N_; ++k) {
+      h_[k] = h;
+      t_[k] = static_cast<float>(k) * h;
+    }
+    h_[N_] = 0.0f;  // terminal knot has h = 0
+    t_[N_] = h * N_;
+    uniform_ = true;
+  }
+  void SetStep(int k, float h) {                                  // trajectory.hpp:120
+    uniform_ = uniform_ && h_.at(k) == h;
+    h_.at(k) = h;
+  }
+  void SetTime(int k, float t) {                                  // trajectory.hpp:119
+    uniform_ = uniform_ && t_.at(k) == t;
+    t_.at(k) = t;
+  }
+  float GetStep(int k) const { return h_.at(k); }
+  float GetTime(int k) const { return t_.at(k); }
+  // every step and time is what SetUniformStep wrote (the solver then runs its uniform-step kernels)
+  bool IsUniformStep() const { return uniform_; }
+  const std::vector<float>& Steps() const { return h_; }
+  const std::vector<float>& Times() const { return t_; }
   void SetZero() {
     std::fill(X_.begin(), X_.end(), 0.0);
     std::fill(U_.begin(), U_.end(), 0.0);
@@ -189,7 +210,8 @@ class Trajectory {
  private:
   int N_, B_;
   std::vector<double> X_, U_;
-  float h_;
+  std::vector<float> h_, t_;  // per knot, 32-bit floats like KnotPoint::t_, h_ (knotpoint.hpp:179-180)
+  bool uniform_ = false;
 };
 
 // ---- descriptor types with the reference's class names --------------------------------------------
@@ -380,6 +402,16 @@ class Problem {
   void SetDynamics(const DiscretizedModel<Model>& dm, int k) {
     Range(k);
     if (k >= N_) throw std::runtime_error("dynamics are set on knots 0..N-1");
+    // The reference keeps one model PER KNOT (models_[k], problem.hpp:155-166).  A handle of this build carries one model
+    // for the whole horizon: setting a different one on another knot would silently solve the wrong dynamics, so it
+    // is refused.  Dynamics that change along the horizon are written as ONE time-varying user model
+    // (`static constexpr bool time_varying = true`; f(x, u, t, xdot) switches on the knot time t).
+    bool any = false;
+    for (int j = 0; j < N_; ++j) any = any || has_dyn_[j];
+    if (any && (model_kind_ != dm.model.Kind() || model_params_ != dm.model.Params()))
+      throw std::runtime_error("Problem::SetDynamics: a different model on knot " + std::to_string(k) +
+                               " -- one model per problem (use a time-varying user model for dynamics that change "
+                               "along the horizon)");
     model_kind_ = dm.model.Kind();
     model_params_ = dm.model.Params();
     n_ = dm.model.StateDimension();
@@ -739,7 +771,12 @@ class iLQR {
     if (c_->traj && !c_->pushed) {
       auto& Z = *c_->traj;
       if (Z.BatchSize() != c_->B || Z.NumSegments() != c_->N) throw std::runtime_error("Trajectory size isn't consistent with the solver.");
-      if (Z.GetStep(0) > 0.0f) detail::Check(c_->h, altro_set_uniform_step(c_->h, Z.GetStep(0)), "altro_set_uniform_step");
+      if (Z.IsUniformStep()) {
+        if (Z.GetStep(0) > 0.0f) detail::Check(c_->h, altro_set_uniform_step(c_->h, Z.GetStep(0)), "altro_set_uniform_step");
+      } else if (Z.GetStep(0) > 0.0f) {  // Trajectory::SetStep / SetTime per knot (trajectory.hpp:119-120)
+        detail::Check(c_->h, altro_set_steps(c_->h, Z.Steps().data(), Z.NumSegments()), "altro_set_steps");
+        detail::Check(c_->h, altro_set_times(c_->h, Z.Times().data(), Z.NumSegments() + 1), "altro_set_times");
+      }
       detail::Check(c_->h, altro_set_trajectory(c_->h, Z.States().data(), Z.Controls().data(), 1), "altro_set_trajectory");
       c_->pushed = true;
     }

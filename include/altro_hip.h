@@ -223,10 +223,29 @@ altro_status altro_set_model(altro_handle h, int kind, const double* params, int
  * functionbase.cpp:42-125).  At the terminal knot u is the zero vector, as in the reference. */
 altro_status altro_register_model_source(const char* name, const char* source, int check_jacobian, int* kind_out);
 
+/* Path of the compiled plugin of a registered user model (the on-disk cache entry: <cache>/altro_user_<hash>.so, next
+ * to its generated .hip and the compiler's .log).  Returns the length of the path, -1 for an unknown kind.  A deployment
+ * prunes its cache directory with it: everything that is not the path of a model it registers is stale. */
+int altro_user_model_path(int kind, char* buf, int len);
+
 /* Trajectory::SetUniformStep (trajectory.hpp:122-130).  hstep > 0.  Belongs to the trajectory, not to the
  * problem definition: may be called at any time (also between solves).  Calls that integrate (rollout,
  * expansions, forward pass, solves) return ALTRO_NOT_READY until a step has been set. */
 altro_status altro_set_uniform_step(altro_handle h, float hstep);
+
+/* Trajectory::SetStep(k, h) for k = 0 .. N-1 and Trajectory::SetTime(k, t) for k = 0 .. N (trajectory.hpp:119-120;
+ * per-knot float h, t in knotpoint.hpp:179-180): `count` must be N resp. N + 1.  Like SetUniformStep they belong to the
+ * trajectory and may change between solves; altro_set_uniform_step afterwards overwrites both again.  Steps without
+ * times leave the times as they were (zero if never set).  The times only matter to a time-varying user model
+ * (`static constexpr bool time_varying = true`: f(x, u, t, xdot), jac(x, u, t, J) with a 32-bit float t -- the
+ * counterpart of ContinuousDynamics::Evaluate(x, u, t, xdot), dynamics.hpp:59-95; RungeKutta4's stage times
+ * t, t + h/2, t + h/2, t + h and its Jacobian times t, t/2, t/2, t are the reference's, integration.hpp:123-150).
+ * A trajectory with per-knot steps (or a time-varying model) runs on the solver's general kernels: same results and
+ * schedule as the reference, without the fused persistent path.
+ * altro_get_steps copies the steps [N] and times [N + 1] back (either pointer may be NULL). */
+altro_status altro_set_steps(altro_handle h, const float* hk, int count);
+altro_status altro_set_times(altro_handle h, const float* tk, int count);
+altro_status altro_get_steps(altro_handle h, float* hk, float* tk);
 
 /* Problem::SetCostFunction(QuadraticCost::LQRCost(Q,R,xref,uref,terminal), k) for
  * k_begin <= k < k_end (problem.hpp:113-127, examples/quadratic_cost.hpp:29-39).

@@ -37,6 +37,7 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 
 #include "../include/altro_hip.h"  // POD structs and enums only
 
@@ -136,12 +137,27 @@ using std::cos;
 using std::sin;
 #include ORACLE_USER_MODEL
 }  // namespace altro_user
+template <class U, class = void>
+struct UserTimeVarying : std::false_type {};
+template <class U>
+struct UserTimeVarying<U, std::void_t<decltype(U::time_varying)>> : std::integral_constant<bool, U::time_varying> {};
 template <class T>
 struct UserModelAdapter {
   static constexpr int n = altro_user::UserModel::n, m = altro_user::UserModel::m;
+  static constexpr bool time_varying = UserTimeVarying<altro_user::UserModel>::value;
   int dof = 0;
-  void f(const T* x, const T* u, T* xd) const { altro_user::UserModel::f(x, u, xd); }
-  void jac(const T* x, const T* u, T* J) const { altro_user::UserModel::jac(x, u, J); }
+  void f(const T* x, const T* u, T* xd) const {
+    if constexpr (!time_varying) altro_user::UserModel::f(x, u, xd);
+  }
+  void jac(const T* x, const T* u, T* J) const {
+    if constexpr (!time_varying) altro_user::UserModel::jac(x, u, J);
+  }
+  void f(const T* x, const T* u, float t, T* xd) const {
+    if constexpr (time_varying) altro_user::UserModel::f(x, u, t, xd);
+  }
+  void jac(const T* x, const T* u, float t, T* J) const {
+    if constexpr (time_varying) altro_user::UserModel::jac(x, u, t, J);
+  }
 };
 #endif
 template <class M>
@@ -262,6 +278,23 @@ struct SolverBase {
   altro_options opts;
 };
 
+// Time-varying dynamics (ContinuousDynamics::Evaluate(x, u, t, xdot), altro/problem/dynamics.hpp:59-95): a model that
+// declares `static constexpr bool time_varying = true` takes a float time; the others never see it.
+template <class M, class = void>
+struct ModelTimeVarying : std::false_type {};
+template <class M>
+struct ModelTimeVarying<M, std::void_t<decltype(M::time_varying)>> : std::integral_constant<bool, M::time_varying> {};
+template <class M, class T>
+void ModelF(const M& mdl, const T* x, const T* u, float t, T* xd) {
+  if constexpr (ModelTimeVarying<M>::value) mdl.f(x, u, t, xd);
+  else mdl.f(x, u, xd);
+}
+template <class M, class T>
+void ModelJac(const M& mdl, const T* x, const T* u, float t, T* J) {
+  if constexpr (ModelTimeVarying<M>::value) mdl.jac(x, u, t, J);
+  else mdl.jac(x, u, J);
+}
+
 // ------------------------------------------------------------------------------------------------
 // One problem instance.
 // ------------------------------------------------------------------------------------------------
@@ -271,6 +304,7 @@ struct Instance final : SolverBase {
   Model model;
   int N;
   std::vector<float> h;  // N+1 entries, h[N] = 0 (trajectory.hpp:122-130)
+  std::vector<float> tm;  // N+1 knot times (KnotPoint::t_, knotpoint.hpp:179)
 
   struct QCost {  // examples/quadratic_cost.hpp:13-27
     T Q[n * n], R[m * m], H[n * m], q[n], r[m], c;
@@ -317,6 +351,7 @@ struct Instance final : SolverBase {
 
   Instance(int N_, const Model& mdl) : model(mdl), N(N_) {
     h.assign(N + 1, 0.0f);
+    tm.assign(N + 1, 0.0f);
     cost.resize(N + 1);
     cons.resize(N + 1);
     x0.assign(n, T(0));
@@ -605,35 +640,39 @@ struct Instance final : SolverBase {
 
   // ---- dynamics ------------------------------------------------------------------------------
   // RungeKutta4::Integrate, altro/problem/integration.hpp:123-131
-  void Dynamics(const T* x, const T* u, float hf, T* xn) const {
+  // (the stage times: `t + 0.5 * h` with float t, h is evaluated in double and narrowed to Evaluate's float parameter)
+  void Dynamics(const T* x, const T* u, float hf, T* xn, float t = 0.0f) const {
     const T hh = T(hf);
+    const float th = (float)((double)t + 0.5 * (double)hf), t1 = (float)((double)t + (double)hf);
     T k1[n], k2[n], k3[n], k4[n], xt[n];
-    model.f(x, u, k1);
+    ModelF(model, x, u, t, k1);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
-    model.f(xt, u, k2);
+    ModelF(model, xt, u, th, k2);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
-    model.f(xt, u, k3);
+    ModelF(model, xt, u, th, k3);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
-    model.f(xt, u, k4);
+    ModelF(model, xt, u, t1, k4);
     for (int i = 0; i < n; ++i) xn[i] = x[i] + hh * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
   }
   // RungeKutta4::Jacobian, integration.hpp:132-169
-  void DynamicsJacobian(const T* x, const T* u, float hf, T* J) const {
+  // (the middle Jacobians are taken at time 0.5 * t and the last one at t -- integration.hpp:144-150, as written)
+  void DynamicsJacobian(const T* x, const T* u, float hf, T* J, float t = 0.0f) const {
     const T hh = T(hf);
+    const float th = (float)((double)t + 0.5 * (double)hf), tj = (float)(0.5 * (double)t);
     T k1[n], k2[n], k3[n], xt[n];
     T Jc[4][n * nm];
-    model.f(x, u, k1);
+    ModelF(model, x, u, t, k1);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
-    model.f(xt, u, k2);
+    ModelF(model, xt, u, th, k2);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] * T(0.5) * hh;
-    model.f(xt, u, k3);
-    model.jac(x, u, Jc[0]);
+    ModelF(model, xt, u, th, k3);
+    ModelJac(model, x, u, t, Jc[0]);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k1[i] * hh;
-    model.jac(xt, u, Jc[1]);
+    ModelJac(model, xt, u, tj, Jc[1]);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + T(0.5) * k2[i] * hh;
-    model.jac(xt, u, Jc[2]);
+    ModelJac(model, xt, u, tj, Jc[2]);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i] * hh;
-    model.jac(xt, u, Jc[3]);
+    ModelJac(model, xt, u, t, Jc[3]);
     const T* A[4];
     const T* B[4];
     for (int s = 0; s < 4; ++s) {
@@ -687,7 +726,7 @@ struct Instance final : SolverBase {
   // iLQR::Rollout, ilqr.hpp:453-459
   void Rollout() override {
     for (int i = 0; i < n; ++i) X[i] = x0[i];
-    for (int k = 0; k < N; ++k) Dynamics(&X[k * n], &U[k * m], h[k], &X[(k + 1) * n]);
+    for (int k = 0; k < N; ++k) Dynamics(&X[k * n], &U[k * m], h[k], &X[(k + 1) * n], tm[k]);
   }
   // iLQR::Cost / CalcIndividualCosts, ilqr.hpp:326-334, 758-763
   T CostOf(const std::vector<T>& Xs, const std::vector<T>& Us) {
@@ -706,7 +745,7 @@ struct Instance final : SolverBase {
       const T* x = &X[k * n];
       const T* u = &U[k * m];
       CostExpansion(k, x, u);
-      if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm]);
+      if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm], tm[k]);
       costs[k] = KnotCost(k, x, u);
       if (round_records) {
         RoundRec(&AB[k * n * nm], n * nm);
@@ -911,7 +950,7 @@ struct Instance final : SolverBase {
         for (int l = 0; l < n; ++l) s += Kk[i + l * m] * dx[l];
         Ub[k * m + i] = U[k * m + i] + s + dk[i] * alpha;
       }
-      Dynamics(&Xb[k * n], &Ub[k * m], h[k], &Xb[(k + 1) * n]);
+      Dynamics(&Xb[k * n], &Ub[k * m], h[k], &Xb[(k + 1) * n], tm[k]);
       if (opts.check_forwardpass_bounds) {
         T sx = 0, su = 0;
         for (int i = 0; i < n; ++i) sx += Xb[(k + 1) * n + i] * Xb[(k + 1) * n + i];
@@ -1215,6 +1254,7 @@ struct oracle_solver_s {
   int model_kind = 0;
   int dof = 0;
   float hstep = 0.0f;
+  std::vector<float> hk, tk;  // per-knot steps [N] / times [N + 1] (Trajectory::SetStep / SetTime); empty: uniform
   std::vector<CostSpec> costs;
   std::vector<ConSpec> cons;
   std::vector<double> x0;
@@ -1232,11 +1272,24 @@ struct oracle_solver_s {
   // CPU-baseline runs (oracle_bench_*): wall time between the start barrier of the thread team and its last task,
   // the threads that ran and the slowest / fastest thread's busy time
   double bench_seconds = 0.0, bench_busy_min = 0.0, bench_busy_max = 0.0;
+  double bench_cpu_seconds = 0.0;  // CPU time the team's threads were actually given (CLOCK_THREAD_CPUTIME_ID, summed)
   int bench_threads = 0;
 };
 typedef oracle_solver_s* oracle_handle;
 
 namespace {
+
+// steps and times of the handle -> one instance (Trajectory::SetUniformStep, trajectory.hpp:122-130, or per knot)
+void ApplyKnotTimes(oracle_handle h, std::vector<float>& hv, std::vector<float>& tv) {
+  const int N = h->desc.N;
+  for (int k = 0; k < N; ++k) hv[k] = h->hk.empty() ? h->hstep : h->hk[k];
+  hv[N] = 0.0f;
+  for (int k = 0; k <= N; ++k) {
+    if (!h->tk.empty()) tv[k] = h->tk[k];
+    else if (!h->hk.empty()) tv[k] = 0.0f;
+    else tv[k] = k < N ? static_cast<float>(k) * h->hstep : h->hstep * N;
+  }
+}
 
 template <class T, class Model>
 std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& mdl) {
@@ -1244,8 +1297,7 @@ std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& md
   auto up = std::make_unique<Instance<T, Model>>(D.N, mdl);
   Instance<T, Model>& I = *up;
   constexpr int n = Model::n, m = Model::m;
-  for (int k = 0; k < D.N; ++k) I.h[k] = h->hstep;
-  I.h[D.N] = 0.0f;
+  ApplyKnotTimes(h, I.h, I.tm);
   for (const CostSpec& c : h->costs) {
     if (c.user) {
       const int np = UserCostF::nparams;
@@ -1384,7 +1436,12 @@ altro_status BenchRun(oracle_handle h, int reps, F solve_one, int stride = 1) {
   for (int b = 0; b < B; ++b) busy[b].store(0);
   using clk = std::chrono::steady_clock;
   clk::time_point t_start;
-  std::vector<double> t_end(nt, 0.0), t_busy(nt, 0.0);
+  std::vector<double> t_end(nt, 0.0), t_busy(nt, 0.0), t_cpu(nt, 0.0);
+  auto thread_cpu = []() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+  };
   auto body = [&](int t) {
     cpu_set_t one;
     CPU_ZERO(&one);
@@ -1393,6 +1450,7 @@ altro_status BenchRun(oracle_handle h, int reps, F solve_one, int stride = 1) {
     if (arrived.fetch_add(1) + 1 == nt) t_start = clk::now();  // the last thread to arrive starts the clock ...
     while (arrived.load() < nt) std::this_thread::yield();      // ... and releases the team
     const clk::time_point t0 = clk::now();
+    const double c0 = thread_cpu();
     for (;;) {
       const long long i = next.fetch_add(1);
       if (i >= tasks) break;
@@ -1410,6 +1468,7 @@ altro_status BenchRun(oracle_handle h, int reps, F solve_one, int stride = 1) {
       busy[b].store(0, std::memory_order_release);
     }
     const clk::time_point t1 = clk::now();
+    t_cpu[t] = thread_cpu() - c0;
     t_busy[t] = std::chrono::duration<double>(t1 - t0).count();
     t_end[t] = std::chrono::duration<double>(t1.time_since_epoch()).count();
   };
@@ -1422,6 +1481,8 @@ altro_status BenchRun(oracle_handle h, int reps, F solve_one, int stride = 1) {
   h->bench_busy_max = *std::max_element(t_busy.begin(), t_busy.end());
   h->bench_busy_min = *std::min_element(t_busy.begin(), t_busy.end());
   h->bench_threads = nt;
+  h->bench_cpu_seconds = 0.0;
+  for (double c : t_cpu) h->bench_cpu_seconds += c;
   // (the calling thread was pinned for the run: give it its mask back)
   cpu_set_t all;
   CPU_ZERO(&all);
@@ -1485,7 +1546,33 @@ altro_status oracle_set_model(oracle_handle h, int kind, const double* params, i
 }
 altro_status oracle_set_uniform_step(oracle_handle h, float hstep) {
   h->hstep = hstep;
+  h->hk.clear();
+  h->tk.clear();
   h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_steps(oracle_handle h, const float* hk, int count) {  // Trajectory::SetStep(k, h)
+  if (count != h->desc.N) return ALTRO_INVALID_ARG;
+  if (h->tk.empty() && h->hk.empty() && h->hstep > 0.0f) {
+    h->tk.resize(count + 1);
+    for (int k = 0; k < count; ++k) h->tk[k] = static_cast<float>(k) * h->hstep;
+    h->tk[count] = h->hstep * count;
+  }
+  h->hk.assign(hk, hk + count);
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_times(oracle_handle h, const float* tk, int count) {  // Trajectory::SetTime(k, t)
+  if (count != h->desc.N + 1) return ALTRO_INVALID_ARG;
+  h->tk.assign(tk, tk + count);
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_get_steps(oracle_handle h, float* hk, float* tk) {
+  std::vector<float> hv(h->desc.N + 1), tv(h->desc.N + 1);
+  ApplyKnotTimes(h, hv, tv);
+  for (int k = 0; k < h->desc.N && hk; ++k) hk[k] = hv[k];
+  for (int k = 0; k <= h->desc.N && tk; ++k) tk[k] = tv[k];
   return ALTRO_OK;
 }
 altro_status oracle_set_lqr_cost(oracle_handle h, int k_begin, int k_end, const double* Q,
@@ -1627,6 +1714,9 @@ altro_status oracle_prepare(oracle_handle h) {
 }
 double oracle_bench_seconds(oracle_handle h) { return h ? h->bench_seconds : 0.0; }
 int oracle_bench_threads(oracle_handle h) { return h ? h->bench_threads : 0; }
+// CPU time the threads of the last run were given, summed: well below threads x wall means the team was descheduled
+// (a CPU quota of the container, other tenants) -- the host figure is then bounded by that quota, not by the cores
+double oracle_bench_cpu_seconds(oracle_handle h) { return h ? h->bench_cpu_seconds : 0.0; }
 // busy time of the slowest (which = 1) / fastest (which = 0) thread of the last run: their ratio is the load balance
 double oracle_bench_busy(oracle_handle h, int which) { return h ? (which ? h->bench_busy_max : h->bench_busy_min) : 0.0; }
 // hardware threads this process may run on / distinct physical cores among them (sysfs topology)

@@ -299,8 +299,76 @@ static void UserFunctorTests() {
   EXPECT(seen);
 }
 
+// ---- Trajectory::SetStep / SetTime per knot (trajectory.hpp:119-120) and Problem::SetDynamics per knot ----------------
+static void KnotTimeTests() {
+  CASE("Trajectory::SetStep(k, h) on every knot: the general kernels reach the uniform-step solution (trajectory.hpp:119-130)");
+  {
+    problems::UnicycleProblem def;
+    auto pa = def.MakeALSolver();
+    auto pb = def.MakeALSolver();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>&a = *pa, &b = *pb;
+    auto Za = def.InitialTrajectory();
+    auto Zb = def.InitialTrajectory();
+    EXPECT(Za->IsUniformStep());
+    const int N = Zb->NumSegments();
+    for (int k = 0; k < N; ++k) Zb->SetStep(k, Za->GetStep(k) * (k == 0 ? 1.0f : 1.0f));
+    Zb->SetStep(0, Za->GetStep(0) * 2.0f);  // (leaves the uniform state) ...
+    Zb->SetStep(0, Za->GetStep(0));         // ... and the same values again: still handed over per knot
+    EXPECT(!Zb->IsUniformStep() && Zb->GetStep(N) == 0.0f && Zb->GetTime(3) == 3.0f * Za->GetStep(0));
+    a.SetTrajectory(Za);
+    b.SetTrajectory(Zb);
+    a.Solve();
+    b.Solve();
+    EXPECT(a.GetStatus() == SolverStatus::kSolved && b.GetStatus() == SolverStatus::kSolved);
+    EXPECT(a.GetStats().iterations_total == b.GetStats().iterations_total);
+    double worst = 0.0;
+    for (int k = 0; k <= N; ++k)
+      for (int i = 0; i < 3; ++i) worst = std::max(worst, std::abs(Za->State(k)[i] - Zb->State(k)[i]));
+    EXPECT(worst < 1e-9);
+    // a genuinely non-uniform grid (finer at the start) still solves, to a different trajectory
+    auto Zc = def.InitialTrajectory();
+    float t = 0.0f;
+    for (int k = 0; k < N; ++k) {
+      const float h = Za->GetStep(0) * (0.5f + static_cast<float>(k) / static_cast<float>(N - 1));
+      Zc->SetStep(k, h);
+      Zc->SetTime(k, t);
+      t += h;
+    }
+    Zc->SetTime(N, t);
+    auto pc = def.MakeALSolver();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& c = *pc;
+    c.SetTrajectory(Zc);
+    c.Solve();
+    EXPECT(c.GetStatus() == SolverStatus::kSolved && c.MaxViolation() < 1e-4);
+    double diff = 0.0;
+    for (int k = 0; k <= N; ++k) diff = std::max(diff, std::abs(Za->State(k)[0] - Zc->State(k)[0]));
+    EXPECT(diff > 1e-3);
+  }
+  CASE("Problem::SetDynamics with a different model on another knot is refused (problem.hpp:155-166 keeps one per knot)");
+  {
+    problem::Problem prob(10);
+    prob.SetDynamics(problem::DiscretizedModel<examples::TripleIntegrator>(examples::TripleIntegrator(1)), 0);
+    prob.SetDynamics(problem::DiscretizedModel<examples::TripleIntegrator>(examples::TripleIntegrator(1)), 1);  // same model: fine
+    bool threw = false;
+    try {
+      prob.SetDynamics(problem::DiscretizedModel<examples::TripleIntegrator>(examples::TripleIntegrator(2)), 2);
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+      prob.SetDynamics(problem::DiscretizedModel<examples::Unicycle>(examples::Unicycle()), 3);
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+  }
+}
+
 int main() {
   try {
+    KnotTimeTests();
     UnicycleiLQRTest();
     AugLagTest();
     ExampleTests();
