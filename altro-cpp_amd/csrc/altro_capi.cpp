@@ -43,7 +43,7 @@ struct altro_solver_s {
   // cannot change options, inputs or device buffers under the solve in flight.
   std::thread worker;
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv, cv_done;
   bool job_posted = false, worker_exit = false;
   std::atomic<int> async_done{1};
   bool async_pending = false;
@@ -629,7 +629,11 @@ altro_status altro_solve_al_async(altro_handle h) {
         // the engine and the options are frozen while async_pending is set (Busy() guards every setter)
         h->async_status = h->engine->SolveAL(h->opts);
         if (h->async_status != ALTRO_OK) h->async_err = h->engine->LastError();
-        h->async_done.store(1, std::memory_order_release);
+        {
+          std::lock_guard<std::mutex> lk(h->mu);  // (the flag changes under the mutex: altro_wait cannot miss the wake-up)
+          h->async_done.store(1, std::memory_order_release);
+        }
+        h->cv_done.notify_all();
       }
     });
   }
@@ -653,7 +657,11 @@ altro_status altro_wait(altro_handle h) {
     h->err = "no asynchronous solve is pending";
     return ALTRO_NOT_READY;
   }
-  while (!h->async_done.load(std::memory_order_acquire)) std::this_thread::yield();
+  {
+    // blocks on a condition variable (the atomic alone serves altro_solve_poll): a waiting caller costs no core
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->cv_done.wait(lk, [h]() { return h->async_done.load(std::memory_order_acquire) != 0; });
+  }
   h->async_pending = false;
   if (h->async_status != ALTRO_OK) h->err = h->async_err;
   return h->async_status;

@@ -1,0 +1,250 @@
+// altro_group.cpp — libaltro_group.so: the multi-GPU result exchange for single-process C / C++ callers
+// (include/altro_group.h).  One RCCL communicator per device of the node (ncclCommInitAll),
+// one all-gather of 32-byte records per solve; the solves themselves run through the C-ABI of libaltro_hip.so.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/altro_group.h"
+
+struct altro_group_s {
+  std::vector<int> dev;
+  std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> stream;
+  std::vector<altro_handle> handle;
+  std::vector<int> batch;
+  std::vector<double*> d_send;  // [slot][4] records of the part, padded to the largest part
+  std::vector<double*> d_recv;  // [ndev][slot][4]
+  std::vector<double> part_ms;
+  double gather_ms = 0.0;
+  int slot = 0;  // records per part in the gather buffers (= largest batch)
+  bool comms_ok = false;
+  std::string err;
+};
+
+namespace {
+std::string g_create_err;
+
+#define GROUP_HIP(expr)                                                                                      \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      g->err = std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " #expr " -> " + hipGetErrorString(e_); \
+      return ALTRO_HIP_ERROR;                                                                                \
+    }                                                                                                        \
+  } while (0)
+#define GROUP_NCCL(expr)                                                                                      \
+  do {                                                                                                        \
+    ncclResult_t r_ = (expr);                                                                                 \
+    if (r_ != ncclSuccess) {                                                                                  \
+      g->err = std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " #expr " -> " + ncclGetErrorString(r_); \
+      return ALTRO_HIP_ERROR;                                                                                 \
+    }                                                                                                         \
+  } while (0)
+
+void FreeBuffers(altro_group g) {
+  for (size_t i = 0; i < g->dev.size(); ++i) {
+    if (hipSetDevice(g->dev[i]) != hipSuccess) continue;
+    if (g->d_send[i]) hipFree(g->d_send[i]);
+    if (g->d_recv[i]) hipFree(g->d_recv[i]);
+    g->d_send[i] = g->d_recv[i] = nullptr;
+  }
+  g->slot = 0;
+}
+
+altro_status EnsureBuffers(altro_group g) {
+  const int ndev = (int)g->dev.size();
+  int slot = 0;
+  for (int i = 0; i < ndev; ++i) {
+    if (!g->handle[i]) {
+      g->err = "part " + std::to_string(i) + " has no handle attached (altro_group_attach)";
+      return ALTRO_NOT_READY;
+    }
+    slot = std::max(slot, g->batch[i]);
+  }
+  if (slot == g->slot) return ALTRO_OK;
+  FreeBuffers(g);
+  for (int i = 0; i < ndev; ++i) {
+    GROUP_HIP(hipSetDevice(g->dev[i]));
+    GROUP_HIP(hipMalloc((void**)&g->d_send[i], (size_t)slot * 4 * sizeof(double)));
+    GROUP_HIP(hipMalloc((void**)&g->d_recv[i], (size_t)ndev * slot * 4 * sizeof(double)));
+    GROUP_HIP(hipMemsetAsync(g->d_send[i], 0, (size_t)slot * 4 * sizeof(double), g->stream[i]));
+    GROUP_HIP(hipStreamSynchronize(g->stream[i]));
+  }
+  g->slot = slot;
+  return ALTRO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void altro_group_shard_range(int total, int parts, int part, int* lo, int* hi) {
+  if (parts < 1) parts = 1;
+  const int base = total / parts, rem = total % parts;
+  const int l = part * base + std::min(part, rem);
+  if (lo) *lo = l;
+  if (hi) *hi = l + base + (part < rem ? 1 : 0);
+}
+
+altro_status altro_group_create(const int* device_ids, int ndev, altro_group* out) {
+  if (!device_ids || ndev < 1 || !out) return ALTRO_INVALID_ARG;
+  altro_group g = new altro_group_s();
+  g->dev.assign(device_ids, device_ids + ndev);
+  g->comm.assign(ndev, nullptr);
+  g->stream.assign(ndev, nullptr);
+  g->handle.assign(ndev, nullptr);
+  g->batch.assign(ndev, 0);
+  g->d_send.assign(ndev, nullptr);
+  g->d_recv.assign(ndev, nullptr);
+  g->part_ms.assign(ndev, 0.0);
+  auto fail = [&](const std::string& what) {
+    g_create_err = what;
+    altro_group_destroy(g);
+    return ALTRO_HIP_ERROR;
+  };
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail("no HIP device (the product has no CPU path)");
+  for (int i = 0; i < ndev; ++i) {
+    if (device_ids[i] < 0 || device_ids[i] >= have) return fail("device id " + std::to_string(device_ids[i]) + " out of range");
+    if (hipSetDevice(device_ids[i]) != hipSuccess || hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking) != hipSuccess)
+      return fail("cannot create a stream on device " + std::to_string(device_ids[i]));
+  }
+  // (after the solver handles' own streams where the caller created those first: the collective's streams then queue up
+  //  behind the solver's hardware queues and not the other way round -- DESIGN.md section 6)
+  const ncclResult_t r = ncclCommInitAll(g->comm.data(), ndev, g->dev.data());
+  if (r != ncclSuccess) return fail(std::string("ncclCommInitAll -> ") + ncclGetErrorString(r));
+  g->comms_ok = true;
+  *out = g;
+  return ALTRO_OK;
+}
+
+int altro_group_size(altro_group g) { return g ? (int)g->dev.size() : 0; }
+int altro_group_total(altro_group g) {
+  int t = 0;
+  if (g)
+    for (int b : g->batch) t += b;
+  return t;
+}
+
+altro_status altro_group_attach(altro_group g, int part, altro_handle h, int batch) {
+  if (!g || !h || part < 0 || part >= (int)g->dev.size() || batch < 1) return ALTRO_INVALID_ARG;
+  g->handle[part] = h;
+  g->batch[part] = batch;
+  return ALTRO_OK;
+}
+
+altro_status altro_group_gather(altro_group g) {
+  if (!g) return ALTRO_INVALID_ARG;
+  altro_status st = EnsureBuffers(g);
+  if (st != ALTRO_OK) return st;
+  const int ndev = (int)g->dev.size();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < ndev; ++i) {
+    // (returns after the pack kernel has run on the handle's own stream)
+    st = altro_pack_results_device(g->handle[i], g->d_send[i]);
+    if (st != ALTRO_OK) {
+      g->err = std::string("altro_pack_results_device on part ") + std::to_string(i) + ": " + altro_last_error(g->handle[i]);
+      return st;
+    }
+  }
+  GROUP_NCCL(ncclGroupStart());
+  for (int i = 0; i < ndev; ++i) {
+    GROUP_HIP(hipSetDevice(g->dev[i]));
+    GROUP_NCCL(ncclAllGather(g->d_send[i], g->d_recv[i], (size_t)g->slot * 4, ncclDouble, g->comm[i], g->stream[i]));
+  }
+  GROUP_NCCL(ncclGroupEnd());
+  for (int i = 0; i < ndev; ++i) {
+    GROUP_HIP(hipSetDevice(g->dev[i]));
+    GROUP_HIP(hipStreamSynchronize(g->stream[i]));
+  }
+  g->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return ALTRO_OK;
+}
+
+altro_status altro_group_solve_al(altro_group g) {
+  if (!g) return ALTRO_INVALID_ARG;
+  const int ndev = (int)g->dev.size();
+  for (int i = 0; i < ndev; ++i)
+    if (!g->handle[i]) {
+      g->err = "part " + std::to_string(i) + " has no handle attached (altro_group_attach)";
+      return ALTRO_NOT_READY;
+    }
+  const auto t0 = std::chrono::steady_clock::now();
+  altro_status first = ALTRO_OK;
+  int launched = 0;
+  for (; launched < ndev; ++launched) {
+    const altro_status st = altro_solve_al_async(g->handle[launched]);  // one parked worker thread per handle
+    if (st != ALTRO_OK) {
+      first = st;
+      g->err = std::string("altro_solve_al_async on part ") + std::to_string(launched) + ": " + altro_last_error(g->handle[launched]);
+      break;
+    }
+  }
+  // wait in completion order (poll), so that part_ms is each part's own wall time
+  std::vector<char> done(ndev, 0);
+  for (int left = launched; left > 0;) {
+    for (int i = 0; i < launched; ++i) {
+      if (done[i]) continue;
+      int d = 0;
+      altro_solve_poll(g->handle[i], &d);
+      if (!d) continue;
+      const altro_status st = altro_wait(g->handle[i]);
+      g->part_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (st != ALTRO_OK && first == ALTRO_OK) {
+        first = st;
+        g->err = std::string("solve on part ") + std::to_string(i) + ": " + altro_last_error(g->handle[i]);
+      }
+      done[i] = 1;
+      --left;
+    }
+    if (left > 0) std::this_thread::yield();
+  }
+  if (first != ALTRO_OK) return first;
+  return altro_group_gather(g);
+}
+
+altro_status altro_group_get_results(altro_group g, int part, double* out, int capacity_records) {
+  if (!g || !out || part < 0 || part >= (int)g->dev.size()) return ALTRO_INVALID_ARG;
+  const int ndev = (int)g->dev.size();
+  if (capacity_records < altro_group_total(g)) {
+    g->err = "altro_group_get_results: the buffer holds fewer records than the global batch";
+    return ALTRO_INVALID_ARG;
+  }
+  if (!g->slot || !g->d_recv[part]) {
+    g->err = "nothing gathered yet (altro_group_solve_al / altro_group_gather)";
+    return ALTRO_NOT_READY;
+  }
+  std::vector<double> all((size_t)ndev * g->slot * 4);
+  GROUP_HIP(hipSetDevice(g->dev[part]));
+  GROUP_HIP(hipMemcpyAsync(all.data(), g->d_recv[part], all.size() * sizeof(double), hipMemcpyDeviceToHost, g->stream[part]));
+  GROUP_HIP(hipStreamSynchronize(g->stream[part]));
+  size_t o = 0;
+  for (int i = 0; i < ndev; ++i)  // trim the padding of the smaller parts
+    for (int r = 0; r < g->batch[i]; ++r, ++o)
+      for (int f = 0; f < 4; ++f) out[4 * o + f] = all[((size_t)i * g->slot + r) * 4 + f];
+  return ALTRO_OK;
+}
+
+double altro_group_part_ms(altro_group g, int part) {
+  return (g && part >= 0 && part < (int)g->part_ms.size()) ? g->part_ms[part] : 0.0;
+}
+double altro_group_gather_ms(altro_group g) { return g ? g->gather_ms : 0.0; }
+const char* altro_group_last_error(altro_group g) { return g ? g->err.c_str() : g_create_err.c_str(); }
+
+void altro_group_destroy(altro_group g) {
+  if (!g) return;
+  FreeBuffers(g);
+  for (size_t i = 0; i < g->dev.size(); ++i) {
+    if (g->comms_ok && g->comm[i]) ncclCommDestroy(g->comm[i]);
+    if (g->stream[i] && hipSetDevice(g->dev[i]) == hipSuccess) hipStreamDestroy(g->stream[i]);
+  }
+  delete g;
+}
+
+}  // extern "C"

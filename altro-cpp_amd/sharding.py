@@ -30,16 +30,17 @@ def result_records(stats):
     return out
 
 
-def pack_and_gather(solver, packed, gathered=None, dist=None):
+def pack_and_gather(solver, packed, gathered=None, dist=None, force_collective=False):
     """The result exchange of one step.
 
     The solver writes its [b][4] fp64 result records straight into ``packed`` -- memory of the rank's
     own device (a torch tensor on cuda:<local_rank>; host memory when the CPU oracle stands in for the
     device in the tests) -- and, with more than one rank, ONE ``all_gather_into_tensor`` assembles
     ``gathered`` = [world * b][4] on every rank.  Equal shard sizes (weak scaling); uneven shards go
-    through ``gather_variable``.  Returns the tensor that holds the global records."""
+    through ``gather_variable``.  Returns the tensor that holds the global records.  ``force_collective`` runs the
+    all-gather also in a group of one rank (the 1-GPU test of the RCCL path, tests/test_rccl_world1_gpu.py)."""
     solver.pack_results_device(packed.data_ptr())
-    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
         dist.all_gather_into_tensor(gathered, packed)
         return gathered
     return packed

@@ -189,24 +189,46 @@ def load_oracle():
     return lib
 
 
+def cpu_quota_cores():
+    """CPUs the container may use per wall second (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cfs_period_us), or None.
+    The GPU boxes expose all 256 hardware threads of the host but run the container under a quota (measured in round 3:
+    `1600000 100000` = 16 CPUs -- scripts/probe_cpu_scaling.py, profiles/r03_cpu_scaling.txt): more threads than the quota
+    are descheduled, which is what made round 2's 256-thread figure look like 6 % parallel efficiency."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
     """The oracle (kind "port": the literal Eigen path cannot be built here) on the host cores, on a
     bounded sample of the SAME workload.  Sound by construction: the instances are built outside the
     timed region (oracle_prepare), one warm-up pass touches every array, the threads are pinned (one per physical core
     first), the clock runs inside the library from the team's start barrier to its last task, and a task is one solve of
     one instance handed out repetition-major (the tail of the run is one straggler solve).  Two team sizes are timed --
-    one thread per physical core, and every hardware thread -- and the better one is `value`."""
+    one thread per usable core, and twice that (SMT / oversubscription) -- and the better one is `value`.  "Usable" honours
+    the container's CPU quota (cpu_quota_cores): threads beyond it only get descheduled."""
     lib = load_oracle()
+    lib.oracle_bench_cpu_seconds.restype = ctypes.c_double
     factory = getattr(P, cfg["factory"])
     ilqr = cfg["mode"] == "ilqr"
     obench = lib.oracle_bench_ilqr if ilqr else lib.oracle_bench_al
     omake = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, _lib=lib, _prefix="oracle_")  # noqa: E731
     hw = int(lib.oracle_host_threads())
     phys = int(lib.oracle_host_physical_cores())
+    quota = cpu_quota_cores()
+    usable = max(1, min(phys, int(round(quota)))) if quota else phys  # cores the team can really run on at once
     o = factory(omake, batch=B, dtype=A.F64, seed=seed)
     lib.oracle_prepare(o._h)
-    # warm-up + calibration: one pass over the batch on every hardware thread (also sizes the per-instance vectors)
-    lib.oracle_set_threads(o._h, ctypes.c_int(hw))
+    # warm-up + calibration: one pass over the batch (also sizes the per-instance vectors)
+    lib.oracle_set_threads(o._h, ctypes.c_int(min(hw, 2 * usable)))
     obench(o._h, ctypes.c_int(1))
     pass_s = lib.oracle_bench_seconds(o._h)
     st = o.get_stats()
@@ -227,9 +249,9 @@ def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
     iters1 = float(s1["iterations_total"][sel].sum())
     solved1 = float((s1["status"][sel] == 0).sum())
     runs = []
-    for nt in sorted({phys, hw}):
+    for nt in sorted({usable, min(hw, 2 * usable)}):
         lib.oracle_set_threads(o._h, ctypes.c_int(nt))
-        # ~budget/2 CPU-seconds per team size: reps from the calibration pass (pass_s wall on hw threads)
+        # ~budget/2 CPU-seconds per team size: reps from the single-thread cost of one pass
         est_cpu_s_per_pass = t1 * (iters_pass / max(iters1, 1.0))
         reps = int(max(1, min(512, round(0.5 * budget_cpu_s / max(est_cpu_s_per_pass, 1e-6)))))
         obench(o._h, ctypes.c_int(reps))
@@ -238,12 +260,15 @@ def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
                      "value": round(solved_pass * reps / sec, 2),
                      "iterations_per_s": round(iters_pass * reps / sec, 1),
                      "busy_min_s": round(lib.oracle_bench_busy(o._h, 0), 4),
-                     "busy_max_s": round(lib.oracle_bench_busy(o._h, 1), 4)})
+                     "busy_max_s": round(lib.oracle_bench_busy(o._h, 1), 4),
+                     # CPU time the team's threads were given / (threads x wall): < 1 = descheduled (quota, other tenants)
+                     "cpu_time_fraction": round(lib.oracle_bench_cpu_seconds(o._h) / (nt * sec), 3)})
     best = max(runs, key=lambda r: r["value"])
     it_rate_1 = iters1 / t1
     return {
         "value": best["value"], "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
         "physical_cores": phys, "hardware_threads": hw,
+        "cpu_quota_cores": quota, "usable_cores": usable,
         "sample": f"the same seeded {B}-instance workload (fp64) solved {best['reps']}x by {best['threads']} pinned host "
                   f"threads (one solve of one instance per task; instances built and warmed up outside the timed "
                   f"region; clock inside the library from the team's start barrier to its last task), "
@@ -251,8 +276,10 @@ def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
         "single_thread_value": round(solved1 / t1, 2),
         "single_thread_ms_per_ilqr_iter": round(1e3 / it_rate_1, 4),
         "single_thread_sample": f"every {idx_stride}th instance of the batch ({len(range(0, B, idx_stride))} solves)",
-        # per-iteration throughput of the team / (one thread's x physical cores): SMT and all-core clocks included
-        "parallel_efficiency": round(best["iterations_per_s"] / (it_rate_1 * phys), 4),
+        # per-iteration throughput of the team / (one thread's x the cores the container may use at once): SMT, all-core
+        # clocks and the other tenants of the host included
+        "parallel_efficiency": round(best["iterations_per_s"] / (it_rate_1 * usable), 4),
+        "parallel_efficiency_vs_physical_cores": round(best["iterations_per_s"] / (it_rate_1 * phys), 4),
         "teams": runs,
     }
 
@@ -375,6 +402,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the all-gather also with ONE rank: the 1-GPU test of the "
+                         "multi-GPU path (tests/test_rccl_world1_gpu.py); the line gains a `dist_check` key")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra key with BASELINE configs 1, 3, 4")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra key with batch-of-1/8/64 solve latencies")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -416,19 +446,23 @@ def main():
 
     solver = new_solver()
     solver.num_constraints()  # (creates the device state, and with it the solver's streams, before RCCL's and torch's)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = f"cuda:{local_rank}"
     packed = torch.empty((B, 4), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else packed
+    gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if use_dist else packed
 
     def solve(s_):
         solve_once(s_, cfg["mode"])
 
     def step():
         solve(solver)
-        S.pack_and_gather(solver, packed, gathered, dist)  # RCCL over xGMI: 32 B per instance
+        S.pack_and_gather(solver, packed, gathered, dist, force_collective=args.force_dist)  # RCCL over xGMI: 32 B per instance
 
     if args.pipeline > 1:
         if cfg["mode"] != "al":
@@ -458,7 +492,7 @@ def main():
                     pending[i] = False
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -474,7 +508,7 @@ def main():
         drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -532,6 +566,15 @@ def main():
                         "altro_get_trajectory + altro_get_stats into host arrays (the caller's buffers, reused)",
             }
         name, cus = solver.device_info()
+        dist_check = None
+        if args.force_dist and world == 1:
+            # the records RCCL delivered are the solver's own statistics of the last timed solve, field for field
+            # (the profiled solve above repeats the same solve: same statistics)
+            stt = solver.get_stats()
+            want = S.result_records(stt)
+            dist_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "records_match_get_stats": bool(np.array_equal(res, want)),
+                          "gather_is_separate_buffer": bool(gathered.data_ptr() != packed.data_ptr())}
         others, latency = None, None
         if world == 1 and args.pipeline == 1 and (not args.no_other_configs or not args.no_latency):
             solver.close()  # (the other workloads get the device to themselves, like the headline had it)
@@ -570,9 +613,10 @@ def main():
             "host_boundary": host,
             "other_configs": others,
             "latency": latency,
+            **({"dist_check": dist_check} if dist_check is not None else {}),
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -159,6 +159,17 @@ class UnicycleProblem {
       }
   }
 
+  // Keep the block [lo, hi) of the seeded GLOBAL batch (multi-GPU: one block per device, altro::BatchGroup::ShardRange):
+  // instance lo + i of the global batch becomes instance i of this problem.
+  void TakeShard(int lo, int hi) {
+    auto cut = [&](std::vector<double>& v, size_t per) {
+      if (v.size() == per * (size_t)batch && batch > 1) v = std::vector<double>(v.begin() + per * lo, v.begin() + per * hi);
+    };
+    cut(xf, 3);
+    cut(circles, 9);
+    batch = hi - lo;
+  }
+
  private:
   Scenario scenario_ = kTurn90;
   float tf_ = 3.0f;

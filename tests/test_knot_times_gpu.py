@@ -98,7 +98,8 @@ def test_step_level_calls_with_per_knot_steps(A, P, oracle_make, hip_make):
         s.update_expansions(); s.backward_pass(); s.forward_pass()
     for k in (0, 37, 99):
         eo, eg = o.get_expansion(k), g.get_expansion(k)
-        assert np.allclose(eg[0], eo[0], rtol=1e-10, atol=1e-12)  # A | B
+        assert np.allclose(eg["A"], eo["A"], rtol=1e-10, atol=1e-12) and np.allclose(eg["B"], eo["B"], rtol=1e-10, atol=1e-12)
+        assert np.abs(eg["B"]).max() > 0
     Ko, do = o.get_gains()
     Kg, dg = g.get_gains()
     assert np.allclose(Kg, Ko, rtol=1e-7, atol=1e-9) and np.allclose(dg, do, rtol=1e-7, atol=1e-9)
