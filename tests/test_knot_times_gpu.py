@@ -89,8 +89,8 @@ def test_geometric_step_schedule_matches_the_oracle(A, P, oracle_make, hip_make,
 @pytest.mark.gpu
 def test_step_level_calls_with_per_knot_steps(A, P, oracle_make, hip_make):
     """Rollout, expansions (RK4 Jacobians with h[k]), backward and forward pass one by one."""
-    g = P.batch_three_obstacles(hip_make, batch=5)
-    o = P.batch_three_obstacles(oracle_make, batch=5)
+    g = P.batch_three_obstacles(hip_make, batch=5, dtype=A.F64)  # (the factory's default is the config's ALTRO_F32)
+    o = P.batch_three_obstacles(oracle_make, batch=5, dtype=A.F64)
     steps = _geometric_steps(100, 5.0, 0.985)
     for s in (g, o):
         s.set_steps(steps)
