@@ -1248,12 +1248,14 @@ class Engine final : public EngineBase {
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
         {
-          const void* variants[6] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
+          const void* variants[8] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecWave>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecHelper>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecHelper>)};
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecHelper>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecFree>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecFree>)};
           for (const void* fn : variants)
             ALTRO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes_));
         }
@@ -1544,10 +1546,12 @@ class Engine final : public EngineBase {
         if (circles) {
           if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
           else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
+          else if (spec_mode_ == kSpecFree) ALTRO_FUSED(true, kSpecFree, b4);
           else ALTRO_FUSED(true, kSpecOff, b3);
         } else {
           if (spec_mode_ == kSpecHelper) ALTRO_FUSED(false, kSpecHelper, b3);
           else if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
+          else if (spec_mode_ == kSpecFree) ALTRO_FUSED(false, kSpecFree, b4);
           else ALTRO_FUSED(false, kSpecOff, b3);
         }
 #undef ALTRO_FUSED
@@ -1566,8 +1570,12 @@ class Engine final : public EngineBase {
     int sweeps = 0;  // longest chain of iterations, the look-ahead sweep of a chain that ran dry included
     for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
-      int extra[3] = {0, 0, 0};
+      int extra[4] = {0, 0, 0, 0};
       ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      if (extra[3] != 0) {
+        err_ = "k_sweep_fused: a forward wave gave up waiting for its sequence word (software synchronisation)";
+        return ALTRO_HIP_ERROR;
+      }
       timing_.fused_sweeps = extra[0];
       timing_.fused_instance_iterations = extra[1];
       sweeps = std::max(sweeps, extra[2]);
@@ -1626,6 +1634,8 @@ class Engine final : public EngineBase {
     const char* e = std::getenv("ALTRO_HIP_SPECULATION");
     if (e && std::string(e) == "helper") return (int)kSpecHelper;
     if (e && std::string(e) == "off") return (int)kSpecOff;
+    if (e && std::string(e) == "free") return (int)kSpecFree;
+    if (e && std::string(e) == "wave") return (int)kSpecWave;
     return (int)kSpecWave;
   }();
   hipStream_t stream2_ = nullptr;

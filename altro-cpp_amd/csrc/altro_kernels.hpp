@@ -2196,6 +2196,106 @@ ALTRO_DEV bool consumer_syncs_before(int k, int G = 2) { return (k & (G - 1)) ==
 ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// How the three waves of the forward pass meet.
+//
+// HARDWARE (SOFT = false: the batched sweeps and the persistent kernel's lock-step modes): LDS-only workgroup barriers --
+// one per stretch of G knots in the knot loop (producer after the stretch, consumers before it), then A, S, V.  Every
+// wave of the workgroup has to execute every one of them: the fourth wave of k_sweep_fused<.., kSpecWave>, which runs the
+// speculative backward pass, therefore walks in LOCK STEP with the knot loop (the recursion at 825 cycles per knot sets
+// the pace of a loop whose own waves need 620).
+//
+// SOFT (k_sweep_fused<.., kSpecFree>): no hardware barrier anywhere in the forward pass.  The rollout wave publishes a
+// stretch by bumping a sequence word in LDS behind the stretch's slot writes (LDS operations of one wave execute in
+// order; the release makes the compiler keep that order), the consumers poll it; the consumers report the stretches
+// they have finished the same way, and the producer -- two stretches ahead at most: the ring has 2 G slots -- looks at
+// those words one stretch before it needs them.  A, S and V are sequence words too.  The fourth wave then runs its
+// recursion at its own pace (700 cycles per knot) beside a knot loop that runs at ITS own pace, and all four waves meet
+// at the workgroup barrier behind the forward pass.  Sequence numbers grow monotonically over the iterations of the
+// persistent kernel (base = iteration * kFwdSeqStride), so nothing is ever reset.  Every poll loop is bounded: a wave
+// that never sees its word gives up after kFwdSpinLimit polls and raises the error word (the launch then reports it;
+// it cannot hang the GPU).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFwdSeqStride = 1 << 12;   // > stretches of one forward pass (N / G + 2)
+constexpr int kFwdSpinLimit = 1 << 22;   // polls (~0.1 us each) before a wave gives up
+enum FwdSyncWord { kSyPub = 0, kSyCons0 = 1, kSyCons1 = 2, kSyA = 3, kSyS = 4, kSyV0 = 5, kSyV1 = 6, kSyErr = 7, kSyWords = 8 };
+template <bool SOFT>
+struct FwdSync {
+  int* w;    // kSyWords ints in LDS (SOFT only)
+  int base;  // sequence offset of this forward pass
+  static ALTRO_DEV int peek(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+  }
+  static ALTRO_DEV void post(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  ALTRO_DEV void wait_for(int word, int value) const {
+    for (int tries = 0; tries < kFwdSpinLimit; ++tries)
+      if (peek(w + word) >= value) return;
+    post(w + kSyErr, 1);
+  }
+  // producer: stretch j is in its slots / consumers: before the first read of stretch j
+  ALTRO_DEV void publish(int j) const {
+    if (SOFT) post(w + kSyPub, base + j + 1);
+    else lds_barrier();
+  }
+  ALTRO_DEV void await(int j) const {
+    if (SOFT) wait_for(kSyPub, base + j + 1);
+    else lds_barrier();
+  }
+  // consumer c (0 cost wave, 1 auxiliary wave) has read stretch j / producer: both have (before it rewrites those slots)
+  ALTRO_DEV void consumed(int c, int j) const {
+    if (SOFT) post(w + kSyCons0 + c, base + j + 1);
+  }
+  ALTRO_DEV void await_consumed(int j) const {
+    if (SOFT) {
+      wait_for(kSyCons0, base + j + 1);
+      wait_for(kSyCons1, base + j + 1);
+    }
+  }
+  // A: the auxiliary wave's verdicts are in LDS (hardware: all three waves take the barrier)
+  ALTRO_DEV void signal_a() const {
+    if (SOFT) post(w + kSyA, base + 1);
+    else lds_barrier();
+  }
+  ALTRO_DEV void await_a() const {
+    if (SOFT) wait_for(kSyA, base + 1);
+    else lds_barrier();
+  }
+  ALTRO_DEV void pass_a() const {  // the rollout wave has no business at A
+    if (!SOFT) lds_barrier();
+  }
+  // S: the selection is in LDS, this wave's candidate / trajectory stores have drained
+  ALTRO_DEV void signal_s() const {
+    if (SOFT) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      post(w + kSyS, base + 1);
+    } else {
+      __syncthreads();
+    }
+  }
+  ALTRO_DEV void await_s() const {
+    if (SOFT) wait_for(kSyS, base + 1);
+    else __syncthreads();
+  }
+  // V: the shares of the violation of the two other waves (c = 0 rollout wave, 1 auxiliary wave) are in LDS
+  ALTRO_DEV void signal_v(int c) const {
+    if (SOFT) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      post(w + kSyV0 + c, base + 1);
+    } else {
+      __syncthreads();
+    }
+  }
+  ALTRO_DEV void await_v() const {
+    if (SOFT) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      wait_for(kSyV0, base + 1);
+      wait_for(kSyV1, base + 1);
+    } else {
+      __syncthreads();
+    }
+  }
+};
+
 // iLQR::RolloutClosedLoop's bound checks (ilqr.hpp:484-495), evaluated by the auxiliary wave so that they
 // stay off the rollout wave's serial chain.  Step k of the rollout fails with kStateLimit when
 // ||x_{k+1}|| > state_max, else with kControlLimit when ||u_k|| > control_max; the first failing step
@@ -2241,9 +2341,10 @@ ALTRO_DEV double from_upper_half(double x) {
 // knots.  What is sequential over the knots stays sequential: the bound verdicts are scalar masks stepped in knot
 // order, and the gradient measure is summed in the lower half in knot order (the upper half's term arrives through
 // v_permlane32_swap), bit-identical to the one-knot-at-a-time loop.
-template <class T, class M, bool PAIRED>
+template <class T, class M, bool PAIRED, bool SOFT = false>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
-                            bool valid, T* cand_inst, int* flags, double* gsx, bool grad) {
+                            bool valid, T* cand_inst, int* flags, double* gsx, bool grad,
+                            const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}) {
   constexpr int G = PAIRED ? kSyncFused : 2;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -2257,7 +2358,10 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
   double gs = 0.0;
   constexpr int kStep = PAIRED ? 2 : 1;
   for (int k0 = 0; k0 <= N; k0 += kStep) {
-    if (consumer_syncs_before(k0, G)) lds_barrier();  // publishes (xbar, ubar) of knots k0 .. k0+G-1 of every trial
+    if (consumer_syncs_before(k0, G)) {  // (xbar, ubar) of knots k0 .. k0+G-1 of every trial are published
+      if (k0 > 0) sy.consumed(1, k0 / G - 1);
+      sy.await(k0 / G);
+    }
     const int k = k0 + half;                       // k <= N + 1; N is the terminal knot (a state only)
     const bool inner = k < N;
     const T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
@@ -2311,9 +2415,10 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
 // HOIST (the persistent kernel of problems with circle constraints: one workgroup per CU, registers are free): the
 // circles' centres and radii in registers, their multipliers fetched one knot ahead.  The batched sweeps keep the
 // runtime loop: the 30 VGPRs would cost them a wave per SIMD.
-template <class T, class M, int FK, bool HOIST>
+template <class T, class M, int FK, bool HOIST, bool SOFT = false>
 ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const DevArrays<T>& A, const KnotRun& run,
-                                 int kend, const T* xch, int lane, double& J, int G) {
+                                 int kend, const T* xch, int lane, double& J, int G,
+                                 const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   const KnotClass& kc = pd->cls[run.cls];
   RunConsts<T, n, m> RC;
@@ -2393,7 +2498,10 @@ ALTRO_DEV void cost_consumer_run(const CtxL<T>& C, const ProblemDesc* pd, const 
   };
   fetch_bound_rows(k_begin, blam, brho, clam, crho);
   for (int k = k_begin; k < kend; ++k) {
-    if (consumer_syncs_before(k, G)) lds_barrier();  // publishes (xbar, ubar) of knots k .. k+G-1 of every trial
+    if (consumer_syncs_before(k, G)) {  // (xbar, ubar) of knots k .. k+G-1 of every trial are published
+      if (k > 0) sy.consumed(0, k / G - 1);
+      sy.await(k / G);
+    }
     const T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
     T xb[n], ub[m];
 #pragma unroll
@@ -2636,11 +2744,13 @@ struct FwdSpec {
   double* inbox;  // {rho, drho} the pass assumed
   bool armed;     // speculate in this forward pass (the previous line search was rejected: a streak is likely)
 };
-template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false>
+template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false, bool SOFT = false>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
-                             const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr) {
+                             const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr,
+                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}) {
+  static_assert(!SOFT || FUSED, "software synchronisation is a mode of the persistent kernel");
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
@@ -2752,6 +2862,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         ub[i] = cur.uk[i] + sacc + (T)cur.kd[R::oD + i] * alpha;
       }
       T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
+      // (software synchronisation: the slots of stretch j are those of stretch j - 2, which both consumers must have read)
+      if (SOFT && (k & (G - 1)) == 0 && k >= 2 * G) sy.await_consumed(k / G - 2);
 #pragma unroll
       for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
 #pragma unroll
@@ -2765,7 +2877,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
-      if (producer_syncs_after(k, N, G)) lds_barrier();
+      if (producer_syncs_after(k, N, G)) sy.publish(k / G);
     };
     if constexpr (RG && kRgAhead == 2) {
       // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
@@ -2792,12 +2904,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
     // final hand-off: x_N
     T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
+    if (SOFT && (N & (G - 1)) == 0 && N >= 2 * G) sy.await_consumed(N / G - 2);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
-    lds_barrier();  // barrier N (producer_syncs_after(N, N))
-    lds_barrier();  // barrier A (auxiliary wave -> cost wave)
+    sy.publish(N / G);  // barrier N (producer_syncs_after(N, N))
+    sy.pass_a();        // barrier A (auxiliary wave -> cost wave)
     // phase 2 is shared by all waves: wait for the selection, take every third block of knots
-    __syncthreads();  // barrier S
+    sy.await_s();  // barrier S
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart = xch + 8;
@@ -2813,7 +2926,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if (t == 0) vpart[grp] = vm;
       }
     }
-    __syncthreads();  // barrier V
+    sy.signal_v(0);  // barrier V
     return;
   }
 
@@ -2823,10 +2936,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
-    aux_wave_run<T, M, FUSED>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx,
-                              grad_in_loop);
-    lds_barrier();    // barrier A
-    __syncthreads();  // barrier S
+    aux_wave_run<T, M, FUSED, SOFT>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx,
+                                    grad_in_loop, sy);
+    sy.signal_a();  // barrier A
+    sy.await_s();   // barrier S
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart2 = xch + 12;
@@ -2840,7 +2953,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if (t == 0) vpart2[grp] = vm;
       }
     }
-    __syncthreads();  // barrier V
+    sy.signal_v(1);  // barrier V
     return;
   }
 
@@ -2859,9 +2972,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       // (not armed: the fourth wave just keeps the barrier count)
       if (spec->armed)
         backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
-                                                    rho_in, drho_in, &nbar);
-      // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V)
-      for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
+                                                    rho_in, drho_in, SOFT ? nullptr : &nbar);
+      // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V.  With
+      //  software synchronisation the forward waves take no hardware barrier: the recursion ran at its own pace)
+      if (!SOFT)
+        for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
       return;
     }
   }
@@ -2879,7 +2994,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   for (int r = 0; r < pd->nruns; ++r) {
     const KnotRun run = pd->runs[r];
     const int kend = run.k_end < N ? run.k_end : N;
-#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK, HOISTC>(C, pd, A, run, kend, xch, lane, J, G)
+#define ALTRO_RUN(FK) cost_consumer_run<T, M, FK, HOISTC, SOFT>(C, pd, A, run, kend, xch, lane, J, G, sy)
     switch (run.fast) {
       case kFastNone: ALTRO_RUN(kFastNone); break;
       case kFastB: ALTRO_RUN(kFastB); break;
@@ -2890,7 +3005,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
 #undef ALTRO_RUN
   }
-  if (consumer_syncs_before(N, G)) lds_barrier();  // barrier N: terminal state and rollout outcome
+  if (consumer_syncs_before(N, G)) {  // barrier N: terminal state and rollout outcome
+    if (N > 0) sy.consumed(0, N / G - 1);
+    sy.await(N / G);
+  }
   {
     const T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
     T xN[n], uz[m];
@@ -2902,7 +3020,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     const KnotClass& kcN = pd->cls[runN.cls];
     J += (double)knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xN, uz, nullptr);
   }
-  lds_barrier();  // barrier A: the auxiliary wave's verdicts
+  sy.await_a();  // barrier A: the auxiliary wave's verdicts
   const bool ok = flags[lane] != 0;
   const int st = flags[kBlock + lane];
   const double gs = gsx[lane];
@@ -2947,7 +3065,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       sel[2 * grp + 1] = accepted ? 1 : 0;
     }
   }
-  __syncthreads();  // barrier S: selection visible, candidate stores of this wave drained
+  sy.signal_s();  // barrier S: selection visible, candidate stores of this wave drained
   T viol = T(0);
   if (valid) {
     viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, cand_base, cand_off0,
@@ -2956,7 +3074,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;
   }
-  __syncthreads();  // barrier V: the other wave's share of the violation
+  sy.await_v();  // barrier V: the other wave's share of the violation
   if (!valid) return;
   viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
   if (!grad_in_loop && accepted) {
@@ -3051,7 +3169,10 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // hand-over values out travel through global memory with release / acquire flags at agent scope.  Neither side ever
 // blocks on the other: this kernel waits a bounded number of polls for a result and otherwise runs the recursion
 // itself, the helper gives up after a bounded number of idle polls.
-enum SpecMode { kSpecOff = 0, kSpecWave = 1, kSpecHelper = 2 };
+// SPEC = kSpecFree: the fourth wave again, but the three forward waves synchronise through sequence words in LDS instead of
+// workgroup barriers (FwdSync<true>), so the recursion and the knot loop each run at their own pace instead of in lock step.
+enum SpecMode { kSpecOff = 0, kSpecWave = 1, kSpecHelper = 2, kSpecFree = 3 };
+ALTRO_DEV constexpr bool spec_has_wave4(int spec) { return spec == kSpecWave || spec == kSpecFree; }
 template <class T>
 struct SpecRemote {
   int* go;      // [Bp] tag of the pass requested by the instance's workgroup (-1: finished)
@@ -3063,10 +3184,11 @@ struct SpecRemote {
 constexpr int kSpecPolls = 400;  // polls of the result flag before the recursion is run locally (~0.1 us each)
 
 template <class T, class M, bool CIRC, int SPEC>
-__global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
+__global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
     DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
     int* sweeps_out, SpecRemote<T> rs) {
-  constexpr int kThreads = (SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * kBlock;
+  constexpr int kThreads = (spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock;
+  constexpr bool kWave4 = spec_has_wave4(SPEC), kSoft = SPEC == kSpecFree;
   using R = Rec<T, M::n, M::m>;
   constexpr int nm = M::n + M::m;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -3097,6 +3219,8 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
   FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8, false};
   int* const remote_ok = reinterpret_cast<int*>(fh2 + 10);  // helper mode: the poll's verdict for the workgroup
   T* const alpha_tab = reinterpret_cast<T*>(fh2 + 12);      // [20] step lengths of the line-search lanes (ilqr.hpp:544)
+  int* const sync_words = reinterpret_cast<int*>(fh2 + 12 + kLineSearchLanes);  // [kSyWords] FwdSync<true> (kSpecFree)
+  if (kSoft && tid < kSyWords) sync_words[tid] = 0;  // (visible behind the staging barrier of the first iteration)
   if (tid < kLineSearchLanes) {
     T alpha = T(1);
     for (int i = 0; i < tid; ++i) alpha /= T(o.line_search_decrease_factor);
@@ -3161,7 +3285,7 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
         double h[6];
         if (SPEC == kSpecHelper) {
           for (int q = 0; q < 5; ++q) h[q] = rs.out[8 * (size_t)b + q];
-        } else {
+        } else {  // (the fourth wave's hand-over values)
           h[0] = fh2[1]; h[1] = fh2[2]; h[2] = fh2[4]; h[3] = fh2[5]; h[4] = fh2[6];
         }
         fh[1] = h[0];
@@ -3200,8 +3324,9 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
     // ---- F ----
     spec.armed = armed;
-    forward2_body<T, M, true, kSrcLds, CIRC>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
-                                             SPEC == kSpecWave ? &spec : nullptr, alpha_tab);
+    forward2_body<T, M, true, kSrcLds, CIRC, kSoft>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
+                                                    kWave4 ? &spec : nullptr, alpha_tab,
+                                                    FwdSync<kSoft>{sync_words, loops * kFwdSeqStride});
     ++loops;
     // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
     //  backward pass of the next iteration would read from global memory: see the end of the loop)
@@ -3209,7 +3334,7 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
     if (!persistent || *active_flag == 0) break;
     // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
     // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
-    if (SPEC == kSpecWave) adopt = armed && fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
+    if (kWave4) adopt = armed && fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
     if (SPEC == kSpecHelper) {
       const bool mine = armed && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
       if (tid == 0) {
@@ -3272,6 +3397,7 @@ __global__ __launch_bounds__((SPEC == kSpecWave ? kFwdWaves + 1 : kFwdWaves) * k
     atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
     const int chain = A.chain_size ? (b / A.chain_size < 3 ? b / A.chain_size : 3) : 0;
     atomicMax(sweeps_out + 2, A.chain_base[chain] + loops + skipped);  // ... counted from the first sweep of the solve
+    if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word
   }
 }
 

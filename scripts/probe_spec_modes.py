@@ -18,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             t0 = time.perf_counter(); s.solve(); best = min(best, time.perf_counter() - t0)
         print(f"  B={B:4d} {name:9s} {1e3 * best:7.3f} ms  (longest chain {s.get_timing()['sweeps']})", flush=True)
     sys.exit(0)
-for mode in ("off", "wave", "helper"):
+for mode in ("off", "wave", "free", "helper"):
     print("ALTRO_HIP_SPECULATION=" + mode, flush=True)
     for B in (1, 32, 128, 250):
         subprocess.run([sys.executable, __file__, "child", str(B)], check=True, env=dict(os.environ, ALTRO_HIP_SPECULATION=mode))

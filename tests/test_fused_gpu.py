@@ -110,6 +110,8 @@ np.savez(sys.argv[1], **out)
 @pytest.mark.parametrize("switch", [{"ALTRO_HIP_NO_DENSE_EXPANSIONS": "1"}, {"ALTRO_HIP_FWD_SRC": "global"},
                                     {"ALTRO_HIP_FWD_SRC": "lds"}, {"ALTRO_HIP_FWD_PER_WAVE": "1"},
                                     {"ALTRO_HIP_NO_SPECULATION": "1"}, {"ALTRO_HIP_SPECULATION": "helper"},
+                                    {"ALTRO_HIP_SPECULATION": "free"}, {"ALTRO_HIP_SPECULATION": "wave"},
+                                    {"ALTRO_HIP_SPECULATION": "free", "ALTRO_HIP_DEBUG_POISON": "12345678,mix"},
                                     {"ALTRO_HIP_PERSIST_AT": "600"}, {"ALTRO_HIP_CHAINS": "4"}, {"ALTRO_HIP_CHAINS": "3", "ALTRO_HIP_PERSIST_AT": "100"}, {"ALTRO_HIP_DEBUG_POISON": "ffffffff"},
                                     {"ALTRO_HIP_DEBUG_POISON": "12345678,mix"}],
                          ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
