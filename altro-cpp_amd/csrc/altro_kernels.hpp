@@ -2218,15 +2218,23 @@ ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFwdSeqStride = 1 << 12;   // > stretches of one forward pass (N / G + 2)
 constexpr int kFwdSpinLimit = 1 << 22;   // polls (~0.1 us each) before a wave gives up
-enum FwdSyncWord { kSyPub = 0, kSyCons0 = 1, kSyCons1 = 2, kSyA = 3, kSyS = 4, kSyV0 = 5, kSyV1 = 6, kSyErr = 7, kSyWords = 8 };
+enum FwdSyncWord { kSyPub = 0, kSyErr = 1, kSyCons0 = 2, kSyCons1 = 3, kSyA = 4, kSyS = 5, kSyV0 = 6, kSyV1 = 7, kSyWords = 8 };
 template <bool SOFT>
 struct FwdSync {
-  int* w;    // kSyWords ints in LDS (SOFT only)
+  int* w;    // kSyWords ints in LDS, 8-byte aligned (SOFT only)
   int base;  // sequence offset of this forward pass
+  // LDS operations of one wavefront execute in issue order, so a sequence word written behind the data it announces
+  // needs no s_waitcnt in front of it, and the data reads behind a poll need none either: wavefront-scope fences keep
+  // the COMPILER from reordering them, the hardware does not.
   static ALTRO_DEV int peek(const int* p) {
-    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return v;
   }
-  static ALTRO_DEV void post(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static ALTRO_DEV void post(int* p, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   ALTRO_DEV void wait_for(int word, int value) const {
     for (int tries = 0; tries < kFwdSpinLimit; ++tries)
       if (peek(w + word) >= value) return;
@@ -2245,10 +2253,24 @@ struct FwdSync {
   ALTRO_DEV void consumed(int c, int j) const {
     if (SOFT) post(w + kSyCons0 + c, base + j + 1);
   }
-  ALTRO_DEV void await_consumed(int j) const {
+  // The producer looks at the consumers' words ONE STRETCH EARLY (right behind a publish: the load's latency hides
+  // behind the next stretch's arithmetic); the consumers, faster than the rollout chain, have posted by then, and the
+  // poll loop behind a stale look is the rare path.
+  ALTRO_DEV long long look_consumed() const {
+    if (!SOFT) return 0;
+    return __hip_atomic_load(reinterpret_cast<const long long*>(w + kSyCons0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  ALTRO_DEV void await_consumed(int j, long long look) const {
     if (SOFT) {
-      wait_for(kSyCons0, base + j + 1);
-      wait_for(kSyCons1, base + j + 1);
+      const int need = base + j + 1;
+      const int c0 = __builtin_amdgcn_readfirstlane((int)(look & 0xffffffffll));
+      const int c1 = __builtin_amdgcn_readfirstlane((int)(look >> 32));
+      if (c0 >= need && c1 >= need) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return;
+      }
+      wait_for(kSyCons0, need);
+      wait_for(kSyCons1, need);
     }
   }
   // A: the auxiliary wave's verdicts are in LDS (hardware: all three waves take the barrier)
@@ -2851,6 +2873,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         }
       }
     };
+    long long cons_look = 0;  // (software synchronisation) the consumers' progress words as of the last publish
     auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
       T ub[m], xn[n];
       fetch(k + (RG ? kRgAhead : 1), nxt);
@@ -2863,7 +2886,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
       T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
       // (software synchronisation: the slots of stretch j are those of stretch j - 2, which both consumers must have read)
-      if (SOFT && (k & (G - 1)) == 0 && k >= 2 * G) sy.await_consumed(k / G - 2);
+      if (SOFT && (k & (G - 1)) == 0 && k >= 2 * G) sy.await_consumed(k / G - 2, cons_look);
 #pragma unroll
       for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
 #pragma unroll
@@ -2877,7 +2900,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
-      if (producer_syncs_after(k, N, G)) sy.publish(k / G);
+      if (producer_syncs_after(k, N, G)) {
+        sy.publish(k / G);
+        if (SOFT) cons_look = sy.look_consumed();
+      }
     };
     if constexpr (RG && kRgAhead == 2) {
       // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
@@ -2904,7 +2930,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
     // final hand-off: x_N
     T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
-    if (SOFT && (N & (G - 1)) == 0 && N >= 2 * G) sy.await_consumed(N / G - 2);
+    if (SOFT && (N & (G - 1)) == 0 && N >= 2 * G) sy.await_consumed(N / G - 2, cons_look);
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
     sy.publish(N / G);  // barrier N (producer_syncs_after(N, N))
