@@ -1176,7 +1176,8 @@ class Engine final : public EngineBase {
       fused_lds_bytes_ = (shared_bytes + (2 * kSyncFused - kFwdSlots) * (size_t)nm * kBlock * sizeof(T) + per_inst + 15) / 16 * 16 +
                          (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T) +  // + the candidates of one instance
-                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 40 * sizeof(double);  // + the speculative pass (gains, hand-over), step-length table
+                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 40 * sizeof(double) +  // + the speculative pass (gains, hand-over), step-length table, sequence words
+                         ((size_t)N_ + 2) * sizeof(T);                                     // + the knot costs of the expansion step
       kdg_ = false;
       rg_ = false;
       if constexpr (kRgEligible) {
@@ -1531,6 +1532,7 @@ class Engine final : public EngineBase {
         int* const out = d_counter_ + max_sweeps + 2;
         const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
         SpecRemote<T> rs{};
+        const int spec_mode_ = this->spec_mode_ == kSpecAuto ? (circles ? (int)kSpecWave : (int)kSpecFree) : this->spec_mode_;
         if (spec_mode_ == kSpecHelper) {
           // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
           rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
@@ -1629,6 +1631,11 @@ class Engine final : public EngineBase {
   bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
   // speculative backward pass of the persistent kernel: on its fourth wave (default), in helper workgroups
   // (ALTRO_HIP_SPECULATION=helper), or not at all (ALTRO_HIP_NO_SPECULATION / =off)
+  // (default, kSpecAuto: the fourth wave -- free-running beside software-synchronised forward waves where the rollout
+  //  wave paces the knot loop, in lock step on problems with circle constraints, whose knot loop is paced by the cost
+  //  wave: there the sequence words only add their polls.  Measured per tail iteration: config 2 46.0 -> 42.0 us free,
+  //  config 3 54.7 lock step against 57.0 us free.)
+  static constexpr int kSpecAuto = -1;
   int spec_mode_ = [] {
     if (std::getenv("ALTRO_HIP_NO_SPECULATION")) return (int)kSpecOff;
     const char* e = std::getenv("ALTRO_HIP_SPECULATION");
@@ -1636,7 +1643,7 @@ class Engine final : public EngineBase {
     if (e && std::string(e) == "off") return (int)kSpecOff;
     if (e && std::string(e) == "free") return (int)kSpecFree;
     if (e && std::string(e) == "wave") return (int)kSpecWave;
-    return (int)kSpecWave;
+    return kSpecAuto;
   }();
   hipStream_t stream2_ = nullptr;
   hipStream_t HelperStream() const { return chains_ > 1 ? chain_stream_[1] : stream2_; }

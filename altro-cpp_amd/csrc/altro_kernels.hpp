@@ -35,10 +35,13 @@ namespace altro_hip {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: instances never share data
 constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost wave, auxiliary wave
-// knots per workgroup barrier of the persistent kernel's knot loop (the batched sweeps: 2), see producer_syncs_after.
-// (4 was measured: persistent launch 5.24 -> 5.30 ms on config 2, 5.03 -> 4.74 ms on config 3; the headline keeps 2.)
+// knots per synchronisation of the persistent kernel's knot loop (the batched sweeps: 2), see producer_syncs_after.
+// Round 2 (hardware barriers only): 4 measured 5.24 -> 5.30 ms on config 2, 5.03 -> 4.74 ms on config 3, the headline kept
+// 2.  Round 3: with the forward waves of config 2 synchronised through sequence words (kSpecFree) a meeting costs the
+// consumers an LDS round trip, and 4 wins on both (tail iteration 43.8 -> 42.2 us on config 2, 57.1 -> 55.6 us on
+// config 3): 4.
 #ifndef ALTRO_SYNC_FUSED
-#define ALTRO_SYNC_FUSED 2
+#define ALTRO_SYNC_FUSED 4
 #endif
 constexpr int kSyncFused = ALTRO_SYNC_FUSED;
 // Debugging aid (ALTRO_HIP_DEBUG_POISON): fills the LDS of the CU it lands on with a pattern, so that a kernel that reads
@@ -52,6 +55,20 @@ __global__ __launch_bounds__(256) void k_poison_lds(unsigned pattern, int words,
 }
 // workgroup barrier that only waits for this wave's LDS traffic (not for its global loads / stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Debug build only (-DALTRO_STAMPS, scripts/gpu_stamps.sh): phase stamps of the persistent kernel, per wave, summed over the
+// iterations of workgroup 0 in LDS and printed by the kernel at its end.  s_memtime runs at the shader clock.
+#ifdef ALTRO_STAMPS
+__shared__ long long g_stamp_acc[32];
+__device__ __forceinline__ void stamp_add(long long* acc, int slot, long long t0) {
+  if ((threadIdx.x & 63) == 0) acc[slot] += (long long)__builtin_amdgcn_s_memtime() - t0;
+}
+#define ALTRO_STAMP_T0() ((long long)__builtin_amdgcn_s_memtime())
+#define ALTRO_STAMP_ADD(slot, t0) stamp_add(g_stamp_acc, (slot), (t0))
+#else
+#define ALTRO_STAMP_T0() 0ll
+#define ALTRO_STAMP_ADD(slot, t0) (void)(t0)
+#endif
 
 // constraint rows and per-instance scalars: arr[row*Bp + b]
 #define SOA(arr, row) (arr)[(unsigned)(row) * (unsigned)Bp + (unsigned)b]
@@ -1621,7 +1638,13 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
         part += (double)mx;
       }
     }
-    for (int j = 0; j < LS; ++j) gsum_rej += __shfl(part, grp * LS + j);
+    if (active_out) {  // the persistent kernel: the instance sits in lanes 0 .. 19 of its wave, the lane index is a constant
+#pragma unroll
+      for (int j = 0; j < LS; ++j)
+        gsum_rej += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(part), j), __builtin_amdgcn_readlane(__double2loint(part), j));
+    } else {
+      for (int j = 0; j < LS; ++j) gsum_rej += __shfl(part, grp * LS + j);
+    }
   }
   int inner_done = 0;
   if (t == 0) {
@@ -1700,7 +1723,10 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
             }
           }
         }
-        if (t == 0) begin_inner_solve(A, o, b);
+        if (t == 0) {
+          begin_inner_solve(A, o, b);
+          if (ff) ff[5] = 1.0;  // (persistent kernel: LDS mirror of need_init_cost)
+        }
       }
       active = cont != 0;
     } else {
@@ -2366,7 +2392,8 @@ ALTRO_DEV double from_upper_half(double x) {
 template <class T, class M, bool PAIRED, bool SOFT = false>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
                             bool valid, T* cand_inst, int* flags, double* gsx, bool grad,
-                            const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}) {
+                            const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
+                            double* J0_out = nullptr) {
   constexpr int G = PAIRED ? kSyncFused : 2;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -2378,8 +2405,18 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
   T* const candp = cand_inst + (unsigned)(PAIRED ? col : lane % LS) * (unsigned)nm;
   BoundMasks bm;
   double gs = 0.0;
+  // PAIRED (persistent kernel): this wave also sums the running cost of the current trajectory, J0 = costs_.sum() in
+  // knot order (ilqr.hpp:326-334, 516), two knots per trip of its loop -- the wave has the slack, and the hundred
+  // dependent additions (with their LDS reads ~6 500 cycles on a wave of their own between two barriers) leave the
+  // critical path of the iteration altogether.  The cost wave needs J0 behind barrier A only.
+  double J0 = 0.0;
   constexpr int kStep = PAIRED ? 2 : 1;
   for (int k0 = 0; k0 <= N; k0 += kStep) {
+    if (PAIRED && sCost) {
+      const double c0 = (double)sCost[k0], c1 = (double)sCost[k0 + 1 <= N ? k0 + 1 : N];
+      J0 += c0;
+      if (k0 + 1 <= N) J0 += c1;  // (wave-uniform)
+    }
     if (consumer_syncs_before(k0, G)) {  // (xbar, ubar) of knots k0 .. k0+G-1 of every trial are published
       if (k0 > 0) sy.consumed(1, k0 / G - 1);
       sy.await(k0 / G);
@@ -2426,6 +2463,7 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
       for (int i = 0; i < m; ++i) cand[n + i] = ub[i];  // (the terminal knot's slot has room for the unused u)
     }
   }
+  if (J0_out) *J0_out = J0;
   const int bit = PAIRED ? col : lane;
   if (!PAIRED || half == 0) {
     flags[lane] = bm.lane_ok(bit) ? 1 : 0;
@@ -2771,7 +2809,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
                              const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr,
-                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}) {
+                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
+                             double* fhw = nullptr) {
   static_assert(!SOFT || FUSED, "software synchronisation is a mode of the persistent kernel");
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -2832,6 +2871,21 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
   }
 
+  // Phase 2 of the persistent kernel (one instance per workgroup): the knots of the instance over all 64 lanes of the
+  // three forward waves -- one knot per lane for N = 100 instead of two per line-search lane -- each knot's copy and
+  // constraint evaluation exactly as in the batched kernels; returns the wave's share of the violation (a maximum:
+  // exact in any order).  `wi` = 0, 1, 2: which third of the lanes this wave is.
+  auto phase2_all_lanes = [&](int wi, int t_rep, bool acc) __attribute__((always_inline)) -> T {
+    const int bF = __builtin_amdgcn_readfirstlane(b);  // lane 0 of every wave holds the workgroup's instance
+    const unsigned Bp = A.Bp;
+    (void)Bp;
+    CtxL<T> CF(A, bF, sPool, sIp, sLam, sPen);  // (one instance per workgroup: the same LDS block for every lane)
+    T v = forward_phase2<T, M>(A, pdg, CF, bF, t_rep, acc, wi * kBlock + lane, kFwdWaves * kBlock, sCand, 0u, sX, sU, nullptr,
+                               sKD, kKdStride, kKdOff);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max_(v, __shfl_xor(v, off));
+    return v;
+  };
   if (wave == 0) {
     // ================= rollout wave: iLQR::RolloutClosedLoop (ilqr.hpp:468-499) =================
     // (the state / control limit checks of the reference run in the cost wave: RolloutBounds)
@@ -2873,6 +2927,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         }
       }
     };
+    const long long st_w0 = ALTRO_STAMP_T0();
     long long cons_look = 0;  // (software synchronisation) the consumers' progress words as of the last publish
     auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
       T ub[m], xn[n];
@@ -2934,14 +2989,22 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 #pragma unroll
     for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
     sy.publish(N / G);  // barrier N (producer_syncs_after(N, N))
+    ALTRO_STAMP_ADD(0, st_w0);
+    const long long st_w0b = ALTRO_STAMP_T0();
     sy.pass_a();        // barrier A (auxiliary wave -> cost wave)
     // phase 2 is shared by all waves: wait for the selection, take every third block of knots
     sy.await_s();  // barrier S
+    ALTRO_STAMP_ADD(1, st_w0b);
+    const long long st_w0c = ALTRO_STAMP_T0();
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart = xch + 8;
       T viol = T(0);
-      if (valid) {
+      if (FUSED) {
+        // one instance per workgroup: its knots over ALL lanes of the three waves (one knot per lane for N = 100)
+        viol = phase2_all_lanes(0, sel[0], sel[1] != 0);
+        if (lane == 0) vpart[0] = viol;
+      } else if (valid) {
         CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
         viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS,
                                     FUSED ? sCand : A.trial,
@@ -2953,6 +3016,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
     }
     sy.signal_v(0);  // barrier V
+    ALTRO_STAMP_ADD(2, st_w0c);
     return;
   }
 
@@ -2962,14 +3026,35 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
+    const long long st_w2 = ALTRO_STAMP_T0();
+    double J0_run = 0.0;
     aux_wave_run<T, M, FUSED, SOFT>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx,
-                                    grad_in_loop, sy);
+                                    grad_in_loop, sy, FUSED ? sCost : nullptr, &J0_run);
+    if (FUSED && lane == 0) {
+      // J0 of the expansion step and, on the first iteration of an inner solve, stats_.initial_cost (ilqr.hpp:298);
+      // ff[4] / ff[5]: LDS mirrors of initial_cost / need_init_cost (phase 3 sets ff[5] when a new inner solve begins)
+      A.J0[b] = J0_run;
+      double ic = ff[4];
+      if (ff[5] != 0.0) {
+        ic = J0_run;
+        A.initial_cost[b] = J0_run;
+        A.need_init_cost[b] = 0;
+      }
+      fhw[0] = J0_run;
+      fhw[3] = ic;
+      ff[4] = ic;
+      ff[5] = 0.0;
+    }
+    ALTRO_STAMP_ADD(7, st_w2);
     sy.signal_a();  // barrier A
     sy.await_s();   // barrier S
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart2 = xch + 12;
-      if (valid) {
+      if (FUSED) {
+        const T viol = phase2_all_lanes(2, sel[0], sel[1] != 0);
+        if (lane == 0) vpart2[0] = viol;
+      } else if (valid) {
         CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
         const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
                                             kFwdWaves * LS, cand_base, cand_off0, FUSED ? sX : nullptr,
@@ -2995,12 +3080,14 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         spec->fh2[7] = 0.0;
       }
       int nbar = 0;
+      const long long st_w3 = ALTRO_STAMP_T0();
       // (not armed: the fourth wave just keeps the barrier count)
       if (spec->armed)
         backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
                                                     rho_in, drho_in, SOFT ? nullptr : &nbar);
       // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V.  With
       //  software synchronisation the forward waves take no hardware barrier: the recursion ran at its own pace)
+      if (spec->armed) ALTRO_STAMP_ADD(8, st_w3);
       if (!SOFT)
         for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
       return;
@@ -3008,11 +3095,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   }
   // ===================== cost wave: iLQR::Cost per trial + everything after ======================
   CtxL<T> C(A, b, sPool, sIp, sLam, sPen);
-  const double J0 = FUSED ? fh[0] : A.J0[b];
+  const long long st_w1 = ALTRO_STAMP_T0();
+  double J0 = FUSED ? 0.0 : A.J0[b];  // (FUSED: summed by the auxiliary wave during the knot loop, read behind barrier A)
   const double dV0 = FUSED ? fh[1] : A.dV0[b], dV1 = FUSED ? fh[2] : A.dV1[b];
   InstPre pre = load_inst_pre(A, b);  // consumed by the state machine at the very end
   if (FUSED) {
-    pre.initial_cost = fh[3];
     pre.rho_reg = fh[4];
     pre.drho = fh[5];
   }
@@ -3046,7 +3133,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     const KnotClass& kcN = pd->cls[runN.cls];
     J += (double)knot_cost<T, n, m, false>(C, pd, kcN, runN.rowbase + (N - runN.k_begin) * kcN.nrows, xN, uz, nullptr);
   }
-  sy.await_a();  // barrier A: the auxiliary wave's verdicts
+  sy.await_a();  // barrier A: the auxiliary wave's verdicts (FUSED: and the running cost)
+  if (FUSED) {
+    J0 = fh[0];
+    pre.initial_cost = fh[3];
+  }
+  ALTRO_STAMP_ADD(3, st_w1);
+  const long long st_w1b = ALTRO_STAMP_T0();
   const bool ok = flags[lane] != 0;
   const int st = flags[kBlock + lane];
   const double gs = gsx[lane];
@@ -3092,8 +3185,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
   }
   sy.signal_s();  // barrier S: selection visible, candidate stores of this wave drained
+  ALTRO_STAMP_ADD(4, st_w1b);
+  const long long st_w1c = ALTRO_STAMP_T0();
   T viol = T(0);
-  if (valid) {
+  if (FUSED) {
+    // (the selection lives in the instance's 20 lanes: every lane of the wave takes lane 0's)
+    viol = phase2_all_lanes(1, __builtin_amdgcn_readfirstlane(t_replay), __builtin_amdgcn_readfirstlane(accepted ? 1 : 0) != 0);
+  } else if (valid) {
     viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, cand_base, cand_off0,
                                 FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
     T vm = viol;
@@ -3101,6 +3199,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     viol = vm;
   }
   sy.await_v();  // barrier V: the other wave's share of the violation
+  ALTRO_STAMP_ADD(5, st_w1c);
+  const long long st_w1d = ALTRO_STAMP_T0();
   if (!valid) return;
   viol = max_(max_(viol, (xch + 8)[grp]), (xch + 12)[grp]);
   if (!grad_in_loop && accepted) {
@@ -3111,6 +3211,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
                        FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
+  ALTRO_STAMP_ADD(6, st_w1d);
 }
 
 template <class T, class M, int SRC>
@@ -3247,6 +3348,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   T* const alpha_tab = reinterpret_cast<T*>(fh2 + 12);      // [20] step lengths of the line-search lanes (ilqr.hpp:544)
   int* const sync_words = reinterpret_cast<int*>(fh2 + 12 + kLineSearchLanes);  // [kSyWords] FwdSync<true> (kSpecFree)
   if (kSoft && tid < kSyWords) sync_words[tid] = 0;  // (visible behind the staging barrier of the first iteration)
+  T* const sCost = reinterpret_cast<T*>(fh2 + 12 + kLineSearchLanes + 4);  // [N + 1] knot costs of the expansion step
   if (tid < kLineSearchLanes) {
     T alpha = T(1);
     for (int i = 0; i < tid; ++i) alpha /= T(o.line_search_decrease_factor);
@@ -3268,7 +3370,16 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   double prev_rho = -1.0, prev_drho = -1.0;
   int skipped = 0;
   int loops = 0;
+#ifdef ALTRO_STAMPS
+  if (tid < 32) g_stamp_acc[tid] = 0;
+  int spec_iters = 0;
+#endif
+  if (wave == 2 && lane == 0) {  // LDS mirrors of initial_cost / need_init_cost (read by this same lane: forward2_body)
+    ff[4] = A.initial_cost[b];
+    ff[5] = A.need_init_cost[b] ? 1.0 : 0.0;
+  }
   for (;;) {
+    const long long st_it = ALTRO_STAMP_T0();
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
     //      forward pass keep the LDS copies current from then on ----
     if (loops == 0) {
@@ -3277,22 +3388,19 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     }
     // (the two per-instance scalars the running-cost wave needs after E: requested now, their memory latency -- two
     //  dependent round trips -- runs beside the expansions instead of behind them)
-    double ic_early = 0.0;
-    int need_ic_early = 0;
-    if (wave == 1 && lane == 0) {
-      ic_early = A.initial_cost[b];
-      need_ic_early = A.need_init_cost[b];
-    }
     // ---- E: expansions from the LDS block ----
     {
       const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
                        sm + L.nX + L.nU + L.nKD + L.rowsP());
-      expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, xch, b, tid, kThreads);
+      expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, sCost, b, tid, kThreads);
+      if (adopt) ALTRO_STAMP_ADD(17 + wave, st_it);  // (17..20: each wave's own share of E)
     }
     // drains the stores: the records are in L2 for the backward wave, the costs in LDS.  (A speculated iteration runs
     // no backward pass of its own, and the records it just rewrote are bit for bit the ones the fourth wave will read:
     // only the LDS traffic has to settle -- the two microseconds of store acknowledgements stay off the chain.)
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
+    if (wave == 0 && adopt) ALTRO_STAMP_ADD(9, st_it);
+    const long long st_b = ALTRO_STAMP_T0();
 
     if (SPEC != kSpecOff) ++tag;  // (wave-uniform: every thread counts)
     // speculate only in a streak of rejections (ff: phase 3 of the previous iteration, rewritten by this one's): a
@@ -3300,6 +3408,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     // release fence of a request to the helper is not free
     const bool armed = SPEC != kSpecOff && loops > 0 && ff[0] != 0.0;
     if (SPEC && adopt) {
+      const long long st_cp = ALTRO_STAMP_T0();
       // ---- B was run ahead (fourth wave / helper workgroup) during the previous forward pass: take its results ----
       if (SPEC == kSpecHelper) {
         const T* src = rs.kd + (size_t)b * (size_t)(N * R::KP);
@@ -3325,38 +3434,36 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         A.drho[b] = h[3];
         if (SPEC == kSpecHelper) request();  // (adopted = in a streak of rejections)
       }
+      if (wave == 0) ALTRO_STAMP_ADD(16, st_cp);
     } else if (wave == 0) {
       // ---- B ----
       backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
       // (its own LDS writes of fh[4], fh[5]: program order)
       if (SPEC == kSpecHelper && lane == 0 && armed) request();
     }
-    if (wave == 1) {
-      // running cost in knot order (ilqr.hpp:326-334)
-      double J0 = 0.0;
-      for (int k = 0; k <= N; ++k) J0 += (double)xch[k];
-      if (lane == 0) {
-        A.J0[b] = J0;
-        double ic = ic_early;
-        if (need_ic_early) {
-          ic = J0;
-          A.initial_cost[b] = J0;
-          A.need_init_cost[b] = 0;
-        }
-        fh[0] = J0;
-        fh[3] = ic;
-      }
-    }
+    // (the running cost J0 of the expansion step is summed by the auxiliary wave during the forward pass: aux_wave_run)
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
+    if (wave == 0 && adopt) ALTRO_STAMP_ADD(10, st_b);
+    const long long st_f = ALTRO_STAMP_T0();
+    const bool st_adopted = adopt;
     // ---- F ----
     spec.armed = armed;
     forward2_body<T, M, true, kSrcLds, CIRC, kSoft>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
                                                     kWave4 ? &spec : nullptr, alpha_tab,
-                                                    FwdSync<kSoft>{sync_words, loops * kFwdSeqStride});
+                                                    FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh);
     ++loops;
+    if (wave == 0 && st_adopted) ALTRO_STAMP_ADD(11, st_f);
+    const long long st_x = ALTRO_STAMP_T0();
     // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
     //  backward pass of the next iteration would read from global memory: see the end of the loop)
     if (SPEC) lds_barrier(); else __syncthreads();
+    if (wave == 0 && st_adopted) ALTRO_STAMP_ADD(12, st_x);
+#ifdef ALTRO_STAMPS
+    if (st_adopted) {
+      ++spec_iters;
+      if (wave == 0) ALTRO_STAMP_ADD(14, st_it);
+    }
+#endif
     if (!persistent || *active_flag == 0) break;
     // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
     // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
@@ -3411,6 +3518,23 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     // the next iteration reads this one's scalars from global memory: drain the stores
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
   }
+#ifdef ALTRO_STAMPS
+  __syncthreads();
+  if (tid == 0 && spec_iters > 60 && loops > 100) {  // (the stragglers: a few dozen lines)
+    const double c = 1.0 / spec_iters;
+    const double ca = 1.0 / loops;  // the per-wave stamps run in every iteration
+    printf("STAMPS (instance %d): %d iterations, %d adopted (speculated); per adopted iteration, shader-clock cycles:\n"
+           "  E %.0f | take-over %.0f | forward pass (wave 0) %.0f | barrier behind F (wave 0 waits) %.0f | whole iteration %.0f\n"
+           "  rollout wave: knot loop %.0f, wait A+S %.0f, phase 2 %.0f\n"
+           "  cost wave: knot loop + wait A %.0f, selection %.0f, phase 2 + wait V %.0f, phase 3 %.0f\n"
+           "  auxiliary wave: knot loop %.0f | fourth wave: speculative backward pass %.0f (only passes of armed iterations)\n"
+           "  take-over: copy + hand-over (wave 0) %.0f, running cost (wave 1) %.0f | E alone, waves 0..3: %.0f %.0f %.0f %.0f\n",
+           b, loops, spec_iters, c * g_stamp_acc[9], c * g_stamp_acc[10], c * g_stamp_acc[11], c * g_stamp_acc[12], c * g_stamp_acc[14],
+           ca * g_stamp_acc[0], ca * g_stamp_acc[1], ca * g_stamp_acc[2], ca * g_stamp_acc[3], ca * g_stamp_acc[4], ca * g_stamp_acc[5],
+           ca * g_stamp_acc[6], ca * g_stamp_acc[7], c * g_stamp_acc[8], c * g_stamp_acc[16], c * g_stamp_acc[15],
+           c * g_stamp_acc[17], c * g_stamp_acc[18], c * g_stamp_acc[19], c * g_stamp_acc[20]);
+  }
+#endif
   // the gains for the getters (nothing inside the sweep reads them from global memory)
   for (int i = tid; i < N * R::KP; i += kThreads) {
     const int k = i / R::KP, e = i - k * R::KP;
