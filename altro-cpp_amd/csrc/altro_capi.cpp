@@ -4,11 +4,16 @@
 // creates the device engine lazily on the first compute call, and forwards every entry point.
 // No exception crosses the boundary; there is NO CPU fallback.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <cctype>
+#include <cerrno>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -28,7 +33,9 @@
 
 using namespace altro_hip;
 
-#define ALTRO_USER_PLUGIN_ABI_HOST 3  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
+extern "C" int altro_chain_claim(int device, int delta);
+
+#define ALTRO_USER_PLUGIN_ABI_HOST 4  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -97,8 +104,42 @@ bool ReadFile(const std::string& path, std::string* out) {
 }
 std::string Tail(const std::string& s, size_t n) { return s.size() > n ? s.substr(s.size() - n) : s; }
 
+// Runs argv[0] with the given arguments, stdout and stderr into `log`: posix_spawn with an argument vector -- no shell,
+// so no quoting of paths, and independent of the host application's SIGCHLD disposition as far as waitpid allows
+// (std::system() returns -1 when SIGCHLD is ignored).  Returns the exit code, or -1.
+extern "C" char** environ;
+int RunTool(const std::vector<std::string>& args, const std::string& log) {
+  posix_spawn_file_actions_t fa;
+  if (posix_spawn_file_actions_init(&fa) != 0) return -1;
+  posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  posix_spawn_file_actions_adddup2(&fa, 1, 2);
+  std::vector<char*> argv;
+  for (const std::string& a : args) argv.push_back(const_cast<char*>(a.c_str()));
+  argv.push_back(nullptr);
+  pid_t pid = 0;
+  const int rc = posix_spawn(&pid, argv[0], &fa, nullptr, argv.data(), environ);
+  posix_spawn_file_actions_destroy(&fa);
+  if (rc != 0) return -1;
+  int status = 0;
+  for (;;) {
+    const pid_t w = waitpid(pid, &status, 0);
+    if (w == pid) break;
+    if (w < 0 && errno != EINTR) return -1;  // (ECHILD: the host reaps children itself -- the result file decides)
+  }
+  return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+// [A-Za-z0-9_] only: the name goes into the generated source (a comment and a #line directive)
+std::string SafeName(const char* name) {
+  std::string out;
+  for (const char* p = name; *p && out.size() < 64; ++p)
+    out += (std::isalnum(static_cast<unsigned char>(*p)) || *p == '_') ? *p : '_';
+  return out.empty() ? std::string("model") : out;
+}
+
 // FunctionBase::CheckJacobian (functionbase.cpp:35-73) on the device: 64 points uniform in [-1, 1]^(n+m)
-// (VectorXd::Random), forward differences with 1e-6, tolerance kDefaultTolerance = 1e-4 (functionbase.hpp:86)
+// (VectorXd::Random), central differences with 1e-6, tolerance kDefaultTolerance = 1e-4 (functionbase.hpp:86) on the error
+// relative to max(1, ||J||): the reference's forward-difference helper is an opt-in test utility, this check gates
+// registration and must not reject a correct Jacobian of a model with large second derivatives
 altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) {
   if (e.checked) return ALTRO_OK;
   const int samples = 64, nm = e.n + e.m;
@@ -113,7 +154,7 @@ altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) 
   }
   if (!(max_err < 1e-4)) {
     char buf[256];
-    snprintf(buf, sizeof(buf), "user model '%s': jac() does not match finite differences of f(): ||J_fd - J|| = %.3g >= 1e-4 "
+    snprintf(buf, sizeof(buf), "user model '%s': jac() does not match finite differences of f(): ||J_fd - J|| / max(1, ||J||) = %.3g >= 1e-4 "
              "(FunctionBase::CheckJacobian)", e.name.c_str(), max_err);
     *err = buf;
     return ALTRO_INVALID_ARG;
@@ -316,8 +357,11 @@ altro_status altro_register_model_source(const char* name, const char* source, i
       arch = arch.substr(0, arch.find(':'));
     }
   }
-  const std::string flags = "-O3 -std=c++17 -fPIC -shared -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value "
-                            "-Wno-unused-result --offload-arch=" + arch;
+  const std::vector<std::string> flagv = {"-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-mllvm",
+                                          "-amdgpu-mfma-vgpr-form=1", "-Wno-unused-value", "-Wno-unused-result",
+                                          "--offload-arch=" + arch};
+  std::string flags;
+  for (const std::string& f : flagv) flags += f + " ";
   const uint64_t hash = Fnv1a(flags, Fnv1a(hdrs, Fnv1a(source)));
   std::lock_guard<std::mutex> lk(g_models_mu);
   for (size_t i = 0; i < g_models.size(); ++i)
@@ -327,19 +371,38 @@ altro_status altro_register_model_source(const char* name, const char* source, i
     }
   std::string cache = inc + "/_user_cache";
   if (const char* e = std::getenv("ALTRO_HIP_CACHE_DIR")) cache = e;
-  mkdir(cache.c_str(), 0755);
+  mkdir(cache.c_str(), 0700);  // (plugins are code: private to the user.  Stale entries -- every header edit changes the
+                               //  hash -- are the deployment's to prune: altro_user_model_path names the live ones)
+  const std::string safe = SafeName(name);
   char hx[32];
   snprintf(hx, sizeof(hx), "%016llx", (unsigned long long)hash);
   const std::string stem = cache + "/altro_user_" + hx;
   const std::string so = stem + ".so";
-  if (access(so.c_str(), R_OK) != 0) {
+  // A cached plugin is trusted only if it says itself that it was built from this very (source, headers, flags): the
+  // generated translation unit embeds the hash, checked after dlopen.  A file that merely carries the right name is
+  // recompiled.
+  auto embedded_hash_ok = [&](void* dl) {
+    auto fn = reinterpret_cast<unsigned long long (*)()>(dlsym(dl, "altro_user_source_hash"));
+    return fn && fn() == (unsigned long long)hash;
+  };
+  void* dl = nullptr;
+  if (access(so.c_str(), R_OK) == 0) {
+    dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (dl && !embedded_hash_ok(dl)) {
+      dlclose(dl);
+      dl = nullptr;
+    }
+    if (!dl) unlink(so.c_str());
+  }
+  if (!dl) {
     const std::string src = stem + ".hip", log = stem + ".log", tmp = stem + "." + std::to_string((long)getpid()) + ".tmp.so";
     {
       std::ofstream f(src);
-      f << "// generated by altro_register_model_source for the user model '" << name << "'\n"
+      f << "// generated by altro_register_model_source for the user model '" << safe << "'\n"
         << "#include <hip/hip_runtime.h>\n#define ALTRO_MODEL_FN __device__ __forceinline__\n"
-        << "namespace altro_user {\n#line 1 \"user model " << name << "\"\n" << source << "\n}  // namespace altro_user\n"
-        << "#include \"altro_user_model.hpp\"  // (the engine headers see ALTRO_USER_COST / ALTRO_USER_CONSTRAINT)\n";
+        << "namespace altro_user {\n#line 1 \"user model " << safe << "\"\n" << source << "\n}  // namespace altro_user\n"
+        << "#include \"altro_user_model.hpp\"  // (the engine headers see ALTRO_USER_COST / ALTRO_USER_CONSTRAINT)\n"
+        << "extern \"C\" unsigned long long altro_user_source_hash() { return 0x" << hx << "ULL; }\n";
       if (!f) {
         err = "cannot write " + src + " (set ALTRO_HIP_CACHE_DIR to a writable directory)";
         return ALTRO_NOT_READY;
@@ -347,21 +410,27 @@ altro_status altro_register_model_source(const char* name, const char* source, i
     }
     std::string hipcc = "/opt/rocm/bin/hipcc";
     if (const char* e = std::getenv("HIPCC")) hipcc = e;
-    const std::string cmd = hipcc + " " + flags + " -I'" + inc + "' -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
-    const int rc = std::system(cmd.c_str());
-    if (rc != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
+    std::vector<std::string> args = {hipcc};
+    args.insert(args.end(), flagv.begin(), flagv.end());
+    args.push_back("-I" + inc);
+    args.push_back("-o");
+    args.push_back(tmp);
+    args.push_back(src);
+    const int rc = RunTool(args, log);
+    if ((rc != 0 && !(rc == -1 && access(tmp.c_str(), R_OK) == 0)) || rename(tmp.c_str(), so.c_str()) != 0) {
       std::string out;
       ReadFile(log, &out);
-      err = "compiling the user model '" + std::string(name) + "' failed:\n" + Tail(out, 1500);
+      err = "compiling the user model '" + safe + "' failed:\n" + Tail(out, 1500);
       unlink(tmp.c_str());
       return ALTRO_INVALID_ARG;
     }
+    dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
   }
   UserModelEntry e;
-  e.name = name;
+  e.name = safe;
   e.so_path = so;
   e.hash = hash;
-  e.dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+  e.dl = dl;
   if (!e.dl) {
     err = std::string("dlopen of the user-model plugin failed: ") + dlerror();
     return ALTRO_HIP_ERROR;
@@ -372,11 +441,14 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   e.check = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_jacobian"));
   auto finfo = reinterpret_cast<int (*)(int*, int*, int*, int*)>(dlsym(e.dl, "altro_user_functor_info"));
   e.check_functors = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_functors"));
-  if (!abi || !dims || !e.make || !e.check || !finfo || !e.check_functors || abi() != ALTRO_USER_PLUGIN_ABI_HOST) {
+  if (!abi || !dims || !e.make || !e.check || !finfo || !e.check_functors || abi() != ALTRO_USER_PLUGIN_ABI_HOST ||
+      !embedded_hash_ok(e.dl)) {
     err = "the cached user-model plugin " + so + " does not match this library; delete it";
     dlclose(e.dl);
     return ALTRO_HIP_ERROR;
   }
+  // one book of chained engines for built-in and plugin engines (altro_engine.hpp: ChainClaim)
+  if (auto hook = reinterpret_cast<void (*)(int (*)(int, int))>(dlsym(e.dl, "altro_user_set_chain_hook"))) hook(&altro_chain_claim);
   dims(&e.n, &e.m);
   e.functors = finfo(&e.cost_nparams, &e.con_p, &e.con_nparams, &e.con_equality);
   if (check_jacobian) {
@@ -397,6 +469,10 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   *kind_out = ALTRO_MODEL_USER_BASE + (int)g_models.size() - 1;
   return ALTRO_OK;
 }
+
+// Engines with chains of sweeps per device: the counter every engine of the process books in -- the built-in ones through
+// this library's copy of the counter (altro_common.hpp: ChainClaimLocal), plugins through the hook they are handed at load.
+int altro_chain_claim(int device, int delta) { return altro_hip::ChainClaimLocal(device, delta); }
 
 int altro_user_model_path(int kind, char* buf, int len) {
   std::lock_guard<std::mutex> lk(g_models_mu);

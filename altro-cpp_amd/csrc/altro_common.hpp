@@ -2,6 +2,7 @@
 // templated device engines (altro_engine.hpp).  No HIP types in here.
 #pragma once
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,23 @@ struct DevOpts {
   double line_search_lower_bound, line_search_upper_bound, line_search_decrease_factor;
   double constraint_tolerance, maximum_penalty, initial_penalty;
 };
+
+// Engines of this process that run their sweeps as chains on streams of their own, PER DEVICE (hardware queues are a
+// device's).  The count lives in libaltro_hip.so; a user-model plugin carries its own copy of this header, so the
+// library hands every plugin a pointer to ITS counter function at load time (altro_user_set_chain_hook): built-in and
+// plugin engines then share one book.  delta = +1 / -1 / 0 (query); returns the count after the change.
+inline int ChainClaimLocal(int device, int delta) {
+  static std::atomic<int> n[64];
+  std::atomic<int>& c = n[device >= 0 && device < 64 ? device : 63];
+  if (delta == 0) return c.load();
+  return c.fetch_add(delta) + delta;
+}
+using ChainClaimFn = int (*)(int, int);
+inline ChainClaimFn& ChainClaimHook() {
+  static ChainClaimFn fn = &ChainClaimLocal;
+  return fn;
+}
+inline int ChainClaim(int device, int delta) { return ChainClaimHook()(device, delta); }
 
 // ---- engine interface ----------------------------------------------------------------------------
 class EngineBase {

@@ -36,12 +36,6 @@ namespace altro_hip {
     }                                                                                          \
   } while (0)
 
-// engines of this process (all models and dtypes) that run their sweeps as chains on streams of their own
-inline std::atomic<int>& ChainedEngines() {
-  static std::atomic<int> n{0};
-  return n;
-}
-
 inline DevOpts ToDevOpts(const altro_options& o) {
   DevOpts d{};
   d.max_iterations_total = o.max_iterations_total;
@@ -609,7 +603,7 @@ class Engine final : public EngineBase {
     if (d_counter_) hipFree(d_counter_);
     if (h_counter_) hipHostFree((void*)h_counter_);
     for (auto& e : prof_ev_) hipEventDestroy(e);
-    if (counted_chained_) ChainedEngines().fetch_sub(1);
+    if (counted_chained_) ChainClaim(desc_.device_id, -1);
     counted_chained_ = false;
     for (int c = 1; c < kMaxChains; ++c) {
       if (chain_stream_[c]) hipStreamDestroy(chain_stream_[c]);
@@ -1050,7 +1044,7 @@ class Engine final : public EngineBase {
       chains_ = B_ >= 2048 ? kMaxChains : 1;
       // (the streams of a process share four hardware queues: a second engine with chains of its own would queue up
       //  behind this one's persistent kernel -- only the first large engine of a process gets them)
-      if (chains_ > 1 && ChainedEngines().load() > 0) chains_ = 1;
+      if (chains_ > 1 && ChainClaim(desc_.device_id, 0) > 0) chains_ = 1;
       if (const char* e = std::getenv("ALTRO_HIP_CHAINS")) chains_ = std::max(1, std::min(kMaxChains, atoi(e)));
       for (;;) {
         chain_size_ = ((B_ + chains_ - 1) / chains_ + kBlock - 1) / kBlock * kBlock;
@@ -1058,7 +1052,7 @@ class Engine final : public EngineBase {
         chains_--;  // (the last chain would be empty)
       }
       if (chains_ > 1) {
-        ChainedEngines().fetch_add(1);
+        ChainClaim(desc_.device_id, +1);
         counted_chained_ = true;
         ALTRO_ALLOC(d_iota_, bp);
         ALTRO_ALLOC(d_merged_, bp);
@@ -1075,17 +1069,31 @@ class Engine final : public EngineBase {
         // GPU_MAX_HW_QUEUES says otherwise), handed out in order of creation: with other streams around (another
         // handle, a framework's stream pool, RCCL) two chains can land on one queue and take turns -- slower than one
         // chain.  One wavefront spinning for 200 us on every chain stream: side by side they take 200 us together.
-        const long long ticks = 20000;  // of the 100 MHz constant clock
+        // Timed ON THE DEVICE: every spin kernel stamps its start and its end with the constant 100 MHz clock, and the
+        // chains run side by side iff the intervals overlap (the latest start lies well before the earliest end).  Host
+        // wall time around launches and synchronisations would also count launch latency and host jitter -- eight ranks
+        // starting at once could silently lose their chains that way.
+        const long long ticks = 20000;  // of the 100 MHz constant clock: 200 us
         ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
-        double best = 1e30;
+        long long* d_stamps = nullptr;
+        ALTRO_HIP_CHECK(hipMalloc((void**)&d_stamps, 2 * kMaxChains * sizeof(long long)));
+        long long h_stamps[2 * kMaxChains] = {0};
+        long long best_overlap = -(1ll << 60);
         for (int rep = 0; rep < 2; ++rep) {  // (the first round also loads the kernel)
-          const auto c0 = std::chrono::steady_clock::now();
           for (int c = 0; c < chains_; ++c)
-            hipLaunchKernelGGL((k_spin<0>), dim3(1), dim3(kBlock), 0, c == 0 ? stream_ : chain_stream_[c], ticks, (int*)nullptr);
+            hipLaunchKernelGGL((k_spin<0>), dim3(1), dim3(kBlock), 0, c == 0 ? stream_ : chain_stream_[c], ticks, d_stamps + 2 * c);
           for (int c = 0; c < chains_; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(c == 0 ? stream_ : chain_stream_[c]));
-          best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count());
+          ALTRO_HIP_CHECK(CopySync(h_stamps, d_stamps, sizeof(h_stamps), hipMemcpyDeviceToHost));
+          long long last_start = h_stamps[0], first_end = h_stamps[1];
+          for (int c = 1; c < chains_; ++c) {
+            last_start = std::max(last_start, h_stamps[2 * c]);
+            first_end = std::min(first_end, h_stamps[2 * c + 1]);
+          }
+          best_overlap = std::max(best_overlap, first_end - last_start);
         }
-        if (best > 1.6 * 200.0) {  // two of them ran one after the other
+        hipFree(d_stamps);
+        chain_overlap_ticks_ = best_overlap;
+        if (best_overlap < ticks / 2) {  // two of them ran (mostly) one after the other
           for (int c = 1; c < chains_; ++c) {
             hipStreamDestroy(chain_stream_[c]);
             hipEventDestroy(chain_ev_[c]);
@@ -1094,7 +1102,7 @@ class Engine final : public EngineBase {
           }
           chains_ = 1;
           chain_size_ = Bp_;
-          ChainedEngines().fetch_sub(1);
+          ChainClaim(desc_.device_id, -1);
           counted_chained_ = false;
         }
       }
@@ -1662,6 +1670,7 @@ class Engine final : public EngineBase {
   size_t stage_cap_ = 0;
   static constexpr int kMaxChains = 4;
   bool counted_chained_ = false;
+  long long chain_overlap_ticks_ = 0;  // result of the side-by-side check of the chain streams (100 MHz ticks)
   int chains_ = 1;      // chains of batched sweeps (see Chain); ALTRO_HIP_CHAINS overrides
   int chain_size_ = 0;  // instances per chain (a multiple of the wavefront size)
   hipStream_t chain_stream_[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};

@@ -3602,11 +3602,14 @@ __global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts 
 // Keeps one wavefront busy for `ticks` of the constant 100 MHz clock: the engine checks with it that the streams of its
 // chains of sweeps run side by side (streams that share a hardware queue run one after the other).
 template <int kDummy>
-__global__ __launch_bounds__(kBlock) void k_spin(long long ticks, int* sink) {
+__global__ __launch_bounds__(kBlock) void k_spin(long long ticks, long long* stamps) {
   const long long t0 = wall_clock64();
   long long t = t0;
   while (t - t0 < ticks) t = wall_clock64();
-  if (sink && t == 0) sink[0] = 1;
+  if (stamps && threadIdx.x == 0) {  // start and end on the device's constant clock
+    stamps[0] = t0;
+    stamps[1] = t;
+  }
 }
 
 // Concatenates the active lists the chains of batched sweeps leave behind into the list of the persistent kernel.

@@ -30,7 +30,7 @@
 
 namespace altro_hip {
 
-#define ALTRO_USER_PLUGIN_ABI 3  // bump when EngineBase or the entry points below change
+#define ALTRO_USER_PLUGIN_ABI 4  // bump when EngineBase or the entry points below change
 
 struct UserM : altro_user::UserModel {
   static constexpr bool kHasFusedRk4 = false;
@@ -39,8 +39,12 @@ struct UserM : altro_user::UserModel {
 };
 
 // FunctionBase::CheckJacobian (functionbase.cpp:42-73) for the continuous dynamics, one sample point per thread:
-// forward differences with step eps (utils::FiniteDiffJacobian, derivative_checker.hpp:10-40) against the
-// user's Jacobian; err[s] = Frobenius norm of the difference (MatrixComparison, functionbase.cpp:15-30).
+// finite differences with step eps against the user's Jacobian; err[s] = Frobenius norm of the difference
+// (MatrixComparison, functionbase.cpp:15-30) RELATIVE to max(1, ||J||_F).  The reference's helper differences forward
+// (utils::FiniteDiffJacobian, derivative_checker.hpp:10-40) and is an opt-in test utility that returns a bool; here the
+// check gates registration, so it must not reject a CORRECT Jacobian: central differences (truncation error of order
+// eps^2 times the third derivative instead of eps times the second: a model with large second derivatives passes)
+// and a relative tolerance.
 template <class M>
 __global__ void k_check_jacobian(const double* __restrict__ z, double* __restrict__ err, int samples, double eps) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -51,27 +55,29 @@ __global__ void k_check_jacobian(const double* __restrict__ z, double* __restric
   for (int i = 0; i < nm; ++i) x[i] = z[(size_t)s * nm + i];
   const float t = 0.37f + 0.01f * (float)(s & 15);  // (a time-varying model is checked at a few knot times)
   model_jac<double, M>(x, x + n, t, J);
-  model_f<double, M>(x, x + n, t, f0);
-  double e2 = 0.0;
+  double e2 = 0.0, j2 = 0.0;
 #pragma unroll
   for (int j = 0; j < nm; ++j) {
     const double keep = x[j];
     x[j] = keep + eps;
     model_f<double, M>(x, x + n, t, f1);
+    x[j] = keep - eps;
+    model_f<double, M>(x, x + n, t, f0);
     x[j] = keep;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-      const double d = (f1[i] - f0[i]) / eps - J[i + j * n];
+      const double d = (f1[i] - f0[i]) / (2.0 * eps) - J[i + j * n];
       e2 += d * d;
+      j2 += J[i + j * n] * J[i + j * n];
     }
   }
-  err[s] = sqrt(e2);
+  err[s] = sqrt(e2) / fmax(1.0, sqrt(j2));
 }
 
 // ScalarFunction::CheckGradient, FunctionBase::CheckHessian (functionbase.cpp:75-125) for the user's cost and
 // FunctionBase::CheckJacobian for the user's constraint, one sample (x, u, parameters) per thread, forward
 // differences: err[3 s + 0] = ||fd(eval) - gradient||, [3 s + 1] = ||fd(gradient) - hessian||_F,
-// [3 s + 2] = ||fd(eval) - jacobian||_F.
+// [3 s + 2] = ||fd(eval) - jacobian||_F, each relative to max(1, norm of the user's derivative).
 template <int n, int m>
 __global__ void k_check_functors(const double* __restrict__ z, const double* __restrict__ par_cost,
                                  const double* __restrict__ par_con, double* __restrict__ err, int samples, double eps) {
@@ -87,44 +93,56 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
     double par[NP > 0 ? NP : 1];
     for (int i = 0; i < NP; ++i) par[i] = par_cost[(size_t)s * NP + i];
     double g0[nm], g1[nm], H[nm * nm], hxx[n * n], hxu[n * m], huu[m * m];
-    const double J0 = UserCostF::eval(x, x + n, par);
     UserCostF::gradient(x, x + n, par, g0, g0 + n);
     UserCostF::hessian(x, x + n, par, hxx, hxu, huu);
     for (int j = 0; j < nm; ++j)
       for (int i = 0; i < nm; ++i)
         H[i + j * nm] = (i < n && j < n) ? hxx[i + j * n] : (i < n) ? hxu[i + (j - n) * n] : (j < n) ? hxu[j + (i - n) * n]
                                                                                                      : huu[(i - n) + (j - n) * m];
-    for (int j = 0; j < nm; ++j) {
+    double g2 = 0.0, h2 = 0.0;
+    for (int j = 0; j < nm; ++j) {  // central differences, see k_check_jacobian
       const double keep = x[j];
       x[j] = keep + eps;
-      const double J1 = UserCostF::eval(x, x + n, par);
+      const double Jp = UserCostF::eval(x, x + n, par);
       UserCostF::gradient(x, x + n, par, g1, g1 + n);
+      x[j] = keep - eps;
+      const double Jm = UserCostF::eval(x, x + n, par);
+      double gm[nm];
+      UserCostF::gradient(x, x + n, par, gm, gm + n);
       x[j] = keep;
-      const double dg = (J1 - J0) / eps - g0[j];
+      const double dg = (Jp - Jm) / (2.0 * eps) - g0[j];
       eg += dg * dg;
+      g2 += g0[j] * g0[j];
       for (int i = 0; i < nm; ++i) {
-        const double dh = (g1[i] - g0[i]) / eps - H[i + j * nm];
+        const double dh = (g1[i] - gm[i]) / (2.0 * eps) - H[i + j * nm];
         eh += dh * dh;
+        h2 += H[i + j * nm] * H[i + j * nm];
       }
     }
+    eg /= fmax(1.0, g2);
+    eh /= fmax(1.0, h2);
   }
   if constexpr (kHasUserCon) {
     constexpr int P = UserConF::p, NP = UserConF::nparams;
     double par[NP > 0 ? NP : 1];
     for (int i = 0; i < NP; ++i) par[i] = par_con[(size_t)s * NP + i];
     double c0[P], c1[P], J[P * nm];
-    UserConF::eval(x, x + n, par, c0);
     UserConF::jacobian(x, x + n, par, J);
+    double j2 = 0.0;
     for (int j = 0; j < nm; ++j) {
       const double keep = x[j];
       x[j] = keep + eps;
       UserConF::eval(x, x + n, par, c1);
+      x[j] = keep - eps;
+      UserConF::eval(x, x + n, par, c0);
       x[j] = keep;
       for (int r = 0; r < P; ++r) {
-        const double dj = (c1[r] - c0[r]) / eps - J[r + j * P];
+        const double dj = (c1[r] - c0[r]) / (2.0 * eps) - J[r + j * P];
         ej += dj * dj;
+        j2 += J[r + j * P] * J[r + j * P];
       }
     }
+    ej /= fmax(1.0, j2);
   }
   err[3 * s + 0] = sqrt(eg);
   err[3 * s + 1] = sqrt(eh);
@@ -136,6 +154,11 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
 extern "C" {
 
 int altro_user_abi() { return ALTRO_USER_PLUGIN_ABI; }
+
+// the library's book of engines that own chains of sweeps (altro_engine.hpp: ChainClaim): plugins share it
+void altro_user_set_chain_hook(int (*fn)(int, int)) {
+  if (fn) altro_hip::ChainClaimHook() = fn;
+}
 
 void altro_user_dims(int* n, int* m) {
   *n = altro_hip::UserM::n;

@@ -186,3 +186,53 @@ def test_user_cost_and_constraint_match_the_oracle(A, P, hip_make, track_oracle,
     # the sway limit holds (to the constraint tolerance) and is active for the long moves
     sway = np.abs(0.5 * np.sin(Xg[:, :, 1])).max(axis=1)
     assert (sway[ok] < 0.04 + 1e-3).all() and (sway[ok][-5:] > 0.04 - 1e-3).all(), sway
+
+
+@pytest.mark.gpu
+def test_plugin_is_compiled_on_this_machine_and_a_stale_cache_entry_is_rebuilt(A, P, hip_make, cartpole_oracle, tmp_path):
+    """The run-time compile itself: a source with a nonce cannot be in any cache, so hipcc really
+    runs HERE, for the architecture of the device that is present; the plugin it produces solves like the oracle.  Then
+    the cache entry is overwritten with ANOTHER plugin under the same file name: the next process notices (the generated
+    translation unit embeds its hash) and rebuilds instead of loading foreign code."""
+    import shutil
+    import subprocess
+    import sys
+    import time
+    nonce = time.time_ns()
+    script = f"""
+import sys, time, os
+sys.path.insert(0, {ROOT!r})
+import __graft_entry__ as g
+A = g.load_package()
+src = open({os.path.join(ROOT, 'tests', 'models', 'cartpole.hpp')!r}).read() + "\\n// nonce {nonce}\\n"
+t0 = time.perf_counter()
+kind = A.register_model_source("cartpole nonce/\\"x", src)   # (a name that needs sanitising)
+print("SECONDS", time.perf_counter() - t0)
+print("PATH", A.user_model_path(kind))
+import importlib, numpy as np
+P = importlib.import_module("altro_cpp_amd.problems")
+s = P.cartpole_move(lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d), kind, batch=6, goal=np.linspace(0.5, 1.5, 6))
+s.solve()
+print("ITERS", s.get_stats()["iterations_total"].tolist())
+"""
+    env = dict(os.environ, ALTRO_HIP_CACHE_DIR=str(tmp_path))
+    env.pop("ALTRO_HIP_ARCH", None)  # the architecture of the device that is here
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("SECONDS", "PATH", "ITERS"))
+        return float(out["SECONDS"]), out["PATH"], out["ITERS"]
+
+    sec1, path1, iters1 = run()
+    assert sec1 > 3.0 and os.path.dirname(path1) == str(tmp_path)  # compiled, here
+    o = P.cartpole_move(cartpole_oracle, 0, batch=6, goal=np.linspace(0.5, 1.5, 6))
+    o.solve()
+    assert iters1 == str(o.get_stats()["iterations_total"].tolist())
+    sec2, path2, iters2 = run()
+    assert sec2 < 2.0 and path2 == path1 and iters2 == iters1  # second process: the cache entry is taken
+    # foreign code under the cached name: the plugin of another source (any other .so of the in-tree cache)
+    other = A.user_model_path(A.register_model_source("cartpole", CARTPOLE))
+    shutil.copyfile(other, path1)
+    sec3, path3, iters3 = run()
+    assert sec3 > 3.0 and path3 == path1 and iters3 == iters1  # noticed and rebuilt
