@@ -20,17 +20,23 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 CASES = {
-    # name: (factory name, kwargs, solve mode)
+    # name: (factory name, kwargs, solve mode[, kwargs the HIP product takes instead])
     "c1_three_obstacles": ("unicycle_three_obstacles", dict(batch=1), "al"),
     "c2_triple_integrator": ("batch_triple_integrator", dict(batch=8), "ilqr"),
     "c3_turn90": ("batch_turn90", dict(batch=8), "al"),
     "c4_three_obstacles_batch": ("batch_three_obstacles", dict(batch=4, dtype=0), "al"),
     "c5_quadrotor12": ("batch_quadrotor12", dict(batch=4, dtype=0), "al"),
+    # ALTRO_F32 (the dtype BASELINE configs[3] and [4] name): fp64 arithmetic with fp32 expansion / gain records.  The
+    # fixture is the RECORD-ROUNDING oracle (oracle dtype 2); the product is created with ALTRO_F32 (dtype 1).
+    "c4_three_obstacles_f32": ("batch_three_obstacles", dict(batch=4, dtype=2), "al", dict(dtype=1)),
+    "c5_quadrotor12_f32": ("batch_quadrotor12", dict(batch=4, dtype=2), "al", dict(dtype=1)),
 }
 
 
-def solve_case(P, make, name):
-    fac, kw, mode = CASES[name]
+def solve_case(P, make, name, product=False):
+    fac, kw, mode = CASES[name][:3]
+    if product and len(CASES[name]) > 3:
+        kw = dict(kw, **CASES[name][3])
     s = getattr(P, fac)(make, **kw)
     (s.solve if mode == "al" else s.solve_ilqr)()
     st = s.get_stats()

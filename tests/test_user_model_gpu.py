@@ -226,7 +226,7 @@ print("ITERS", s.get_stats()["iterations_total"].tolist())
 
     sec1, path1, iters1 = run()
     assert sec1 > 3.0 and os.path.dirname(path1) == str(tmp_path)  # compiled, here
-    o = P.cartpole_move(cartpole_oracle, 0, batch=6, goal=np.linspace(0.5, 1.5, 6))
+    o = P.cartpole_move(cartpole_oracle, A.MODEL_USER_BASE, batch=6, goal=np.linspace(0.5, 1.5, 6))
     o.solve()
     assert iters1 == str(o.get_stats()["iterations_total"].tolist())
     sec2, path2, iters2 = run()
