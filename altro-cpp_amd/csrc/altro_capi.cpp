@@ -829,6 +829,10 @@ int altro_get_history(altro_handle h, int instance, int field, double* out, int 
   if (!h || !out || Busy(h) || Ensure(h) != ALTRO_OK) return -1;
   return h->engine->GetHistory(instance, field, out, cap);
 }
+int altro_get_history_all(altro_handle h, int instance, double* out, int cap) {
+  if (!h || !out || Busy(h) || Ensure(h) != ALTRO_OK) return -1;
+  return h->engine->GetHistoryAll(instance, out, cap);
+}
 altro_status altro_device_info(altro_handle h, char* name, int name_len, int* cu_count) {
   if (!h) return ALTRO_INVALID_ARG;
   return Forward(h, [&](EngineBase& e) { return e.DeviceInfo(name, name_len, cu_count); });

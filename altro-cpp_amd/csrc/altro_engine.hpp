@@ -456,6 +456,22 @@ class Engine final : public EngineBase {
       return -1;
     return cnt;
   }
+  // every field of one instance's history at once: one synchronisation in front, the eight column copies enqueued back
+  // to back, one synchronisation behind (the per-field call costs three per field)
+  int GetHistoryAll(int instance, double* out, int cap) override {
+    if (!A_.hist || instance < 0 || instance >= B_ || cap <= 0) return -1;
+    if (hipSetDevice(desc_.device_id) != hipSuccess) return -1;
+    int len = 0;
+    if (CopySync(&len, A_.hist_len + instance, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const int cnt = std::min(std::min(len, A_.hist_cap), cap);
+    if (cnt <= 0) return 0;
+    for (int f = 0; f < kHistFields; ++f)
+      if (hipMemcpy2DAsync(out + (size_t)f * cap, sizeof(double), A_.hist + (size_t)f * A_.hist_cap * Bp_ + instance,
+                           (size_t)Bp_ * sizeof(double), sizeof(double), (size_t)cnt, hipMemcpyDeviceToHost, stream_) != hipSuccess)
+        return -1;
+    if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
+    return cnt;
+  }
   altro_status DeviceInfo(char* name, int name_len, int* cu_count) override {
     hipDeviceProp_t p;
     ALTRO_HIP_CHECK(hipGetDeviceProperties(&p, desc_.device_id));

@@ -522,7 +522,7 @@ problem::Problem BuildAugLagProblem(const problem::Problem& prob) {
 namespace ilqr {
 
 constexpr int kHistoryBatchLimit = 64;   // batches up to this size record the per-iteration history by default
-constexpr int kHistoryCapacity = 302;    // rows kept per instance (max_iterations_total + the initial row)
+constexpr int kHistoryCapacity = 302;    // rows kept per instance at least (default max_iterations_total + the initial row)
 
 namespace detail_ilqr {
 // State shared by an iLQR solver, the AL solver built on it and the knot-point views: the C-ABI handle, the
@@ -537,6 +537,7 @@ struct Core {
   std::shared_ptr<Trajectory<n, m>> traj;
   bool pushed = false;
   bool record_history = false;
+  int hist_cap = 0;  // rows of the device-side history per instance
   int stats_instance = 0;
   unsigned epoch = 0;
   std::vector<std::vector<examples::ConstraintDesc>> cons;  // per knot, solver order (empty without AL)
@@ -664,7 +665,7 @@ class iLQR {
     if (prob.IsAugLag())
       for (int k = 0; k <= c_->N; ++k) c_->cons[k] = prob.Constraints(k);
     SetRecordHistory(c_->B <= kHistoryBatchLimit);
-    SetRecordCostToGo(c_->B <= kHistoryBatchLimit);
+    ctg_auto_ = c_->B <= kHistoryBatchLimit;  // (see SetRecordCostToGo)
   }
   bool IsInitialized() const { return c_->h != nullptr; }
 
@@ -679,16 +680,33 @@ class iLQR {
   void SelectInstance(int b) { c_->stats_instance = b; }
   // per-iteration vectors of SolverStats (solver_stats.hpp:56-63) need the device to log every iteration
   void SetRecordHistory(bool on) {
-    detail::Check(Need(), altro_set_record_history(c_->h, on ? kHistoryCapacity : 0), "altro_set_record_history");
+    c_->hist_cap = on ? HistoryRowsNeeded() : 0;
+    detail::Check(Need(), altro_set_record_history(c_->h, c_->hist_cap), "altro_set_record_history");
     c_->record_history = on;
   }
+  // rows the SolverStats vectors can reach under the current options (one per iteration + the initial row)
+  int HistoryRowsNeeded() const { return std::max(kHistoryCapacity, c_->opts.max_iterations_total + 2); }
 
-  // KnotPointFunctions::GetCostToGoHessian / Gradient need the backward pass to store P, p of every knot
-  // (the solve itself only needs them in registers).  On by default for batches of up to kHistoryBatchLimit
-  // instances; switch it off for timing runs: the persistent tail kernel only runs without it.
+  // KnotPointFunctions::GetCostToGoHessian / Gradient need the backward pass to store P, p of every knot (the solve
+  // itself only needs them in registers, and the persistent tail kernel -- the fast path of exactly the small batches a
+  // facade user solves -- only runs without the recording).  Default for batches of up to kHistoryBatchLimit instances:
+  // the STEP-LEVEL BackwardPass() records (that is where the reference's tests read the cost-to-go:
+  // test/ilqr/unicycle_ilqr_test.cpp:39-54), Solve() does not.  SetRecordCostToGo(true) records everywhere (a Solve()
+  // then takes the batched kernels only), SetRecordCostToGo(false) nowhere.
   void SetRecordCostToGo(bool on) {
+    ctg_auto_ = false;
+    ApplyRecordCtg(on);
+  }
+  void ApplyRecordCtg(bool on) {
+    if (on == record_ctg_) return;
     detail::Check(Need(), altro_set_record_ctg(c_->h, on ? 1 : 0), "altro_set_record_ctg");
     record_ctg_ = on;
+  }
+  // called in front of every whole solve (also by AugmentedLagrangianiLQR::Solve): recording policy and a history
+  // buffer large enough for the iteration caps in force
+  void PrepareSolve() {
+    if (ctg_auto_) ApplyRecordCtg(false);
+    if (c_->record_history && HistoryRowsNeeded() > c_->hist_cap) SetRecordHistory(true);
   }
 
   std::shared_ptr<Trajectory<n, m>> GetTrajectory() { return c_->traj; }
@@ -709,6 +727,7 @@ class iLQR {
 
   void Solve() {  // ilqr.hpp:284-316
     Push();
+    PrepareSolve();
     detail::Check(c_->h, altro_solve_ilqr(c_->h), "altro_solve_ilqr");
     Pull(true, true);
   }
@@ -735,6 +754,7 @@ class iLQR {
   }
   void BackwardPass() {  // ilqr.hpp:385-445
     PushOptions();
+    if (ctg_auto_) ApplyRecordCtg(true);
     detail::Check(c_->h, altro_backward_pass(c_->h), "altro_backward_pass");
     ++c_->epoch;
     PullStats();
@@ -808,13 +828,12 @@ class iLQR {
                                    &S.regularization, &S.violations, &S.max_penalty};
     const double last[8] = {s.cost, s.alpha, s.improvement_ratio, s.gradient, s.cost_decrease, s.regularization,
                             s.violation, s.max_penalty};
-    std::vector<double> buf(kHistoryCapacity);
+    const int cap = std::max(c_->hist_cap, 1);
+    std::vector<double> buf((size_t)8 * cap);
+    const int cnt = c_->record_history ? altro_get_history_all(c_->h, b, buf.data(), cap) : 0;  // one call, one sync
     for (int f = 0; f < 8; ++f) {
       vec[f]->clear();
-      if (c_->record_history) {
-        const int cnt = altro_get_history(c_->h, b, f, buf.data(), kHistoryCapacity);
-        if (cnt > 0) vec[f]->assign(buf.begin(), buf.begin() + cnt);
-      }
+      if (cnt > 0) vec[f]->assign(buf.begin() + (size_t)f * cap, buf.begin() + (size_t)f * cap + cnt);
       vec[f]->push_back(last[f]);
     }
   }
@@ -831,6 +850,7 @@ class iLQR {
   SolverStatus status_al_ = SolverStatus::kUnsolved;
   altro_options o_{};
   bool record_ctg_ = false;
+  bool ctg_auto_ = false;
 };
 }  // namespace ilqr
 
@@ -869,6 +889,7 @@ class AugmentedLagrangianiLQR {
   void Solve() {  // al_solver.hpp:304-334
     ilqr_solver_.MarkTrajectoryDirty();  // the caller may have refilled the shared trajectory (auglag_test.cpp:366)
     ilqr_solver_.Push();
+    ilqr_solver_.PrepareSolve();
     detail::Check(Handle(), altro_solve_al(Handle()), "altro_solve_al");
     ilqr_solver_.Pull(true, true);
     status_ = ilqr_solver_.StatusAL();
@@ -933,6 +954,7 @@ class AugmentedLagrangianiLQR {
   void SolveAsync() {
     ilqr_solver_.MarkTrajectoryDirty();
     ilqr_solver_.Push();
+    ilqr_solver_.PrepareSolve();
     detail::Check(Handle(), altro_solve_al_async(Handle()), "altro_solve_al_async");
   }
   bool Poll() {

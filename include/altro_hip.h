@@ -369,6 +369,9 @@ altro_status altro_get_timing(altro_handle h, altro_timing* t);
  * 6 violations, 7 max_penalty.  Returns the number of rows written to out (<= cap). */
 altro_status altro_set_record_history(altro_handle h, int capacity);
 int altro_get_history(altro_handle h, int instance, int field, double* out, int cap);
+/* All eight fields of one instance in one call: out[field][cap] (row stride cap), returns the rows per field.  One
+ * device synchronisation instead of one per field -- what a SolverStats mirror refreshes after every compute call. */
+int altro_get_history_all(altro_handle h, int instance, double* out, int cap);
 
 /* ---- device interop (multi-GPU gather without a host round trip) ------------------------------ */
 /* Pack {cost, violation, iterations_total, status} as 4 fp64 per instance into caller-provided

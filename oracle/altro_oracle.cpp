@@ -1853,4 +1853,14 @@ int oracle_get_history(oracle_handle h, int instance, int field, double* out, in
   return cnt;
 }
 
+int oracle_get_history_all(oracle_handle h, int instance, double* out, int cap) {
+  int cnt = 0;
+  for (int f = 0; f < 8; ++f) {
+    const int c = oracle_get_history(h, instance, f, out + (size_t)f * cap, cap);
+    if (c < 0) return -1;
+    cnt = c;
+  }
+  return cnt;
+}
+
 }  // extern "C"

@@ -366,8 +366,40 @@ static void KnotTimeTests() {
   }
 }
 
+// ---- what the facade records by default (cost-to-go, history) and what that costs ------------------------------------
+static void RecordingPolicyTests() {
+  CASE("Solve() of a small batch takes the persistent kernel; the step-level BackwardPass() records the cost-to-go");
+  problems::UnicycleProblem def;
+  auto ps = def.MakeALSolver();
+  augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& solver = *ps;
+  solver.GetOptions().profiler_enable = true;
+  solver.Solve();
+  EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.GetStats().iterations_total == 11);
+  EXPECT(solver.GetTiming().fused_sweeps > 0);  // (round 2: the default recording kept the facade off this path)
+  EXPECT(solver.GetStats().alpha.size() == 12 && solver.GetStats().alpha[0] == 0.0625);  // history: one call, all fields
+  bool threw = false;
+  try {
+    solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient();
+  } catch (const std::runtime_error&) {
+    threw = true;  // not recorded by a whole solve unless asked for
+  }
+  EXPECT(threw);
+  solver.GetiLQRSolver().SetRecordCostToGo(true);
+  solver.SetTrajectory(def.InitialTrajectory());
+  solver.Solve();
+  EXPECT(solver.GetStats().iterations_total == 11 && solver.GetTiming().fused_sweeps == 0);
+  EXPECT(solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient().size() == 3);
+  CASE("The history follows max_iterations_total (no silent truncation at 300 rows)");
+  solver.GetOptions().max_iterations_total = 450;
+  solver.SetTrajectory(def.InitialTrajectory());
+  solver.Solve();
+  EXPECT(solver.GetiLQRSolver().HistoryRowsNeeded() == 452 && solver.GetStats().iterations_total == 11);
+  EXPECT(solver.GetStats().cost.size() == 12);
+}
+
 int main() {
   try {
+    RecordingPolicyTests();
     KnotTimeTests();
     UnicycleiLQRTest();
     AugLagTest();
