@@ -5,12 +5,14 @@ export TMPDIR=/tmp
 C=${1:-2}
 P=gpurun_out/profile_c$C
 rm -rf $P; mkdir -p $P
-CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o bench -- $CMD > $P/trace_run.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -o bench -- $CMD > $P/fetch_run.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -o bench -- $CMD > $P/write_run.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $P/sq -o bench -- $CMD > $P/sq_run.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $P/mfma -o bench -- $CMD > $P/mfma_run.log 2>&1
+# L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS), MI355X_MICROARCH.md): do the candidate stores and re-reads stay in L2?
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/tcc -o bench -- $CMD > $P/tcc_run.log 2>&1
 python - $P <<'PY'
 import csv, glob, collections, json, sys
 P = sys.argv[1]
@@ -20,7 +22,7 @@ def short(name):
         if k in name: return k
     return name[:40]
 out = {}
-for tag in ('fetch', 'write', 'sq', 'mfma'):
+for tag in ('fetch', 'write', 'sq', 'mfma', 'tcc'):
     f = glob.glob(f'{P}/{tag}/**/*counter_collection.csv', recursive=True)
     if not f: continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -39,6 +41,10 @@ json.dump(out, open(f'{P}/summary.json', 'w'), indent=1)
 for k, v in out.items():
     if 'trace' in v and v['trace']['pct'] > 1.0: print(k, json.dumps(v)[:700])
 PY
-for d in trace fetch write sq mfma; do rm -rf $P/$d; done
-python bench.py --config $C --steps 5 --warmup 1 2>&1 | tail -1 > $P/bench_line.json
+for d in trace fetch write sq mfma tcc; do rm -rf $P/$d; done
+if [ "$C" = "2" ]; then
+  python bench.py --config $C --steps 5 --warmup 1 2>&1 | tail -1 > $P/bench_line.json
+else
+  python bench.py --config $C --steps 5 --warmup 1 --no-other-configs --no-latency 2>&1 | tail -1 > $P/bench_line.json
+fi
 ls $P
