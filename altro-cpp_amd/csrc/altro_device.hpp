@@ -743,8 +743,10 @@ struct CtxL {
   const T* sIp;    // per-instance parameter slots (LDS)
   const T* sLam;   // duals (LDS)
   const T* sPen;   // penalties (LDS)
-  ALTRO_DEV CtxL(const DevArrays<T>& A_, int b_, const T* pool_, const T* ip_, const T* lam_, const T* pen_)
-      : A(A_), b((unsigned)b_), sPool(pool_), sIp(ip_), sLam(lam_), sPen(pen_) {}
+  T* cdst;         // where store_c puts the constraint values: nullptr = the global c_ rows; otherwise an LDS scratch
+                   // [row] (the expansions computed AHEAD by the persistent kernel, committed later or dropped)
+  ALTRO_DEV CtxL(const DevArrays<T>& A_, int b_, const T* pool_, const T* ip_, const T* lam_, const T* pen_, T* cdst_ = nullptr)
+      : A(A_), b((unsigned)b_), sPool(pool_), sIp(ip_), sLam(lam_), sPen(pen_), cdst(cdst_) {}
   ALTRO_DEV T par(int per_instance, int off, int i) const {
     const T* base = per_instance ? sIp : sPool;  // both LDS
     return base[off + i];
@@ -752,7 +754,10 @@ struct CtxL {
   ALTRO_DEV T shared(int off) const { return sPool[off]; }
   ALTRO_DEV T lam(int r) const { return sLam[r]; }
   ALTRO_DEV T pen(int r) const { return sPen[r]; }
-  ALTRO_DEV void store_c(int r, T c) const { A.cval[(unsigned)r * (unsigned)A.Bp + b] = c; }
+  ALTRO_DEV void store_c(int r, T c) const {
+    if (cdst) cdst[r] = c;
+    else A.cval[(unsigned)r * (unsigned)A.Bp + b] = c;
+  }
 };
 
 // Dual-cone projection and its (diagonal) Jacobian (altro/constraints/constraint.hpp:70-78 for

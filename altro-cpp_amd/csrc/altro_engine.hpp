@@ -1200,8 +1200,9 @@ class Engine final : public EngineBase {
       fused_lds_bytes_ = (shared_bytes + (2 * kSyncFused - kFwdSlots) * (size_t)nm * kBlock * sizeof(T) + per_inst + 15) / 16 * 16 +
                          (4 + 2 + kBlock + 2 + 16) * sizeof(double) +
                          (size_t)(N_ + 1) * kLineSearchLanes * nm * sizeof(T) +  // + the candidates of one instance
-                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 40 * sizeof(double) +  // + the speculative pass (gains, hand-over), step-length table, sequence words
-                         ((size_t)N_ + 2) * sizeof(T);                                     // + the knot costs of the expansion step
+                         ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 48 * sizeof(double) +  // + the speculative pass (gains, hand-over), step-length table, sequence words
+                         ((size_t)N_ + 4) * sizeof(T) +                                    // + the knot costs of the expansion step
+                         padv((size_t)rows) * sizeof(T);                                   // + the constraint values of the expansions computed ahead
       kdg_ = false;
       rg_ = false;
       if constexpr (kRgEligible) {

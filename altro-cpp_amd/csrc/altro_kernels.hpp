@@ -44,6 +44,7 @@ constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost 
 #define ALTRO_SYNC_FUSED 4
 #endif
 constexpr int kSyncFused = ALTRO_SYNC_FUSED;
+constexpr int kFwdSpinLimit = 1 << 22;   // polls of an LDS sequence word (~0.1 us each) before a wave gives up
 // Debugging aid (ALTRO_HIP_DEBUG_POISON): fills the LDS of the CU it lands on with a pattern, so that a kernel that reads
 // LDS it has not written computes with the pattern instead of with whatever the previous kernel happened to leave there.
 template <int kDummy>
@@ -1608,7 +1609,8 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
                               int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
                               int* active_out = nullptr, T* sLamW = nullptr, T* sPenW = nullptr,
                               double* ff = nullptr, int kd_stride = Rec<T, M::n, M::m>::KP,
-                              int kd_off = Rec<T, M::n, M::m>::oD) {
+                              int kd_off = Rec<T, M::n, M::m>::oD, const int* eahead_words = nullptr, int eahead_waves = 0,
+                              int eahead_tag = 0) {
   constexpr int m = M::m;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -1681,6 +1683,15 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   bool active = true;
   if (inner_done) {
     if (mode == kFwdAL) {
+      // (persistent kernel: the other waves may be computing the next iteration's expansions AHEAD from the LDS copies
+      //  of the multipliers that the sweeps below rewrite -- k_sweep_fused, "E AHEAD".  Their result is dropped when
+      //  the inner solve ends, but the records they leave in memory must be this iteration's, not a mixture: wait
+      //  until they are through.  Bounded like every poll of the kernel.)
+      if (eahead_words && !accepted) {
+        for (int w = 0; w < eahead_waves; ++w)
+          for (int tries = 0; tries < kFwdSpinLimit; ++tries)
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(eahead_words + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= eahead_tag) break;
+      }
       // AugmentedLagrangianiLQR: UpdateDuals, UpdateConvergenceStatistics, IsDone, UpdatePenalties
       // (al_solver.hpp:313-401); each lane sweeps the rows of knots t, t+20, ...
       T vpart = T(0), ppart = T(0);
@@ -2243,8 +2254,9 @@ ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
 // it cannot hang the GPU).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFwdSeqStride = 1 << 12;   // > stretches of one forward pass (N / G + 2)
-constexpr int kFwdSpinLimit = 1 << 22;   // polls (~0.1 us each) before a wave gives up
-enum FwdSyncWord { kSyPub = 0, kSyErr = 1, kSyCons0 = 2, kSyCons1 = 3, kSyA = 4, kSyS = 5, kSyV0 = 6, kSyV1 = 7, kSyWords = 8 };
+enum FwdSyncWord { kSyPub = 0, kSyErr = 1, kSyCons0 = 2, kSyCons1 = 3, kSyA = 4, kSyS = 5, kSyV0 = 6, kSyV1 = 7,
+                   kSyEAhead0 = 8,  // + wave index 0..2: iteration whose expansions-ahead that wave has finished (all modes)
+                   kSyWords = 16 };
 template <bool SOFT>
 struct FwdSync {
   int* w;    // kSyWords ints in LDS, 8-byte aligned (SOFT only)
@@ -2810,7 +2822,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
                              const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr,
                              const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
-                             double* fhw = nullptr) {
+                             double* fhw = nullptr, const int* eahead_words = nullptr, int eahead_waves = 0,
+                             int eahead_tag = 0) {
   static_assert(!SOFT || FUSED, "software synchronisation is a mode of the persistent kernel");
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -3090,6 +3103,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       if (spec->armed) ALTRO_STAMP_ADD(8, st_w3);
       if (!SOFT)
         for (const int bars = N / G + 1 + 3; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
+      else
+        sy.await_s();  // (the selection is published: the caller reads it -- expansions ahead, k_sweep_fused)
       return;
     }
   }
@@ -3210,7 +3225,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   }
   forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
-                       FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff);
+                       FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff, eahead_words, eahead_waves, eahead_tag);
   ALTRO_STAMP_ADD(6, st_w1d);
 }
 
@@ -3346,9 +3361,10 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8, false};
   int* const remote_ok = reinterpret_cast<int*>(fh2 + 10);  // helper mode: the poll's verdict for the workgroup
   T* const alpha_tab = reinterpret_cast<T*>(fh2 + 12);      // [20] step lengths of the line-search lanes (ilqr.hpp:544)
-  int* const sync_words = reinterpret_cast<int*>(fh2 + 12 + kLineSearchLanes);  // [kSyWords] FwdSync<true> (kSpecFree)
-  if (kSoft && tid < kSyWords) sync_words[tid] = 0;  // (visible behind the staging barrier of the first iteration)
-  T* const sCost = reinterpret_cast<T*>(fh2 + 12 + kLineSearchLanes + 4);  // [N + 1] knot costs of the expansion step
+  int* const sync_words = reinterpret_cast<int*>(fh2 + 12 + kLineSearchLanes);  // [kSyWords] FwdSync<true> (kSpecFree), E ahead
+  if (tid < kSyWords) sync_words[tid] = 0;  // (visible behind the staging barrier of the first iteration)
+  T* const sCost = reinterpret_cast<T*>(fh2 + 12 + kLineSearchLanes + kSyWords / 2);  // [N + 1] knot costs of the expansion step
+  T* const sCvalAhead = sCost + ((N + 2) & ~1);  // [total_rows] constraint values of the expansions computed ahead
   if (tid < kLineSearchLanes) {
     T alpha = T(1);
     for (int i = 0; i < tid; ++i) alpha /= T(o.line_search_decrease_factor);
@@ -3370,6 +3386,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   double prev_rho = -1.0, prev_drho = -1.0;
   int skipped = 0;
   int loops = 0;
+  bool e_done = false;  // this iteration's expansions were computed beside phase 3 of the previous one
 #ifdef ALTRO_STAMPS
   if (tid < 32) g_stamp_acc[tid] = 0;
   int spec_iters = 0;
@@ -3388,17 +3405,18 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     }
     // (the two per-instance scalars the running-cost wave needs after E: requested now, their memory latency -- two
     //  dependent round trips -- runs beside the expansions instead of behind them)
-    // ---- E: expansions from the LDS block ----
-    {
-      const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
-                       sm + L.nX + L.nU + L.nKD + L.rowsP());
+    // ---- E: expansions from the LDS block (unless they were computed AHEAD, beside phase 3 of the previous iteration:
+    //      see the end of the loop) ----
+    const CtxL<T> CE(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
+                     sm + L.nX + L.nU + L.nKD + L.rowsP());
+    if (!e_done) {
       expansion_from_lds<T, M>(A, pd, CE, sm, sm + L.nX, sCost, b, tid, kThreads);
       if (adopt) ALTRO_STAMP_ADD(17 + wave, st_it);  // (17..20: each wave's own share of E)
+      // drains the stores: the records are in L2 for the backward wave, the costs in LDS.  (A speculated iteration runs
+      // no backward pass of its own, and the records it just rewrote are bit for bit the ones the fourth wave will read:
+      // only the LDS traffic has to settle -- the two microseconds of store acknowledgements stay off the chain.)
+      if (SPEC && adopt) lds_barrier(); else __syncthreads();
     }
-    // drains the stores: the records are in L2 for the backward wave, the costs in LDS.  (A speculated iteration runs
-    // no backward pass of its own, and the records it just rewrote are bit for bit the ones the fourth wave will read:
-    // only the LDS traffic has to settle -- the two microseconds of store acknowledgements stay off the chain.)
-    if (SPEC && adopt) lds_barrier(); else __syncthreads();
     if (wave == 0 && adopt) ALTRO_STAMP_ADD(9, st_it);
     const long long st_b = ALTRO_STAMP_T0();
 
@@ -3450,10 +3468,31 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     spec.armed = armed;
     forward2_body<T, M, true, kSrcLds, CIRC, kSoft>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
                                                     kWave4 ? &spec : nullptr, alpha_tab,
-                                                    FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh);
+                                                    FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh,
+                                                    sync_words + kSyEAhead0, persistent ? (kWave4 ? 3 : 2) : 0, loops + 1);
     ++loops;
     if (wave == 0 && st_adopted) ALTRO_STAMP_ADD(11, st_f);
     const long long st_x = ALTRO_STAMP_T0();
+    // ---- E AHEAD.  Phase 3 runs on the cost wave alone; the other waves left the forward pass behind barrier V and
+    //      would only wait for it.  If the line search rejected every trial, the trajectory and -- unless phase 3 ends
+    //      the inner solve -- the multipliers are what they were, so the next iteration's expansions can be computed
+    //      NOW, from the same LDS block, by the waves that are free: the same work the next iteration would do at its
+    //      top (nothing is skipped), 6 000 cycles earlier.  If phase 3 does end the inner solve (dual / penalty update)
+    //      or the instance, the result is discarded and E runs again as usual. ----
+    //      Two things keep the state exactly the reference's: the constraint values c_ that an expansion step stores
+    //      (ilqr.hpp:675 -> al_cost.hpp:264-274) go to an LDS scratch and are committed only when the expansions are the
+    //      next iteration's -- phase 3's dual update reads the c_ the line search left (quirk Q6) --, and the cost wave
+    //      holds its dual / penalty sweeps until these waves are through (forward_phase3), so that the records left in
+    //      memory when the instance finishes are this iteration's own.
+    if (persistent && wave != 1 && reinterpret_cast<const int*>(xch)[1] == 0) {
+      constexpr int kAhead = kWave4 ? 3 : 2;                     // waves 0, 2 (, 3)
+      const int wi = wave == 0 ? 0 : wave - 1;                   // 0, 1 (, 2)
+      const CtxL<T> CA(A, b, sPool, sm + L.nX + L.nU + L.nKD + 2 * L.rowsP(), sm + L.nX + L.nU + L.nKD,
+                       sm + L.nX + L.nU + L.nKD + L.rowsP(), sCvalAhead);
+      expansion_from_lds<T, M>(A, pd, CA, sm, sm + L.nX, sCost, b, wi * kBlock + lane, kAhead * kBlock);
+      if (lane == 0) FwdSync<true>::post(sync_words + kSyEAhead0 + wi, loops);  // (loops: already this iteration's number + 1)
+      if (wave == 0 && st_adopted) ALTRO_STAMP_ADD(21, st_x);
+    }
     // (phase 2's stores were drained by barrier V; what is in flight now are the scalars of phase 3, which only a
     //  backward pass of the next iteration would read from global memory: see the end of the loop)
     if (SPEC) lds_barrier(); else __syncthreads();
@@ -3465,6 +3504,11 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     }
 #endif
     if (!persistent || *active_flag == 0) break;
+    // (the expansions ahead are the next iteration's iff the step was rejected and the inner solve goes on: then their
+    //  constraint values become c_, as the expansion step at the top of the loop would have stored them)
+    e_done = ff[0] != 0.0 && ff[3] == 0.0;
+    if (e_done)
+      for (int r = tid; r < pd->total_rows; r += kThreads) A.cval[(unsigned)r * Bp + (unsigned)b] = sCvalAhead[r];
     // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
     // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
     if (kWave4) adopt = armed && fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
@@ -3510,6 +3554,10 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
           for (int j = 0; j < k; ++j) hist_push(A, b);
           skipped += k;  // (kept apart from `loops`, which must stay wave-uniform)
         }
+        // the cost wave of the next iteration reads these counters from global memory (load_inst_pre): another wave, and
+        // the barrier below may be LDS-only -- drain this wave's stores first (with the expansions computed ahead there
+        // is no expansion phase in between any more to hide the race)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
     // (waves of a workgroup share the CU's vector L1, which stores write through and keep coherent,
@@ -3528,11 +3576,11 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
            "  rollout wave: knot loop %.0f, wait A+S %.0f, phase 2 %.0f\n"
            "  cost wave: knot loop + wait A %.0f, selection %.0f, phase 2 + wait V %.0f, phase 3 %.0f\n"
            "  auxiliary wave: knot loop %.0f | fourth wave: speculative backward pass %.0f (only passes of armed iterations)\n"
-           "  take-over: copy + hand-over (wave 0) %.0f, running cost (wave 1) %.0f | E alone, waves 0..3: %.0f %.0f %.0f %.0f\n",
+           "  take-over: copy + hand-over (wave 0) %.0f, running cost (wave 1) %.0f | E alone, waves 0..3: %.0f %.0f %.0f %.0f | E ahead (wave 0) %.0f\n",
            b, loops, spec_iters, c * g_stamp_acc[9], c * g_stamp_acc[10], c * g_stamp_acc[11], c * g_stamp_acc[12], c * g_stamp_acc[14],
            ca * g_stamp_acc[0], ca * g_stamp_acc[1], ca * g_stamp_acc[2], ca * g_stamp_acc[3], ca * g_stamp_acc[4], ca * g_stamp_acc[5],
            ca * g_stamp_acc[6], ca * g_stamp_acc[7], c * g_stamp_acc[8], c * g_stamp_acc[16], c * g_stamp_acc[15],
-           c * g_stamp_acc[17], c * g_stamp_acc[18], c * g_stamp_acc[19], c * g_stamp_acc[20]);
+           c * g_stamp_acc[17], c * g_stamp_acc[18], c * g_stamp_acc[19], c * g_stamp_acc[20], c * g_stamp_acc[21]);
   }
 #endif
   // the gains for the getters (nothing inside the sweep reads them from global memory)

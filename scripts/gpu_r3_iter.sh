@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_fused_gpu.py -q -m gpu -x 2>&1 | grep -v "^E  " | tail -8 | tee gpurun_out/pytest_fused.log
+timeout 900 python -m pytest tests/test_fused_gpu.py -q -m gpu 2>&1 | grep -v "^E  " | tail -8 | tee gpurun_out/pytest_fused.log
 for c in 2 3; do
   for mode in wave free; do
     ALTRO_HIP_SPECULATION=$mode timeout 300 python bench.py --config $c --no-cpu-baseline --no-other-configs --no-latency 2>&1 | python -c "
@@ -14,4 +14,4 @@ for line in sys.stdin:
 " | tee -a gpurun_out/iter_ab.log
   done
 done
-bash scripts/gpu_stamps.sh wave free 2>&1 | grep -A6 "turn90\|^==" | grep -v "^--$" | head -40 | tee gpurun_out/stamps.log
+bash scripts/gpu_stamps.sh wave free 2>&1 | grep -A7 "turn90\|^==" | grep -v "^--$" | head -40 | tee gpurun_out/stamps.log
