@@ -1422,7 +1422,9 @@ class Engine final : public EngineBase {
       A.next_list = d_list_[(i + 1) % 2] + ch.lo;
       A.next_count = ch.d_cnt + i;
       const int ninst = std::max(1, ch.known);
-      if (fused_ok && i > 0 && (tail_mode || total_known() <= persist_at_)) {
+      // (a batch that fits the CUs from the start -- the MPC case, one or a few dozen instances -- goes to the persistent
+      //  kernel at once: its first sweep as three launches and a host round trip would only add latency)
+      if (fused_ok && (i > 0 || (C == 1 && !no_fused_first_)) && (tail_mode || total_known() <= persist_at_)) {
         // the tail: every instance left gets a workgroup that runs whole iterations (k_sweep_fused, launched below
         // for all chains together); this chain's list is the one sweep i would have worked on
         tail_mode = true;
@@ -1457,7 +1459,7 @@ class Engine final : public EngineBase {
     for (int c = 0; c < C; ++c) {
       altro_status st = enqueue_sweep(chain[c], 0);
       if (st != ALTRO_OK) return st;
-      chain[c].sweeps = 1;
+      if (!chain[c].tail) chain[c].sweeps = 1;  // (tail already: the persistent kernel takes the batch from its first sweep)
     }
     // Every chain: enqueue sweep s, then wait for the count sweep s-1 left (published by sweep s, which is already
     // enqueued), then enqueue sweep s+1 ... -- the chains polled in turn, none of them ever blocking the others.
@@ -1516,11 +1518,17 @@ class Engine final : public EngineBase {
         DevArrays<T> A = A_;
         ChainLists lists{};
         long long ninst_l = 0;
+        bool whole_batch = false;
         A.chain_size = C > 1 ? chain_size_ : 0;
         for (int c = 0; c < C; ++c) {
           Chain& ch = chain[c];
           A.chain_base[c] = ch.sweeps;  // batched sweeps this chain ran (0 .. sweeps-1)
           if (!ch.tail) continue;
+          if (ch.sweeps == 0) {  // (single chain, no batched sweep ran: every instance, in order)
+            whole_batch = true;
+            ninst_l += B_;
+            continue;
+          }
           lists.list[lists.n] = d_list_[ch.sweeps % 2] + ch.lo;
           lists.count[lists.n] = ch.d_cnt + (ch.sweeps - 1);
           lists.n++;
@@ -1531,7 +1539,11 @@ class Engine final : public EngineBase {
           }
         }
         const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), B_);
-        if (lists.n == 1) {
+        if (whole_batch) {
+          A.act_list = nullptr;
+          A.act_count = nullptr;
+          A.act_count_const = B_;
+        } else if (lists.n == 1) {
           A.act_list = lists.list[0];
           A.act_count = lists.count[0];
         } else {
@@ -1703,6 +1715,7 @@ class Engine final : public EngineBase {
   int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;
+  bool no_fused_first_ = std::getenv("ALTRO_HIP_NO_FUSED_FIRST") != nullptr;  // (A/B: first sweep as three launches)
   T *X_init_ = nullptr, *U_init_ = nullptr;
   double* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;
