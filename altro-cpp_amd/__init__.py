@@ -216,12 +216,12 @@ class BatchSolver:
         self._call("set_lqr_cost", C.c_int(k_begin), C.c_int(k_end), _dp(Qc), _dp(Rc), _dp(xref),
                    _dp(uref), C.c_int(per))
 
-    def set_user_cost(self, k_begin, k_end, params):
-        """The UserCost of the handle's user model (register_model_source) on knots [k_begin, k_end);
-        params: [UserCost::nparams] or [B][nparams]."""
+    def set_user_cost(self, k_begin, k_end, params, type=0):
+        """A user cost of the handle's user model (register_model_source) on knots [k_begin, k_end);
+        params: [nparams] or [B][nparams]; ``type``: index of the cost class in the source's ALTRO_USER_COSTS list."""
         p = _f64(params)
         per = 1 if p.ndim == 2 else 0
-        self._call("set_user_cost", C.c_int(k_begin), C.c_int(k_end), _dp(p), C.c_int(p.shape[-1]), C.c_int(per))
+        self._call("set_user_cost_type", C.c_int(type), C.c_int(k_begin), C.c_int(k_end), _dp(p), C.c_int(p.shape[-1]), C.c_int(per))
 
     def add_constraint(self, kind, k_begin, k_end, params):
         p = _f64(params)
@@ -229,9 +229,13 @@ class BatchSolver:
         self._call("add_constraint", C.c_int(kind), C.c_int(k_begin), C.c_int(k_end), _dp(p),
                    C.c_int(p.shape[-1]), C.c_int(per))
 
-    def add_user_constraint(self, k_begin, k_end, params):
-        """The UserConstraint of the handle's user model on knots [k_begin, k_end); params: [nparams] or [B][nparams]."""
-        self.add_constraint(CON_USER, k_begin, k_end, params)
+    def add_user_constraint(self, k_begin, k_end, params, type=0):
+        """A user constraint of the handle's user model on knots [k_begin, k_end); params: [nparams] or [B][nparams];
+        ``type``: index of the constraint class in the source's ALTRO_USER_CONSTRAINTS list."""
+        p = _f64(params)
+        per = 1 if p.ndim == 2 else 0
+        self._call("add_user_constraint_type", C.c_int(type), C.c_int(k_begin), C.c_int(k_end), _dp(p),
+                   C.c_int(p.shape[-1]), C.c_int(per))
 
     def add_goal_constraint(self, k, xf):
         self.add_constraint(CON_GOAL, k, k + 1, xf)

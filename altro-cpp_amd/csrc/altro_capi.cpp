@@ -35,7 +35,7 @@ using namespace altro_hip;
 
 extern "C" int altro_chain_claim(int device, int delta);
 
-#define ALTRO_USER_PLUGIN_ABI_HOST 4  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
+#define ALTRO_USER_PLUGIN_ABI_HOST 5  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -78,9 +78,9 @@ struct UserModelEntry {
   int n = 0, m = 0;
   EngineBase* (*make)(const altro_desc*, std::string*) = nullptr;
   int (*check)(int, const double*, int, double, double*) = nullptr;
-  int (*check_functors)(int, const double*, int, double, double*) = nullptr;
-  int functors = 0;  // bit 0: the source defines a UserCost, bit 1: a UserConstraint
-  int cost_nparams = 0, con_p = 0, con_nparams = 0, con_equality = 0;
+  int (*check_functors)(int, const double*, int, double, double*, int*) = nullptr;
+  int functors = 0;  // bit 0: the source defines cost types, bit 1: constraint types
+  int cost_types = 0, con_types = 0;
   bool checked = false;
   uint64_t hash = 0;
 };
@@ -163,7 +163,8 @@ altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) 
     // ScalarFunction::CheckGradient, FunctionBase::CheckHessian / CheckJacobian (functionbase.cpp:42-125) for the
     // user's cost and constraint, at the same points
     double errs[3] = {0, 0, 0};
-    const int rc2 = e.check_functors(device, z.data(), samples, 1e-6, errs);
+    int worst[3] = {0, 0, 0};
+    const int rc2 = e.check_functors(device, z.data(), samples, 1e-6, errs, worst);
     if (rc2 != 0) {
       *err = "user model '" + e.name + "': the cost / constraint derivative check could not run on the device (code " +
              std::to_string(rc2) + ")";
@@ -174,9 +175,9 @@ altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) 
                            "UserConstraint::jacobian() does not match finite differences of eval()"};
     for (int q = 0; q < 3; ++q)
       if (!(errs[q] < 1e-4)) {
-        char buf[320];
-        snprintf(buf, sizeof(buf), "user model '%s': %s: error %.3g >= 1e-4 (FunctionBase::Check%s)", e.name.c_str(), what[q],
-                 errs[q], q == 0 ? "Gradient" : q == 1 ? "Hessian" : "Jacobian");
+        char buf[360];
+        snprintf(buf, sizeof(buf), "user model '%s': %s (%s type %d): error %.3g >= 1e-4 (FunctionBase::Check%s)", e.name.c_str(),
+                 what[q], q < 2 ? "cost" : "constraint", worst[q], errs[q], q == 0 ? "Gradient" : q == 1 ? "Hessian" : "Jacobian");
         *err = buf;
         return ALTRO_INVALID_ARG;
       }
@@ -439,8 +440,9 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   auto dims = reinterpret_cast<void (*)(int*, int*)>(dlsym(e.dl, "altro_user_dims"));
   e.make = reinterpret_cast<EngineBase* (*)(const altro_desc*, std::string*)>(dlsym(e.dl, "altro_user_make_engine"));
   e.check = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_jacobian"));
-  auto finfo = reinterpret_cast<int (*)(int*, int*, int*, int*)>(dlsym(e.dl, "altro_user_functor_info"));
-  e.check_functors = reinterpret_cast<int (*)(int, const double*, int, double, double*)>(dlsym(e.dl, "altro_user_check_functors"));
+  auto finfo = reinterpret_cast<int (*)(int*, int*)>(dlsym(e.dl, "altro_user_functor_info"));
+  e.check_functors =
+      reinterpret_cast<int (*)(int, const double*, int, double, double*, int*)>(dlsym(e.dl, "altro_user_check_functors"));
   if (!abi || !dims || !e.make || !e.check || !finfo || !e.check_functors || abi() != ALTRO_USER_PLUGIN_ABI_HOST ||
       !embedded_hash_ok(e.dl)) {
     err = "the cached user-model plugin " + so + " does not match this library; delete it";
@@ -450,7 +452,7 @@ altro_status altro_register_model_source(const char* name, const char* source, i
   // one book of chained engines for built-in and plugin engines (altro_engine.hpp: ChainClaim)
   if (auto hook = reinterpret_cast<void (*)(int (*)(int, int))>(dlsym(e.dl, "altro_user_set_chain_hook"))) hook(&altro_chain_claim);
   dims(&e.n, &e.m);
-  e.functors = finfo(&e.cost_nparams, &e.con_p, &e.con_nparams, &e.con_equality);
+  e.functors = finfo(&e.cost_types, &e.con_types);
   if (check_jacobian) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {  // without a device the check runs at first use
@@ -570,7 +572,11 @@ altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const do
 }
 altro_status altro_set_user_cost(altro_handle h, int k_begin, int k_end, const double* params, int nparams,
                                  int per_instance) {
-  if (!h || nparams < 0 || (nparams > 0 && !params)) return ALTRO_INVALID_ARG;
+  return altro_set_user_cost_type(h, 0, k_begin, k_end, params, nparams, per_instance);
+}
+altro_status altro_set_user_cost_type(altro_handle h, int type, int k_begin, int k_end, const double* params, int nparams,
+                                      int per_instance) {
+  if (!h || type < 0 || nparams < 0 || (nparams > 0 && !params)) return ALTRO_INVALID_ARG;
   if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
   const altro_desc& d = h->spec.desc;
   if (k_begin < 0 || k_end > d.N + 1 || k_begin >= k_end) {
@@ -581,10 +587,17 @@ altro_status altro_set_user_cost(altro_handle h, int k_begin, int k_end, const d
   c.k_begin = k_begin;
   c.k_end = k_end;
   c.per_instance = per_instance ? 1 : 0;
-  c.user = 1;
+  c.user = 1 + type;
   if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? d.batch : 1));
-  h->spec.costs.push_back(std::move(c));  // UserCost::nparams is checked when the engine of the model exists
+  h->spec.costs.push_back(std::move(c));  // the type's nparams is checked when the engine of the model exists
   return ALTRO_OK;
+}
+altro_status altro_add_user_constraint_type(altro_handle h, int type, int k_begin, int k_end, const double* params, int nparams,
+                                            int per_instance) {
+  if (!h || type < 0) return ALTRO_INVALID_ARG;
+  const altro_status st = altro_add_constraint(h, ALTRO_CON_USER, k_begin, k_end, params, nparams, per_instance);
+  if (st == ALTRO_OK) h->spec.cons.back().user_type = type;
+  return st;
 }
 altro_status altro_add_constraint(altro_handle h, int kind, int k_begin, int k_end, const double* params,
                                   int nparams, int per_instance) {

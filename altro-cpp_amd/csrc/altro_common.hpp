@@ -25,12 +25,13 @@ struct CostSpec {
   int k_begin, k_end;
   std::vector<double> Q, R, xref, uref;
   int per_instance;  // bit0 xref, bit1 uref (user cost: params are per instance)
-  int user = 0;      // the user model's UserCost instead of an LQR cost
+  int user = 0;      // 0: LQR cost; 1 + t: the t-th user cost type of the model's source (ALTRO_USER_COSTS) instead
   std::vector<double> params;  // user cost: [nparams] or [B][nparams]
 };
 struct ConSpec {
   int kind, k_begin, k_end, nparams, per_instance;
   std::vector<double> params;
+  int user_type = 0;  // ALTRO_CON_USER: index of the constraint type in the model's source (ALTRO_USER_CONSTRAINTS)
 };
 struct ProblemSpec {
   altro_desc desc{};
@@ -62,7 +63,7 @@ struct ConDesc {
   int per_instance;  // params in the per-instance pool ([slot][Bp]) instead of the shared pool
   int param_off;     // first slot / element of this constraint's parameters
   int row_off;       // row offset inside the knot
-  unsigned lo_mask;  // CONTROL_BOUND: controls with a finite lower bound (basic_constraints.hpp:138-145)
+  unsigned lo_mask;  // CONTROL_BOUND: controls with a finite lower bound (basic_constraints.hpp:138-145); USER: index of the type
   unsigned hi_mask;  // CONTROL_BOUND: controls with a finite upper bound
 };
 struct KnotClass {
@@ -77,7 +78,7 @@ struct CostGroupDesc {
   int q_off, r_off, c_off;   // pool element (shared) or slot (per instance)
   int q_pi, r_pi, c_pi;      // per-instance flags
   int q_diag, r_diag;        // Q / R are diagonal (every off-diagonal entry is exactly zero)
-  int user, u_off, u_pi;     // user cost (altro_set_user_cost): parameters at u_off (pool element / first slot)
+  int user, u_off, u_pi;     // user cost (altro_set_user_cost): 1 + index of its type; parameters at u_off (pool element / first slot)
 };
 // A run of consecutive knot points [k_begin, k_end) with the same class: rows of knot k start at
 // rowbase + (k - k_begin) * nrows(cls).  Lets the serial kernels keep the class in scalar registers.

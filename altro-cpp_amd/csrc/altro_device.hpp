@@ -20,39 +20,80 @@ namespace altro_hip {
 
 // -------------------------------------------------------------------------------------------------
 // User-defined cost / constraint functors.  Only a user-model plugin (the translation
-// unit altro_register_model_source generates) defines ALTRO_USER_COST / ALTRO_USER_CONSTRAINT -- its source is
-// included BEFORE this header, in namespace altro_user.  Everywhere else the stand-ins below keep the call sites
-// well-formed and `if constexpr (kHasUser...)` removes them: the built-in engines compile exactly as without them.
+// unit altro_register_model_source generates) defines them -- its source is included BEFORE this header, in namespace
+// altro_user -- and announces them with
+//     #define ALTRO_USER_COSTS        CostA, CostB, ...      (or ALTRO_USER_COST X for a single one)
+//     #define ALTRO_USER_CONSTRAINTS  ConA, ConB, ...        (or ALTRO_USER_CONSTRAINT X)
+// Every knot of the reference's Problem may carry any CostFunction / Constraint subclass (problem.hpp:113-202); here a
+// cost group / constraint descriptor carries the INDEX of its type in the list, and the device code dispatches on it
+// (UserDispatch: an if-chain over the list, each arm instantiated for its own nparams / p).  Everywhere else the lists
+// are empty and `if constexpr (kHasUser...)` removes every trace: the built-in engines compile exactly as without them.
 // -------------------------------------------------------------------------------------------------
-#ifdef ALTRO_USER_COST
-using UserCostF = altro_user::ALTRO_USER_COST;
-constexpr bool kHasUserCost = true;
-#else
-struct UserCostF {
-  static constexpr int nparams = 0;
-  template <class T>
-  ALTRO_DEV static T eval(const T*, const T*, const T*) { return T(0); }
-  template <class T>
-  ALTRO_DEV static void gradient(const T*, const T*, const T*, T*, T*) {}
-  template <class T>
-  ALTRO_DEV static void hessian(const T*, const T*, const T*, T*, T*, T*) {}
+template <class... Fs>
+struct UserTypeList {
+  static constexpr int size = (int)sizeof...(Fs);
 };
-constexpr bool kHasUserCost = false;
-#endif
-#ifdef ALTRO_USER_CONSTRAINT
-using UserConF = altro_user::ALTRO_USER_CONSTRAINT;
-constexpr bool kHasUserCon = true;
-#else
-struct UserConF {
-  static constexpr int p = 1, nparams = 0;
-  static constexpr bool equality = false;
-  template <class T>
-  ALTRO_DEV static void eval(const T*, const T*, const T*, T*) {}
-  template <class T>
-  ALTRO_DEV static void jacobian(const T*, const T*, const T*, T*) {}
+template <class F>
+struct UserTag {
+  using type = F;
 };
-constexpr bool kHasUserCon = false;
+template <class L>
+struct UserDispatch;
+template <>
+struct UserDispatch<UserTypeList<>> {
+  template <class Fn>
+  __host__ __device__ __forceinline__ static void call(int, Fn&&) {}
+};
+template <class F0, class... Fs>
+struct UserDispatch<UserTypeList<F0, Fs...>> {
+  // fn(UserTag<F>{}) for the idx-th type of the list (nothing for an index out of range)
+  template <class Fn>
+  __host__ __device__ __forceinline__ static void call(int idx, Fn&& fn) {
+    if (idx == 0) fn(UserTag<F0>{});
+    else UserDispatch<UserTypeList<Fs...>>::call(idx - 1, fn);
+  }
+};
+#if defined(ALTRO_USER_COSTS) || defined(ALTRO_USER_COST) || defined(ALTRO_USER_CONSTRAINTS) || defined(ALTRO_USER_CONSTRAINT)
+namespace user_lists_ {
+using namespace ::altro_user;  // (the names in the macros are the user's)
+#if defined(ALTRO_USER_COSTS)
+using Costs = UserTypeList<ALTRO_USER_COSTS>;
+#elif defined(ALTRO_USER_COST)
+using Costs = UserTypeList<ALTRO_USER_COST>;
+#else
+using Costs = UserTypeList<>;
 #endif
+#if defined(ALTRO_USER_CONSTRAINTS)
+using Cons = UserTypeList<ALTRO_USER_CONSTRAINTS>;
+#elif defined(ALTRO_USER_CONSTRAINT)
+using Cons = UserTypeList<ALTRO_USER_CONSTRAINT>;
+#else
+using Cons = UserTypeList<>;
+#endif
+}  // namespace user_lists_
+using UserCostList = user_lists_::Costs;
+using UserConList = user_lists_::Cons;
+#else
+using UserCostList = UserTypeList<>;
+using UserConList = UserTypeList<>;
+#endif
+constexpr bool kHasUserCost = UserCostList::size > 0;
+constexpr bool kHasUserCon = UserConList::size > 0;
+// what the host needs to know of the idx-th user type (parameter count, rows, cone); -1 for an index out of range
+inline int UserCostParams(int idx) {
+  int np = -1;
+  UserDispatch<UserCostList>::call(idx, [&](auto tag) { np = decltype(tag)::type::nparams; });
+  return np;
+}
+inline void UserConInfo(int idx, int* nparams, int* p, int* equality) {
+  *nparams = *p = *equality = -1;
+  UserDispatch<UserConList>::call(idx, [&](auto tag) {
+    using F = typename decltype(tag)::type;
+    *nparams = F::nparams;
+    *p = F::p;
+    *equality = F::equality ? 1 : 0;
+  });
+}
 
 // -------------------------------------------------------------------------------------------------
 // Device array bundle (passed to kernels by value)
@@ -795,10 +836,15 @@ ALTRO_DEV void load_user_params(const Ctx& C, int per_instance, int off, T* par)
 // CostFunction::Evaluate of the user's cost (costfunction.hpp:52-58)
 template <class T, class Ctx>
 ALTRO_DEV T user_cost_eval(const Ctx& C, const CostGroupDesc& g, const T* x, const T* u) {
-  constexpr int NP = UserCostF::nparams;
-  T par[NP > 0 ? NP : 1];
-  load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
-  return UserCostF::eval(x, u, par);
+  T J = T(0);
+  UserDispatch<UserCostList>::call(g.user - 1, [&](auto tag) {  // (g.user = 1 + index of the type)
+    using F = typename decltype(tag)::type;
+    constexpr int NP = F::nparams;
+    T par[NP > 0 ? NP : 1];
+    load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
+    J = F::eval(x, u, par);
+  });
+  return J;
 }
 
 template <class T, int n, int m, class Ctx>
@@ -839,21 +885,24 @@ ALTRO_DEV T quad_cost(const Ctx& C, const CostGroupDesc& g, const T* x, const T*
 template <class T, bool STORE, class Ctx>
 ALTRO_DEV void user_con_auglag(const Ctx& C, const ConDesc& cd, int r0, T rho, const T* x, const T* u, T& a, T& bsum,
                                T& vmax) {
-  constexpr int P = UserConF::p, NP = UserConF::nparams;
-  T par[NP > 0 ? NP : 1], c[P];
-  load_user_params<T, NP>(C, cd.per_instance, cd.param_off, par);
-  UserConF::eval(x, u, par, c);
+  UserDispatch<UserConList>::call((int)cd.lo_mask, [&](auto tag) {  // (lo_mask of a USER constraint: index of its type)
+    using F = typename decltype(tag)::type;
+    constexpr int P = F::p, NP = F::nparams;
+    T par[NP > 0 ? NP : 1], c[P];
+    load_user_params<T, NP>(C, cd.per_instance, cd.param_off, par);
+    F::eval(x, u, par, c);
 #pragma unroll
-  for (int i = 0; i < P; ++i) {
-    T lam = C.lam(r0 + i);
-    T lp = dual_proj(cd.type, lam - rho * c[i]);
-    a += lp * lp;
-    bsum += lam * lam;
-    if (STORE) {
-      C.store_c(r0 + i, c[i]);
-      vmax = max_(vmax, violation(cd.type, c[i]));
+    for (int i = 0; i < P; ++i) {
+      T lam = C.lam(r0 + i);
+      T lp = dual_proj(cd.type, lam - rho * c[i]);
+      a += lp * lp;
+      bsum += lam * lam;
+      if (STORE) {
+        C.store_c(r0 + i, c[i]);
+        vmax = max_(vmax, violation(cd.type, c[i]));
+      }
     }
-  }
+  });
 }
 
 // ALCost::Evaluate (al_cost.hpp:264-274) = quadratic cost + sum of ConstraintValues::AugLag
@@ -1079,12 +1128,16 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
   if constexpr (kHasUserCost) user_cost = g.user != 0;
   if (user_cost) {
     // CostFunction::Evaluate / Gradient / Hessian of the user's cost (costfunction.hpp:52-73)
-    constexpr int NP = UserCostF::nparams;
-    T par[NP > 0 ? NP : 1];
-    load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
-    J = UserCostF::eval(x, u, par);
-    UserCostF::gradient(x, u, par, gx, gu);
-    UserCostF::hessian(x, u, par, hxx, hxu, huu);
+    J = T(0);
+    UserDispatch<UserCostList>::call(g.user - 1, [&](auto tag) {
+      using F = typename decltype(tag)::type;
+      constexpr int NP = F::nparams;
+      T par[NP > 0 ? NP : 1];
+      load_user_params<T, NP>(C, g.u_pi, g.u_off, par);
+      J = F::eval(x, u, par);
+      F::gradient(x, u, par, gx, gu);
+      F::hessian(x, u, par, hxx, hxu, huu);
+    });
   } else {
     T xQx = T(0), uRu = T(0), qx = T(0), ru = T(0);
 #pragma unroll
@@ -1186,11 +1239,13 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
     } else if (kHasUserCon && cd.kind == ALTRO_CON_USER) {
       // the user's constraint: con_->Evaluate / Jacobian, then ConstraintValues::AugLagGradient / AugLagHessian
       // (constraint_values.hpp:131-177) with the full p x (n+m) Jacobian
-      constexpr int P = UserConF::p, NP = UserConF::nparams, nm = n + m;
+      UserDispatch<UserConList>::call((int)cd.lo_mask, [&](auto tag) {
+      using F = typename decltype(tag)::type;
+      constexpr int P = F::p, NP = F::nparams, nm = n + m;
       T par[NP > 0 ? NP : 1], c[P], jac[P * nm], lp[P];
       load_user_params<T, NP>(C, cd.per_instance, cd.param_off, par);
-      UserConF::eval(x, u, par, c);
-      UserConF::jacobian(x, u, par, jac);
+      F::eval(x, u, par, c);
+      F::jacobian(x, u, par, jac);
 #pragma unroll
       for (int r = 0; r < P; ++r) {
         T lam = C.lam(r0 + r);
@@ -1244,6 +1299,7 @@ ALTRO_DEV T knot_cost_expansion(const Ctx& C, const ProblemDesc* pd, const KnotC
           for (int r = 0; r < P; ++r) sh += (rho * jac[r + (n + i) * P]) * jac[r + (n + j) * P];
           huu[i + j * m] += sh;
         }
+      });
     } else {  // CIRCLE: dc_i/d(px,py) = (2(cx-px), 2(cy-py)) (obstacle_constraints.hpp:109-121)
       T g0 = T(0), g1 = T(0), h00 = T(0), h10 = T(0), h01 = T(0), h11 = T(0);
       for (int i = 0; i < cd.p; ++i) {

@@ -752,12 +752,18 @@ class Engine final : public EngineBase {
           err_ = "this model defines no UserCost (altro_set_user_cost needs a user model whose source defines ALTRO_USER_COST)";
           return ALTRO_INVALID_ARG;
         } else {
-          constexpr int NP = UserCostF::nparams;
-          if ((int)c.params.size() != NP * (c.per_instance ? B_ : 1)) {
-            err_ = "user cost: expected " + std::to_string(NP) + " parameters" + (c.per_instance ? " per instance" : "");
+          const int NP = UserCostParams(c.user - 1);  // (-1: no such type in the source)
+          if (NP < 0) {
+            err_ = "user cost type " + std::to_string(c.user - 1) + ": the model's source defines " +
+                   std::to_string(UserCostList::size) + " cost type(s) (ALTRO_USER_COSTS)";
             return ALTRO_INVALID_ARG;
           }
-          g.user = 1;
+          if ((int)c.params.size() != NP * (c.per_instance ? B_ : 1)) {
+            err_ = "user cost type " + std::to_string(c.user - 1) + ": expected " + std::to_string(NP) + " parameters" +
+                   (c.per_instance ? " per instance" : "");
+            return ALTRO_INVALID_ARG;
+          }
+          g.user = c.user;
           g.u_pi = c.per_instance ? 1 : 0;
           // (the quadratic fields stay valid, all-zero pool entries: every generic read is in bounds)
           g.Q_off = g.R_off = g.q_off = g.r_off = g.c_off = (int)pool.size();
@@ -887,12 +893,20 @@ class Engine final : public EngineBase {
           err_ = "this model defines no UserConstraint (ALTRO_CON_USER needs a user model whose source defines ALTRO_USER_CONSTRAINT)";
           return ALTRO_INVALID_ARG;
         } else {
-          if (c.nparams != UserConF::nparams) {
-            err_ = "user constraint: expected " + std::to_string(UserConF::nparams) + " parameters";
+          int unp = -1, up = -1, ueq = -1;
+          UserConInfo(c.user_type, &unp, &up, &ueq);
+          if (unp < 0) {
+            err_ = "user constraint type " + std::to_string(c.user_type) + ": the model's source defines " +
+                   std::to_string(UserConList::size) + " constraint type(s) (ALTRO_USER_CONSTRAINTS)";
             return ALTRO_INVALID_ARG;
           }
-          d.type = UserConF::equality ? 0 : 1;
-          d.p = UserConF::p;
+          if (c.nparams != unp) {
+            err_ = "user constraint type " + std::to_string(c.user_type) + ": expected " + std::to_string(unp) + " parameters";
+            return ALTRO_INVALID_ARG;
+          }
+          d.type = ueq ? 0 : 1;
+          d.p = up;
+          d.lo_mask = (unsigned)c.user_type;  // (the device dispatches on it: user_con_auglag)
         }
       } else {
         err_ = "unknown constraint kind";

@@ -22,15 +22,18 @@
 // The same source may define the reference's other two plug-in classes (include/altro_hip.h): a cost function
 // (problem::CostFunction, costfunction.hpp:52-73 -> struct UserCost, #define ALTRO_USER_COST UserCost) and a
 // constraint (constraints::Constraint<ConType>, constraint.hpp:173-202 -> struct UserConstraint,
-// #define ALTRO_USER_CONSTRAINT UserConstraint).  altro_device.hpp picks them up (UserCostF / UserConF); their
-// derivatives are checked on the device like the model's (k_check_functors below).
+// #define ALTRO_USER_CONSTRAINT UserConstraint) -- or SEVERAL types of each, as a reference problem may hold any
+// mix of CostFunction / Constraint subclasses (problem.hpp:66-133): #define ALTRO_USER_COSTS TypeA, TypeB and
+// #define ALTRO_USER_CONSTRAINTS TypeC, TypeD; the index in the list is the `type` of altro_set_user_cost_type /
+// altro_add_user_constraint_type.  altro_device.hpp picks them up (UserCostList / UserConList); the derivatives of
+// every type are checked on the device like the model's (k_check_functors below).
 #pragma once
 
 #include "altro_engine.hpp"
 
 namespace altro_hip {
 
-#define ALTRO_USER_PLUGIN_ABI 4  // bump when EngineBase or the entry points below change
+#define ALTRO_USER_PLUGIN_ABI 5  // bump when EngineBase or the entry points below change
 
 struct UserM : altro_user::UserModel {
   static constexpr bool kHasFusedRk4 = false;
@@ -74,13 +77,15 @@ __global__ void k_check_jacobian(const double* __restrict__ z, double* __restric
   err[s] = sqrt(e2) / fmax(1.0, sqrt(j2));
 }
 
-// ScalarFunction::CheckGradient, FunctionBase::CheckHessian (functionbase.cpp:75-125) for the user's cost and
-// FunctionBase::CheckJacobian for the user's constraint, one sample (x, u, parameters) per thread, forward
-// differences: err[3 s + 0] = ||fd(eval) - gradient||, [3 s + 1] = ||fd(gradient) - hessian||_F,
+// ScalarFunction::CheckGradient, FunctionBase::CheckHessian (functionbase.cpp:75-125) for one of the user's cost types
+// and FunctionBase::CheckJacobian for one of the user's constraint types (indices into ALTRO_USER_COSTS /
+// ALTRO_USER_CONSTRAINTS, -1: none), one sample (x, u, parameters) per thread, central differences:
+// err[3 s + 0] = ||fd(eval) - gradient||, [3 s + 1] = ||fd(gradient) - hessian||_F,
 // [3 s + 2] = ||fd(eval) - jacobian||_F, each relative to max(1, norm of the user's derivative).
 template <int n, int m>
 __global__ void k_check_functors(const double* __restrict__ z, const double* __restrict__ par_cost,
-                                 const double* __restrict__ par_con, double* __restrict__ err, int samples, double eps) {
+                                 const double* __restrict__ par_con, double* __restrict__ err, int samples, double eps,
+                                 int cost_type, int con_type) {
   constexpr int nm = n + m;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= samples) return;
@@ -88,13 +93,14 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
 #pragma unroll
   for (int i = 0; i < nm; ++i) x[i] = z[(size_t)s * nm + i];
   double eg = 0.0, eh = 0.0, ej = 0.0;
-  if constexpr (kHasUserCost) {
-    constexpr int NP = UserCostF::nparams;
+  UserDispatch<UserCostList>::call(cost_type, [&](auto tag) {
+    using F = typename decltype(tag)::type;
+    constexpr int NP = F::nparams;
     double par[NP > 0 ? NP : 1];
     for (int i = 0; i < NP; ++i) par[i] = par_cost[(size_t)s * NP + i];
     double g0[nm], g1[nm], H[nm * nm], hxx[n * n], hxu[n * m], huu[m * m];
-    UserCostF::gradient(x, x + n, par, g0, g0 + n);
-    UserCostF::hessian(x, x + n, par, hxx, hxu, huu);
+    F::gradient(x, x + n, par, g0, g0 + n);
+    F::hessian(x, x + n, par, hxx, hxu, huu);
     for (int j = 0; j < nm; ++j)
       for (int i = 0; i < nm; ++i)
         H[i + j * nm] = (i < n && j < n) ? hxx[i + j * n] : (i < n) ? hxu[i + (j - n) * n] : (j < n) ? hxu[j + (i - n) * n]
@@ -103,12 +109,12 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
     for (int j = 0; j < nm; ++j) {  // central differences, see k_check_jacobian
       const double keep = x[j];
       x[j] = keep + eps;
-      const double Jp = UserCostF::eval(x, x + n, par);
-      UserCostF::gradient(x, x + n, par, g1, g1 + n);
+      const double Jp = F::eval(x, x + n, par);
+      F::gradient(x, x + n, par, g1, g1 + n);
       x[j] = keep - eps;
-      const double Jm = UserCostF::eval(x, x + n, par);
+      const double Jm = F::eval(x, x + n, par);
       double gm[nm];
-      UserCostF::gradient(x, x + n, par, gm, gm + n);
+      F::gradient(x, x + n, par, gm, gm + n);
       x[j] = keep;
       const double dg = (Jp - Jm) / (2.0 * eps) - g0[j];
       eg += dg * dg;
@@ -121,20 +127,21 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
     }
     eg /= fmax(1.0, g2);
     eh /= fmax(1.0, h2);
-  }
-  if constexpr (kHasUserCon) {
-    constexpr int P = UserConF::p, NP = UserConF::nparams;
+  });
+  UserDispatch<UserConList>::call(con_type, [&](auto tag) {
+    using F = typename decltype(tag)::type;
+    constexpr int P = F::p, NP = F::nparams;
     double par[NP > 0 ? NP : 1];
     for (int i = 0; i < NP; ++i) par[i] = par_con[(size_t)s * NP + i];
     double c0[P], c1[P], J[P * nm];
-    UserConF::jacobian(x, x + n, par, J);
+    F::jacobian(x, x + n, par, J);
     double j2 = 0.0;
     for (int j = 0; j < nm; ++j) {
       const double keep = x[j];
       x[j] = keep + eps;
-      UserConF::eval(x, x + n, par, c1);
+      F::eval(x, x + n, par, c1);
       x[j] = keep - eps;
-      UserConF::eval(x, x + n, par, c0);
+      F::eval(x, x + n, par, c0);
       x[j] = keep;
       for (int r = 0; r < P; ++r) {
         const double dj = (c1[r] - c0[r]) / (2.0 * eps) - J[r + j * P];
@@ -143,7 +150,7 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
       }
     }
     ej /= fmax(1.0, j2);
-  }
+  });
   err[3 * s + 0] = sqrt(eg);
   err[3 * s + 1] = sqrt(eh);
   err[3 * s + 2] = sqrt(ej);
@@ -172,28 +179,27 @@ altro_hip::EngineBase* altro_user_make_engine(const altro_desc* d, std::string* 
   return MakeEngineImpl<double, WithRec32<UserM>>(*d, err);
 }
 
-// What the source defines besides the model: bit 0 a UserCost, bit 1 a UserConstraint; their parameter counts,
-// the constraint's OutputDimension and cone.
-int altro_user_functor_info(int* cost_nparams, int* con_p, int* con_nparams, int* con_equality) {
+// What the source defines besides the model: bit 0 cost types, bit 1 constraint types; how many of each
+// (ALTRO_USER_COSTS / ALTRO_USER_CONSTRAINTS lists, or the single ALTRO_USER_COST / ALTRO_USER_CONSTRAINT).
+int altro_user_functor_info(int* n_cost_types, int* n_con_types) {
   using namespace altro_hip;
-  *cost_nparams = kHasUserCost ? UserCostF::nparams : 0;
-  *con_p = kHasUserCon ? UserConF::p : 0;
-  *con_nparams = kHasUserCon ? UserConF::nparams : 0;
-  *con_equality = (kHasUserCon && UserConF::equality) ? 1 : 0;
+  *n_cost_types = UserCostList::size;
+  *n_con_types = UserConList::size;
   return (kHasUserCost ? 1 : 0) | (kHasUserCon ? 2 : 0);
 }
 
-// Device-side CheckGradient / CheckHessian / CheckJacobian of the user's cost and constraint at `samples` points:
-// z = (x, u) from the caller, parameters uniform in [0.5, 1.5] (weights, radii, limits: positive).
-// errs[0..2] = the largest gradient, Hessian and constraint-Jacobian error.  Returns 0 or a HIP error code.
-int altro_user_check_functors(int device, const double* z_host, int samples, double eps, double* errs) {
+// Device-side CheckGradient / CheckHessian / CheckJacobian of EVERY cost and constraint type of the source at
+// `samples` points: z = (x, u) from the caller, parameters uniform in [0.5, 1.5] (weights, radii, limits: positive).
+// errs[0..2] = the largest gradient, Hessian and constraint-Jacobian error over the types, worst[0..2] = the index
+// of the type that has it.  Returns 0 or a HIP error code.
+int altro_user_check_functors(int device, const double* z_host, int samples, double eps, double* errs, int* worst) {
   using namespace altro_hip;
   errs[0] = errs[1] = errs[2] = 0.0;
+  worst[0] = worst[1] = worst[2] = 0;
   if (!kHasUserCost && !kHasUserCon) return 0;
   constexpr int nm = UserM::n + UserM::m;
-  constexpr int NPc = kHasUserCost ? UserCostF::nparams : 0, NPk = kHasUserCon ? UserConF::nparams : 0;
+  constexpr int kCosts = UserCostList::size, kCons = UserConList::size;
   if (hipSetDevice(device) != hipSuccess) return 1;
-  std::vector<double> pc((size_t)samples * (NPc > 0 ? NPc : 1)), pk((size_t)samples * (NPk > 0 ? NPk : 1));
   unsigned long long st = 0x9E3779B97F4A7C15ull;
   auto next = [&]() {  // splitmix64
     unsigned long long v = (st += 0x9E3779B97F4A7C15ull);
@@ -201,35 +207,48 @@ int altro_user_check_functors(int device, const double* z_host, int samples, dou
     v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
     return 0.5 + (double)((v ^ (v >> 31)) >> 11) * 0x1p-53;
   };
-  for (double& v : pc) v = next();
-  for (double& v : pk) v = next();
-  double *dz = nullptr, *dpc = nullptr, *dpk = nullptr, *derr = nullptr;
+  double *dz = nullptr, *derr = nullptr;
   int rc = 0;
   if (hipMalloc((void**)&dz, (size_t)samples * nm * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&dpc, pc.size() * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&dpk, pk.size() * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&derr, (size_t)samples * 3 * sizeof(double)) != hipSuccess)
     rc = 2;
+  if (!rc && hipMemcpy(dz, z_host, (size_t)samples * nm * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 3;
   std::vector<double> herr((size_t)samples * 3, 0.0);
-  if (!rc && (hipMemcpy(dz, z_host, (size_t)samples * nm * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-              hipMemcpy(dpc, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-              hipMemcpy(dpk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
-    rc = 3;
-  if (!rc) {
-    hipLaunchKernelGGL((k_check_functors<UserM::n, UserM::m>), dim3((samples + 63) / 64), dim3(64), 0, nullptr, dz, dpc, dpk,
-                       derr, samples, eps);
-    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = 4;
-  }
-  if (!rc && hipMemcpy(herr.data(), derr, herr.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
-  hipFree(dz);
-  hipFree(dpc);
-  hipFree(dpk);
-  hipFree(derr);
-  for (int s = 0; s < samples; ++s)
-    for (int q = 0; q < 3; ++q) {
-      const double e = herr[(size_t)3 * s + q];
-      if (e > errs[q] || e != e) errs[q] = e;
+  for (int t = 0; !rc && t < (kCosts > kCons ? kCosts : kCons); ++t) {  // pass t: cost type t beside constraint type t
+    const int ct = t < kCosts ? t : -1, kt = t < kCons ? t : -1;
+    int dummy_p = 0, dummy_eq = 0, npk = 0;
+    const int npc = ct >= 0 ? UserCostParams(ct) : 0;
+    if (kt >= 0) UserConInfo(kt, &npk, &dummy_p, &dummy_eq);
+    std::vector<double> pc((size_t)samples * (npc > 0 ? npc : 1)), pk((size_t)samples * (npk > 0 ? npk : 1));
+    for (double& v : pc) v = next();
+    for (double& v : pk) v = next();
+    double *dpc = nullptr, *dpk = nullptr;
+    if (hipMalloc((void**)&dpc, pc.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&dpk, pk.size() * sizeof(double)) != hipSuccess)
+      rc = 2;
+    if (!rc && (hipMemcpy(dpc, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dpk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+      rc = 3;
+    if (!rc) {
+      hipLaunchKernelGGL((k_check_functors<UserM::n, UserM::m>), dim3((samples + 63) / 64), dim3(64), 0, nullptr, dz, dpc, dpk,
+                         derr, samples, eps, ct, kt);
+      if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = 4;
     }
+    if (!rc && hipMemcpy(herr.data(), derr, herr.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
+    hipFree(dpc);
+    hipFree(dpk);
+    if (rc) break;
+    for (int s = 0; s < samples; ++s)
+      for (int q = 0; q < 3; ++q) {
+        const double e = herr[(size_t)3 * s + q];
+        if (e > errs[q] || e != e) {
+          errs[q] = e;
+          worst[q] = t;
+        }
+      }
+  }
+  hipFree(dz);
+  hipFree(derr);
   return rc;
 }
 

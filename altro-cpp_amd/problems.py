@@ -203,6 +203,32 @@ def cartpole_track(make, model_kind, batch=1, N=60, dtype=F64, goal=None, sway=0
     return s
 
 
+def cartpole_multi(make, model_kind, batch=1, N=60, dtype=F64, goal=None, sway=0.05, vmax=0.6, **kw):
+    """The cart-pole move with SEVERAL user cost / constraint classes in one problem (tests/models/cartpole_multi.hpp):
+    stage cost = SwingCost (cost type 0), terminal cost = TipCost (type 1, another parameter count); on the knots after
+    the first the sway limit (constraint type 0, 2 inequality rows) AND the cart speed limit (type 2, 1 inequality row)
+    share each knot with the built-in force bound; at the last knot the tip-over-goal equality (type 1)."""
+    n, m = 4, 1
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.05)
+    hd = float(h)
+    goal = np.full(batch, 1.0) if goal is None else np.broadcast_to(np.asarray(goal, dtype=np.float64), (batch,))
+    stage = np.stack([goal, np.full(batch, 1e-1 * hd), np.full(batch, 2.0 * hd), np.full(batch, 1e-1 * hd),
+                      np.full(batch, 1e-1 * hd), np.full(batch, 1e-2 * hd)], axis=1)
+    term = np.stack([goal, np.full(batch, 100.0), np.full(batch, 100.0)], axis=1)
+    s.set_model(model_kind)
+    s.set_uniform_step(h)
+    s.set_user_cost(0, N, stage, type=0)
+    s.set_user_cost(N, N + 1, term, type=1)
+    s.add_control_bound(0, N, [-3.0], [3.0])
+    s.add_user_constraint(1, N, np.stack([np.full(batch, -sway), np.full(batch, sway)], axis=1), type=0)
+    s.add_user_constraint(1, N, np.array([vmax]), type=2)
+    s.add_user_constraint(N, N + 1, goal[:, None].copy(), type=1)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
 # ---------------------------------------------------------------------------------------------------
 # Seeded synthetic batches (SURVEY.md section 8(d)); instance 0 = the exact reference problem.
 # The generator is std::mt19937_64 (the C++ facade, include/altro/problems.hpp, draws the same numbers from

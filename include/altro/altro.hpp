@@ -244,7 +244,8 @@ struct Quadrotor12 {  // build-defined model of BASELINE config 5
 // (altro/problem/dynamics.hpp:59-95), problem::CostFunction (costfunction.hpp:52-73) and
 // constraints::Constraint<ConType> (constraint.hpp:173-202); a kernel cannot call host virtual functions, so here
 // the three travel as SOURCE (include/altro_hip.h, altro_register_model_source): `struct UserModel { n, m, f, jac }`
-// and, optionally, `struct UserCost` / `struct UserConstraint` announced by ALTRO_USER_COST / ALTRO_USER_CONSTRAINT.
+// and, optionally, `struct UserCost` / `struct UserConstraint` announced by ALTRO_USER_COST / ALTRO_USER_CONSTRAINT --
+// or several classes of each, listed by ALTRO_USER_COSTS / ALTRO_USER_CONSTRAINTS and picked by their index (`type`).
 // The constructor compiles (or loads from the on-disk cache) the plugin and runs the device-side
 // CheckJacobian / CheckGradient / CheckHessian; errors (compiler output included) are thrown.
 struct UserModel {
@@ -273,6 +274,7 @@ struct QuadraticCost {
   bool user = false;
   std::vector<double> user_params;
   int user_nparams = 0;
+  int user_type = 0;  // index of the class in the source's ALTRO_USER_COSTS list
   static QuadraticCost LQRCost(const std::vector<double>& Q, const std::vector<double>& R,
                                const std::vector<double>& xref, const std::vector<double>& uref,
                                bool terminal = false) {
@@ -286,16 +288,18 @@ struct QuadraticCost {
   }
   bool operator==(const QuadraticCost& o) const {
     return Q == o.Q && R == o.R && xref == o.xref && uref == o.uref && terminal == o.terminal && user == o.user &&
-           user_params == o.user_params && user_nparams == o.user_nparams;
+           user_params == o.user_params && user_nparams == o.user_nparams && user_type == o.user_type;
   }
 };
 // problem::CostFunction of the caller (costfunction.hpp:52-73): the `struct UserCost` of the UserModel's source with
-// these parameters (UserCost::nparams doubles, or `batch` such blocks back to back).
+// these parameters (UserCost::nparams doubles, or `batch` such blocks back to back); `type` picks the class when the
+// source lists several (ALTRO_USER_COSTS), as each knot of a reference problem may hold another CostFunction subclass.
 struct UserCost : QuadraticCost {
-  explicit UserCost(const std::vector<double>& params, int nparams = -1) {
+  explicit UserCost(const std::vector<double>& params, int nparams = -1, int type = 0) {
     user = true;
     user_params = params;
     user_nparams = nparams >= 0 ? nparams : static_cast<int>(params.size());
+    user_type = type;
   }
 };
 
@@ -306,7 +310,10 @@ struct ConstraintDesc {
   std::string label;
   int user_p = 0;              // USER: OutputDimension of the source's UserConstraint
   bool user_equality = false;  // USER: its cone (constraints::Equality / NegativeOrthant)
-  bool operator==(const ConstraintDesc& o) const { return kind == o.kind && params == o.params && nparams == o.nparams; }
+  int user_type = 0;           // USER: index of the class in the source's ALTRO_USER_CONSTRAINTS list
+  bool operator==(const ConstraintDesc& o) const {
+    return kind == o.kind && params == o.params && nparams == o.nparams && user_type == o.user_type;
+  }
   bool IsEquality() const { return kind == ALTRO_CON_GOAL || (kind == ALTRO_CON_USER && user_equality); }
   // Constraint<ConType>::GetConstraintType, altro/constraints/constraint.hpp:193-201
   std::string GetConstraintType() const { return IsEquality() ? "Equality Constraint" : "Inequality Constraint"; }
@@ -321,11 +328,13 @@ struct ConstraintDesc {
   }
 };
 // constraints::Constraint<ConType> of the caller (constraint.hpp:173-202): the `struct UserConstraint` of the
-// UserModel's source with these parameters; p = its OutputDimension, equality = its cone.
+// UserModel's source with these parameters; p = its OutputDimension, equality = its cone; `type` picks the class when
+// the source lists several (ALTRO_USER_CONSTRAINTS).
 struct UserConstraint : ConstraintDesc {
   UserConstraint(const std::vector<double>& par, int p, bool equality = false, int npar = -1,
-                 const std::string& name = "User Constraint") {
+                 const std::string& name = "User Constraint", int type = 0) {
     kind = ALTRO_CON_USER;
+    user_type = type;
     params = par;
     nparams = npar >= 0 ? npar : static_cast<int>(par.size());
     user_p = p;
@@ -462,8 +471,8 @@ class Problem {
       while (e <= N_ && costs_[e] == costs_[k]) ++e;
       const auto& c = costs_[k];
       if (c.user) {
-        Check(h, altro_set_user_cost(h, k, e, c.user_params.data(), c.user_nparams,
-                                     (int)c.user_params.size() > c.user_nparams ? 1 : 0), "altro_set_user_cost");
+        Check(h, altro_set_user_cost_type(h, c.user_type, k, e, c.user_params.data(), c.user_nparams,
+                                          (int)c.user_params.size() > c.user_nparams ? 1 : 0), "altro_set_user_cost_type");
       } else {
         const int per = ((int)c.xref.size() > n_ ? 1 : 0) | ((int)c.uref.size() > m_ ? 2 : 0);
         Check(h, altro_set_lqr_cost(h, k, e, c.Q.data(), c.R.data(), c.xref.data(), c.uref.data(), per),
@@ -485,7 +494,11 @@ class Problem {
         while (e <= N_ && cons_[e].size() > j && cons_[e][j] == cons_[k][j]) ++e;
         const auto& c = cons_[k][j];
         const int per = (int)c.params.size() > c.nparams ? 1 : 0;
-        Check(h, altro_add_constraint(h, c.kind, k, e, c.params.data(), c.nparams, per), "altro_add_constraint");
+        if (c.kind == ALTRO_CON_USER)
+          Check(h, altro_add_user_constraint_type(h, c.user_type, k, e, c.params.data(), c.nparams, per),
+                "altro_add_user_constraint_type");
+        else
+          Check(h, altro_add_constraint(h, c.kind, k, e, c.params.data(), c.nparams, per), "altro_add_constraint");
         k = e;
       }
     Check(h, altro_set_initial_state(h, x0_.data(), (int)x0_.size() > n_ ? 1 : 0), "altro_set_initial_state");

@@ -260,6 +260,17 @@ altro_status altro_set_lqr_cost(altro_handle h, int k_begin, int k_end, const do
  * [B][nparams] when per_instance != 0.  The last cost set on a knot wins, whichever kind. */
 altro_status altro_set_user_cost(altro_handle h, int k_begin, int k_end, const double* params, int nparams,
                                  int per_instance);
+/* Several cost / constraint CLASSES in one model source -- every knot of the reference's Problem may carry any
+ * CostFunction / Constraint subclass (problem.hpp:113-202): the source lists them,
+ *     #define ALTRO_USER_COSTS        TrackCost, ParkCost           (instead of ALTRO_USER_COST)
+ *     #define ALTRO_USER_CONSTRAINTS  SwayLimit, RestAtGoal         (instead of ALTRO_USER_CONSTRAINT)
+ * each a struct of the form described above with its own nparams / p / equality, and `type` is the index in the list
+ * (altro_set_user_cost and altro_add_constraint(ALTRO_CON_USER) mean type 0).  The derivative checks at registration
+ * cover every type. */
+altro_status altro_set_user_cost_type(altro_handle h, int type, int k_begin, int k_end, const double* params, int nparams,
+                                      int per_instance);
+altro_status altro_add_user_constraint_type(altro_handle h, int type, int k_begin, int k_end, const double* params,
+                                            int nparams, int per_instance);
 
 /* Problem::SetConstraint(con, k) for k_begin <= k < k_end (problem.hpp:178-202).  Insertion order
  * is kept: at each knot the AL cost visits all equalities, then all inequalities, each in

@@ -166,32 +166,67 @@ struct IsUserModel : std::false_type {};
 template <class T>
 struct IsUserModel<UserModelAdapter<T>> : std::true_type {};
 #endif
-// The user's cost / constraint functors of the same source (problem::CostFunction, costfunction.hpp:52-73;
-// constraints::Constraint<ConType>, constraint.hpp:173-202), or stand-ins that are never called.
-#if defined(ORACLE_USER_MODEL) && defined(ALTRO_USER_COST)
-using UserCostF = altro_user::ALTRO_USER_COST;
-constexpr bool kHasUserCost = true;
-#else
-struct UserCostF {
-  static constexpr int nparams = 0;
-  template <class T> static T eval(const T*, const T*, const T*) { return T(0); }
-  template <class T> static void gradient(const T*, const T*, const T*, T*, T*) {}
-  template <class T> static void hessian(const T*, const T*, const T*, T*, T*, T*) {}
+// The user's cost / constraint classes of the same source (problem::CostFunction, costfunction.hpp:52-73;
+// constraints::Constraint<ConType>, constraint.hpp:173-202).  A reference problem may hold any mix of subclasses
+// (problem.hpp:66-133): the source lists its types (ALTRO_USER_COSTS A, B / ALTRO_USER_CONSTRAINTS C, D, or a single
+// ALTRO_USER_COST / ALTRO_USER_CONSTRAINT) and a cost / constraint carries the index of its type, which is what a
+// virtual call resolves in the reference.  Pick<List>::at(i, fn) calls fn with a null pointer of the i-th type.
+template <class... Fs>
+struct FunctorTypes {
+  static constexpr int count = (int)sizeof...(Fs);
 };
-constexpr bool kHasUserCost = false;
-#endif
-#if defined(ORACLE_USER_MODEL) && defined(ALTRO_USER_CONSTRAINT)
-using UserConF = altro_user::ALTRO_USER_CONSTRAINT;
-constexpr bool kHasUserCon = true;
-#else
-struct UserConF {
-  static constexpr int p = 1, nparams = 0;
-  static constexpr bool equality = false;
-  template <class T> static void eval(const T*, const T*, const T*, T*) {}
-  template <class T> static void jacobian(const T*, const T*, const T*, T*) {}
+template <class L>
+struct Pick;
+template <>
+struct Pick<FunctorTypes<>> {
+  template <class Fn>
+  static bool at(int, Fn&&) { return false; }
 };
-constexpr bool kHasUserCon = false;
+template <class F, class... Rest>
+struct Pick<FunctorTypes<F, Rest...>> {
+  template <class Fn>
+  static bool at(int i, Fn&& fn) {
+    if (i != 0) return Pick<FunctorTypes<Rest...>>::at(i - 1, fn);
+    fn(static_cast<F*>(nullptr));
+    return true;
+  }
+};
+#ifdef ORACLE_USER_MODEL
+namespace user_types_ {
+using namespace ::altro_user;
+#if defined(ALTRO_USER_COSTS)
+using Costs = FunctorTypes<ALTRO_USER_COSTS>;
+#elif defined(ALTRO_USER_COST)
+using Costs = FunctorTypes<ALTRO_USER_COST>;
+#else
+using Costs = FunctorTypes<>;
 #endif
+#if defined(ALTRO_USER_CONSTRAINTS)
+using Cons = FunctorTypes<ALTRO_USER_CONSTRAINTS>;
+#elif defined(ALTRO_USER_CONSTRAINT)
+using Cons = FunctorTypes<ALTRO_USER_CONSTRAINT>;
+#else
+using Cons = FunctorTypes<>;
+#endif
+}  // namespace user_types_
+using UserCosts = user_types_::Costs;
+using UserCons = user_types_::Cons;
+#else
+using UserCosts = FunctorTypes<>;
+using UserCons = FunctorTypes<>;
+#endif
+// parameter count of cost type t; (parameters, rows, cone) of constraint type t; false for a type the source lacks
+inline bool UserCostShape(int t, int* nparams) {
+  return Pick<UserCosts>::at(t, [&](auto* f) { *nparams = std::remove_pointer_t<decltype(f)>::nparams; });
+}
+inline bool UserConShape(int t, int* nparams, int* p, bool* equality) {
+  return Pick<UserCons>::at(t, [&](auto* f) {
+    using F = std::remove_pointer_t<decltype(f)>;
+    *nparams = F::nparams;
+    *p = F::p;
+    *equality = F::equality;
+  });
+}
 
 // ------------------------------------------------------------------------------------------------
 // Host-side problem specification (dtype independent, fp64).
@@ -200,12 +235,13 @@ struct CostSpec {
   int k_begin, k_end;
   std::vector<double> Q, R, xref, uref;
   int per_instance;
-  int user = 0;  // oracle_set_user_cost: the user's cost with `params`
+  int user = 0;  // oracle_set_user_cost_type: 1 + index of the user's cost type, with `params`
   std::vector<double> params;
 };
 struct ConSpec {
   int kind, k_begin, k_end, nparams, per_instance;
   std::vector<double> params;
+  int user_type = 0;  // ALTRO_CON_USER: index of the user's constraint type
 };
 
 // SolverStats Log / NewIteration semantics (altro/common/solver_stats.hpp:133-136,192-203,
@@ -308,11 +344,12 @@ struct Instance final : SolverBase {
 
   struct QCost {  // examples/quadratic_cost.hpp:13-27
     T Q[n * n], R[m * m], H[n * m], q[n], r[m], c;
-    bool user = false;    // the user's problem::CostFunction instead
+    int user = 0;         // 1 + t: the user's t-th problem::CostFunction subclass instead
     std::vector<T> upar;  // its parameters
   };
   struct Con {  // altro/constraints/constraint_values.hpp:39-51
     int kind, type /*0 equality, 1 inequality*/, p;
+    int utype = 0;              // USER: index of the user's constraint class
     std::vector<T> par;         // GOAL: xf[n]; CIRCLE: (cx,cy,r)*; BOUND: finite lb values, finite ub values
     std::vector<int> lo, hi;    // BOUND: finite index lists (basic_constraints.hpp:138-145)
     std::vector<T> c, lam, pen; // c_, lambda_, penalty_
@@ -381,7 +418,7 @@ struct Instance final : SolverBase {
   void SetLQRCost(int k, const double* Q, const double* R, const double* xref, const double* uref) {
     // QuadraticCost::LQRCost, examples/quadratic_cost.hpp:29-39
     QCost& c = cost[k];
-    c.user = false;
+    c.user = 0;
     for (int i = 0; i < n * n; ++i) c.Q[i] = T(Q[i]);
     for (int i = 0; i < m * m; ++i) c.R[i] = T(R[i]);
     for (int i = 0; i < n * m; ++i) c.H[i] = T(0);
@@ -405,17 +442,21 @@ struct Instance final : SolverBase {
     for (int i = 0; i < m; ++i) b += ur[i] * Ru[i];
     c.c = T(0.5) * a + T(0.5) * b;
   }
-  void SetUserCost(int k, const double* par, int npar) {
+  void SetUserCost(int k, int type, const double* par, int npar) {
     QCost& c = cost[k];
-    c.user = true;
+    c.user = 1 + type;
     c.upar.assign(par, par + npar);
   }
-  void AddConstraint(int k, int kind, const double* par, int npar) {
+  void AddConstraint(int k, int kind, const double* par, int npar, int utype = 0) {
     Con c;
     c.kind = kind;
     if (kind == ALTRO_CON_USER) {
-      c.type = UserConF::equality ? 0 : 1;
-      c.p = UserConF::p;
+      int np = 0, rows = 0;
+      bool eq = false;
+      UserConShape(utype, &np, &rows, &eq);  // (oracle_add_constraint_type has checked that the type exists)
+      c.utype = utype;
+      c.type = eq ? 0 : 1;
+      c.p = rows;
       c.par.assign(par, par + npar);
     } else if (kind == ALTRO_CON_GOAL) {
       c.type = 0;
@@ -468,7 +509,8 @@ struct Instance final : SolverBase {
   // con_->Evaluate (basic_constraints.hpp:27-31,98-111; obstacle_constraints.hpp:99-107)
   static void ConEval(Con& c, const T* x, const T* u) {
     if (c.kind == ALTRO_CON_USER) {
-      if constexpr (IsUserModel<Model>::value) UserConF::eval(x, u, c.par.data(), c.c.data());
+      if constexpr (IsUserModel<Model>::value)
+        Pick<UserCons>::at(c.utype, [&](auto* f) { std::remove_pointer_t<decltype(f)>::eval(x, u, c.par.data(), c.c.data()); });
     } else if (c.kind == ALTRO_CON_GOAL) {
       for (int i = 0; i < n; ++i) c.c[i] = x[i] - c.par[i];
     } else if (c.kind == ALTRO_CON_CONTROL_BOUND) {
@@ -487,8 +529,9 @@ struct Instance final : SolverBase {
   static void ConJac(const Con& c, const T* x, const T* u, T* jac) {
     for (int i = 0; i < c.p * nm; ++i) jac[i] = T(0);
     if (c.kind == ALTRO_CON_USER) {
-      T Jcm[UserConF::p * nm] = {};  // the user's Jacobian is p x (n+m) column-major (Eigen's default)
-      if constexpr (IsUserModel<Model>::value) UserConF::jacobian(x, u, c.par.data(), Jcm);
+      std::vector<T> Jcm((size_t)c.p * nm, T(0));  // the user's Jacobian is p x (n+m) column-major (Eigen's default)
+      if constexpr (IsUserModel<Model>::value)
+        Pick<UserCons>::at(c.utype, [&](auto* f) { std::remove_pointer_t<decltype(f)>::jacobian(x, u, c.par.data(), Jcm.data()); });
       for (int r = 0; r < c.p; ++r)
         for (int j = 0; j < nm; ++j) jac[r * nm + j] = Jcm[r + j * c.p];
     } else if (c.kind == ALTRO_CON_GOAL) {
@@ -527,7 +570,11 @@ struct Instance final : SolverBase {
   // QuadraticCost::Evaluate, examples/quadratic_cost.cpp:8-11
   static T QuadEval(const QCost& c, const T* x, const T* u) {
     if constexpr (IsUserModel<Model>::value) {
-      if (c.user) return UserCostF::eval(x, u, c.upar.data());  // CostFunction::Evaluate
+      if (c.user) {  // CostFunction::Evaluate of the user's class
+        T J = T(0);
+        Pick<UserCosts>::at(c.user - 1, [&](auto* f) { J = std::remove_pointer_t<decltype(f)>::eval(x, u, c.upar.data()); });
+        return J;
+      }
     }
     T xQx = 0, xHu = 0, uRu = 0, qx = 0, ru = 0;
     for (int i = 0; i < n; ++i) {
@@ -566,8 +613,11 @@ struct Instance final : SolverBase {
     T* huu = &luu[k * m * m];
     if (IsUserModel<Model>::value && qc.user) {  // CostFunction::Gradient / Hessian of the user's cost (costfunction.hpp:59-73)
       if constexpr (IsUserModel<Model>::value) {
-        UserCostF::gradient(x, u, qc.upar.data(), gx, gu);
-        UserCostF::hessian(x, u, qc.upar.data(), hxx, hxu, huu);
+        Pick<UserCosts>::at(qc.user - 1, [&](auto* f) {
+          using F = std::remove_pointer_t<decltype(f)>;
+          F::gradient(x, u, qc.upar.data(), gx, gu);
+          F::hessian(x, u, qc.upar.data(), hxx, hxu, huu);
+        });
       }
     } else {
       for (int i = 0; i < n; ++i) {
@@ -1300,9 +1350,10 @@ std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& md
   ApplyKnotTimes(h, I.h, I.tm);
   for (const CostSpec& c : h->costs) {
     if (c.user) {
-      const int np = UserCostF::nparams;
+      int np = 0;
+      UserCostShape(c.user - 1, &np);
       const double* par = c.params.data() + (c.per_instance ? (size_t)b * np : 0);
-      for (int k = c.k_begin; k < c.k_end; ++k) I.SetUserCost(k, par, np);
+      for (int k = c.k_begin; k < c.k_end; ++k) I.SetUserCost(k, c.user - 1, par, np);
       continue;
     }
     const double* xr = c.xref.data() + ((c.per_instance & 1) ? (size_t)b * n : 0);
@@ -1311,7 +1362,7 @@ std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& md
   }
   for (const ConSpec& c : h->cons) {
     const double* par = c.params.data() + (c.per_instance ? (size_t)b * c.nparams : 0);
-    for (int k = c.k_begin; k < c.k_end; ++k) I.AddConstraint(k, c.kind, par, c.nparams);
+    for (int k = c.k_begin; k < c.k_end; ++k) I.AddConstraint(k, c.kind, par, c.nparams, c.user_type);
   }
   if (!h->x0.empty()) I.SetInitialState(h->x0.data() + (h->x0_per_instance ? (size_t)b * n : 0));
   const double* X = h->has_X ? h->X.data() + (h->traj_per_instance ? (size_t)b * (D.N + 1) * n : 0) : nullptr;
@@ -1592,34 +1643,52 @@ altro_status oracle_set_lqr_cost(oracle_handle h, int k_begin, int k_end, const 
   h->built = false;
   return ALTRO_OK;
 }
-altro_status oracle_set_user_cost(oracle_handle h, int k_begin, int k_end, const double* params, int nparams,
-                                  int per_instance) {
+altro_status oracle_set_user_cost_type(oracle_handle h, int type, int k_begin, int k_end, const double* params, int nparams,
+                                       int per_instance) {
   if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
-  if (!kHasUserCost || nparams != UserCostF::nparams) return ALTRO_INVALID_ARG;
+  int np = 0;
+  if (!UserCostShape(type, &np) || nparams != np) return ALTRO_INVALID_ARG;
   CostSpec c;
   c.k_begin = k_begin;
   c.k_end = k_end;
   c.per_instance = per_instance ? 1 : 0;
-  c.user = 1;
+  c.user = 1 + type;
   if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
   h->costs.push_back(std::move(c));
   h->built = false;
   return ALTRO_OK;
 }
-altro_status oracle_add_constraint(oracle_handle h, int kind, int k_begin, int k_end,
-                                   const double* params, int nparams, int per_instance) {
+altro_status oracle_set_user_cost(oracle_handle h, int k_begin, int k_end, const double* params, int nparams,
+                                  int per_instance) {
+  return oracle_set_user_cost_type(h, 0, k_begin, k_end, params, nparams, per_instance);
+}
+static altro_status AddConstraintOfType(oracle_handle h, int kind, int user_type, int k_begin, int k_end,
+                                        const double* params, int nparams, int per_instance) {
   if (k_begin < 0 || k_end > h->desc.N + 1 || k_begin >= k_end) return ALTRO_INVALID_ARG;
   ConSpec c;
+  c.user_type = user_type;
   c.kind = kind;
   c.k_begin = k_begin;
   c.k_end = k_end;
   c.nparams = nparams;
   c.per_instance = per_instance;
-  if (kind == ALTRO_CON_USER && (!kHasUserCon || nparams != UserConF::nparams)) return ALTRO_INVALID_ARG;
+  if (kind == ALTRO_CON_USER) {
+    int np = 0, rows = 0;
+    bool eq = false;
+    if (!UserConShape(user_type, &np, &rows, &eq) || nparams != np) return ALTRO_INVALID_ARG;
+  }
   if (nparams > 0) c.params.assign(params, params + (size_t)nparams * (per_instance ? h->desc.batch : 1));
   h->cons.push_back(std::move(c));
   h->built = false;
   return ALTRO_OK;
+}
+altro_status oracle_add_constraint(oracle_handle h, int kind, int k_begin, int k_end,
+                                   const double* params, int nparams, int per_instance) {
+  return AddConstraintOfType(h, kind, 0, k_begin, k_end, params, nparams, per_instance);
+}
+altro_status oracle_add_user_constraint_type(oracle_handle h, int type, int k_begin, int k_end, const double* params,
+                                             int nparams, int per_instance) {
+  return AddConstraintOfType(h, ALTRO_CON_USER, type, k_begin, k_end, params, nparams, per_instance);
 }
 altro_status oracle_set_initial_state(oracle_handle h, const double* x0, int per_instance) {
   const int n = h->desc.n;

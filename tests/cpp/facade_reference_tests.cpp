@@ -299,6 +299,66 @@ static void UserFunctorTests() {
   EXPECT(seen);
 }
 
+// Several CostFunction / Constraint subclasses in one problem (problem.hpp:66-133): tests/models/cartpole_multi.hpp
+// lists two cost classes and three constraint classes; tests/test_user_types_gpu.py checks the same problem against the
+// oracle, here it goes through the facade (examples::UserCost / UserConstraint with a `type`).
+static void UserTypeListTests() {
+  CASE("Two user cost classes and three user constraint classes knot by knot (problem.hpp:66-133)");
+  std::ifstream f(MULTI_SOURCE_PATH);
+  std::stringstream src;
+  src << f.rdbuf();
+  EXPECT(!src.str().empty());
+  const int N = 60;
+  const double goal = 1.2, sway = 0.05, vmax = 0.6, h = 0.05;
+  examples::UserModel model("cartpole_multi", src.str(), 4, 1);
+  problem::Problem prob(N);
+  const examples::UserCost stage({goal, 1e-1 * h, 2.0 * h, 1e-1 * h, 1e-1 * h, 1e-2 * h}, -1, /*type=*/0);
+  const examples::UserCost term({goal, 100.0, 100.0}, -1, /*type=*/1);
+  for (int k = 0; k < N; ++k) {
+    prob.SetDynamics(problem::DiscretizedModel<examples::UserModel>(model), k);
+    prob.SetCostFunction(stage, k);
+    prob.SetConstraint(examples::ControlBound({-3.0}, {3.0}), k);
+  }
+  prob.SetCostFunction(term, N);
+  for (int k = 1; k < N; ++k) {
+    prob.SetConstraint(examples::UserConstraint({-sway, sway}, 2, false, -1, "Sway Limit", /*type=*/0), k);
+    prob.SetConstraint(examples::UserConstraint({vmax}, 1, false, -1, "Speed Limit", /*type=*/2), k);
+  }
+  prob.SetConstraint(examples::UserConstraint({goal}, 1, true, -1, "Tip At Goal", /*type=*/1), N);
+  prob.SetInitialState({0.0, 0.0, 0.0, 0.0});
+  EXPECT(prob.IsFullyDefined());
+  EXPECT(prob.NumConstraints(0) == 2 && prob.NumConstraints(1) == 5 && prob.NumConstraints(N) == 1);
+  augmented_lagrangian::AugmentedLagrangianiLQR<4, 1> solver(prob);
+  auto Z = std::make_shared<Trajectory<4, 1>>(N);
+  Z->SetUniformStep(static_cast<float>(h));
+  solver.SetTrajectory(Z);
+  solver.Solve();
+  EXPECT(solver.GetStatus() == SolverStatus::kSolved);
+  EXPECT(solver.MaxViolation() < 1e-4);
+  double worst_sway = 0.0, worst_speed = 0.0;
+  for (int k = 0; k <= N; ++k) {
+    worst_sway = std::max(worst_sway, std::abs(0.5 * std::sin(Z->State(k)[1])));
+    worst_speed = std::max(worst_speed, std::abs(Z->State(k)[2]));
+  }
+  EXPECT(worst_sway > sway - 1e-3 && worst_sway < sway + 1e-3);    // both inequality classes are active and held
+  EXPECT(worst_speed > vmax - 1e-3 && worst_speed < vmax + 1e-3);
+  EXPECT(std::abs(Z->State(N)[0] + 0.5 * std::sin(Z->State(N)[1]) - goal) < 1e-4);  // the equality class
+  // a class index the source does not have is refused with the count of classes it has
+  problem::Problem bad = prob;
+  bad.SetCostFunction(examples::UserCost({goal, 100.0, 100.0}, -1, /*type=*/2), N);
+  bool thrown = false;
+  try {
+    augmented_lagrangian::AugmentedLagrangianiLQR<4, 1> s2(bad);
+    auto Z2 = std::make_shared<Trajectory<4, 1>>(N);
+    Z2->SetUniformStep(static_cast<float>(h));
+    s2.SetTrajectory(Z2);
+    s2.Solve();
+  } catch (const std::exception& e) {
+    thrown = std::string(e.what()).find("2 cost type") != std::string::npos;
+  }
+  EXPECT(thrown);
+}
+
 // ---- Trajectory::SetStep / SetTime per knot (trajectory.hpp:119-120) and Problem::SetDynamics per knot ----------------
 static void KnotTimeTests() {
   CASE("Trajectory::SetStep(k, h) on every knot: the general kernels reach the uniform-step solution (trajectory.hpp:119-130)");
@@ -405,6 +465,7 @@ int main() {
     AugLagTest();
     ExampleTests();
     UserFunctorTests();
+    UserTypeListTests();
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 100;
