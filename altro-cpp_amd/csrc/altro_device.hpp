@@ -18,6 +18,9 @@ namespace altro_hip {
 
 #define ALTRO_DEV __device__ __forceinline__
 
+// most chains of batched sweeps an engine runs side by side (Engine::Chain; four unless ALTRO_HIP_CHAINS asks for more)
+constexpr int kMaxSweepChains = 8;
+
 // -------------------------------------------------------------------------------------------------
 // User-defined cost / constraint functors.  Only a user-model plugin (the translation
 // unit altro_register_model_source generates) defines them -- its source is included BEFORE this header, in namespace
@@ -253,7 +256,7 @@ struct DevArrays {
   // batch), and for the persistent kernel the number of batched sweeps each chain ran before it (chain_size = 0: [0])
   int chain_lo, chain_hi;
   int chain_size;
-  int chain_base[4];
+  int chain_base[kMaxSweepChains];
   // per-knot steps h[k] (k < N) and times t[k] (k <= N), 32-bit floats like the reference's KnotPoint (knotpoint.hpp:
   // 179-180): nullptr for a uniform step and a time-invariant model (the hot kernels then use ProblemDesc::hstep);
   // set by altro_set_steps / altro_set_times or by a time-varying user model -- see Engine::knot_times_
@@ -668,6 +671,17 @@ ALTRO_DEV void rk4_step(const T* x, const T* u, T hh, T* xn, float t = 0.0f) {
 
 // RungeKutta4::Jacobian (integration.hpp:132-169).  The reference evaluates the two middle Jacobians at time 0.5 * t
 // and the last one at t (not t + h): reproduced for time-varying models (integration.hpp:144-150).
+//
+// STRUCTURAL ZEROS.  The chain rule through the four stages is three products of n x n by n x (n + m) matrices; the
+// continuous Jacobian of most models is sparse (the 12-state model: 14 entries of 192), and entries its jac() never
+// writes are the literal 0 after inlining and unrolling.  IEEE arithmetic does not let the compiler drop `0 * x`
+// (x might be infinite), so the dense code multiplied by them: 6 900 fp64 FMAs per knot for the 12-state model, most
+// of its k_expansions time and 1.1 KB of scratch per lane.  ALTRO_SZ(a) is true when `a` is a COMPILE-TIME zero
+// (__builtin_constant_p resolves after inlining, unrolling and constant propagation): those terms are skipped, and the
+// zero pattern propagates through the stages (fill-in included).  Entries that are zero only at run time are
+// multiplied as before; a model whose Jacobian is dense compiles to the same code as before.  Against the dense
+// evaluation the result differs at most in the sign of a zero (and in not turning 0 * inf into NaN).
+#define ALTRO_SZ(a) (__builtin_constant_p(a) && (a) == T(0))
 template <class T, class M>
 ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -689,12 +703,12 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) 
   model_jac<T, M>(x, u, t, Jc);
 #pragma unroll
   for (int e = 0; e < n * n; ++e) {
-    dA[e] = Jc[e] * hh;
+    dA[e] = ALTRO_SZ(Jc[e]) ? T(0) : Jc[e] * hh;
     sA[e] = dA[e];
   }
 #pragma unroll
   for (int e = 0; e < n * m; ++e) {
-    dB[e] = Jc[n * n + e] * hh;
+    dB[e] = ALTRO_SZ(Jc[n * n + e]) ? T(0) : Jc[n * n + e] * hh;
     sB[e] = dB[e];
   }
   // stages 1..3: dA_s = A_s (I + c dA_{s-1}) h ; dB_s = B_s h + c A_s dB_{s-1} h
@@ -717,15 +731,19 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) 
 #pragma unroll
     for (int j = 0; j < n; ++j)
 #pragma unroll
-      for (int i = 0; i < n; ++i) Mx[i + j * n] = (i == j ? T(1) : T(0)) + coef * dA[i + j * n];
+      for (int i = 0; i < n; ++i) {
+        const T di = (i == j ? T(1) : T(0));
+        Mx[i + j * n] = ALTRO_SZ(dA[i + j * n]) ? di : di + coef * dA[i + j * n];
+      }
 #pragma unroll
     for (int j = 0; j < n; ++j)
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         T acc = T(0);
 #pragma unroll
-        for (int l = 0; l < n; ++l) acc += Jc[i + l * n] * Mx[l + j * n];
-        nA[i + j * n] = acc * hh;
+        for (int l = 0; l < n; ++l)
+          if (!(ALTRO_SZ(Jc[i + l * n]) || ALTRO_SZ(Mx[l + j * n]))) acc += Jc[i + l * n] * Mx[l + j * n];
+        nA[i + j * n] = ALTRO_SZ(acc) ? T(0) : acc * hh;
       }
 #pragma unroll
     for (int j = 0; j < m; ++j)
@@ -733,27 +751,35 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) 
       for (int i = 0; i < n; ++i) {
         T acc = T(0);
 #pragma unroll
-        for (int l = 0; l < n; ++l) acc += Jc[i + l * n] * dB[l + j * n];
-        nB[i + j * n] = Jc[n * n + i + j * n] * hh + coef * acc * hh;
+        for (int l = 0; l < n; ++l)
+          if (!(ALTRO_SZ(Jc[i + l * n]) || ALTRO_SZ(dB[l + j * n]))) acc += Jc[i + l * n] * dB[l + j * n];
+        const T jb = Jc[n * n + i + j * n];
+        if (ALTRO_SZ(acc)) nB[i + j * n] = ALTRO_SZ(jb) ? T(0) : jb * hh;
+        else if (ALTRO_SZ(jb)) nB[i + j * n] = coef * acc * hh;
+        else nB[i + j * n] = jb * hh + coef * acc * hh;
       }
 #pragma unroll
     for (int e = 0; e < n * n; ++e) {
       dA[e] = nA[e];
-      sA[e] = sA[e] + wgt * nA[e];
+      if (!ALTRO_SZ(nA[e])) sA[e] = ALTRO_SZ(sA[e]) ? wgt * nA[e] : sA[e] + wgt * nA[e];
     }
 #pragma unroll
     for (int e = 0; e < n * m; ++e) {
       dB[e] = nB[e];
-      sB[e] = sB[e] + wgt * nB[e];
+      if (!ALTRO_SZ(nB[e])) sB[e] = ALTRO_SZ(sB[e]) ? wgt * nB[e] : sB[e] + wgt * nB[e];
     }
   }
 #pragma unroll
   for (int j = 0; j < n; ++j)
 #pragma unroll
-    for (int i = 0; i < n; ++i) J[i + j * n] = (i == j ? T(1) : T(0)) + sA[i + j * n] / 6;
+    for (int i = 0; i < n; ++i) {
+      const T di = (i == j ? T(1) : T(0));
+      J[i + j * n] = ALTRO_SZ(sA[i + j * n]) ? di : di + sA[i + j * n] / 6;
+    }
 #pragma unroll
-  for (int e = 0; e < n * m; ++e) J[n * n + e] = sB[e] / 6;
+  for (int e = 0; e < n * m; ++e) J[n * n + e] = ALTRO_SZ(sB[e]) ? T(0) : sB[e] / 6;
 }
+#undef ALTRO_SZ
 
 // -------------------------------------------------------------------------------------------------
 // Per-knot problem access

@@ -81,7 +81,9 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
     cur_ = stream_;
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
-    persist_at_ = num_cus_;
+    // (round 3, tail iteration at 39 us: hand-over at 1x .. 8x the CUs measured, 2x .. 4x best by ~1 %: workgroups beyond
+    //  the CUs queue up behind the first round; from 6x on the persistent kernel loses to the batched sweeps)
+    persist_at_ = 2 * num_cus_;
     fwd_single_at_ = 2 * num_cus_;  // (measured 1x .. 8x the CUs: config 3 -1.2 % at 2x, config 2 indifferent)
     if (const char* e = std::getenv("ALTRO_HIP_FWD_SINGLE_AT")) fwd_single_at_ = atoi(e);
     if (const char* e = std::getenv("ALTRO_HIP_DEBUG_POISON")) {
@@ -1071,7 +1073,7 @@ class Engine final : public EngineBase {
     {
       // chains of batched sweeps: four for a batch that fills the GPU several times over (measured on 4096 instances:
       // config 2 -5 %, config 3 -14 %; a quarter of a 1024-instance batch no longer fills the CUs)
-      chains_ = B_ >= 2048 ? kMaxChains : 1;
+      chains_ = B_ >= 2048 ? kDefaultChains : 1;
       // (the streams of a process share four hardware queues: a second engine with chains of its own would queue up
       //  behind this one's persistent kernel -- only the first large engine of a process gets them)
       if (chains_ > 1 && ChainClaim(desc_.device_id, 0) > 0) chains_ = 1;
@@ -1711,13 +1713,14 @@ class Engine final : public EngineBase {
   bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
   double* d_stage_ = nullptr;
   size_t stage_cap_ = 0;
-  static constexpr int kMaxChains = 4;
+  static constexpr int kMaxChains = kMaxSweepChains;
+  static constexpr int kDefaultChains = 4;
   bool counted_chained_ = false;
   long long chain_overlap_ticks_ = 0;  // result of the side-by-side check of the chain streams (100 MHz ticks)
   int chains_ = 1;      // chains of batched sweeps (see Chain); ALTRO_HIP_CHAINS overrides
   int chain_size_ = 0;  // instances per chain (a multiple of the wavefront size)
-  hipStream_t chain_stream_[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t chain_ev_[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t chain_stream_[kMaxChains] = {};
+  hipEvent_t chain_ev_[kMaxChains] = {};
   hipEvent_t start_ev_ = nullptr;
   int* d_iota_ = nullptr;    // 0, 1, 2, ...: the active list of a chain's first sweep
   int* d_merged_ = nullptr;  // the lists of all chains, concatenated for the persistent kernel

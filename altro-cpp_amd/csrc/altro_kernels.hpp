@@ -3593,7 +3593,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   if (sweeps_out && tid == 0) {
     atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations of this launch
     atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
-    const int chain = A.chain_size ? (b / A.chain_size < 3 ? b / A.chain_size : 3) : 0;
+    const int chain = A.chain_size ? (b / A.chain_size < kMaxSweepChains - 1 ? b / A.chain_size : kMaxSweepChains - 1) : 0;
     atomicMax(sweeps_out + 2, A.chain_base[chain] + loops + skipped);  // ... counted from the first sweep of the solve
     if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word
   }
@@ -3662,8 +3662,8 @@ __global__ __launch_bounds__(kBlock) void k_spin(long long ticks, long long* sta
 
 // Concatenates the active lists the chains of batched sweeps leave behind into the list of the persistent kernel.
 struct ChainLists {
-  const int* list[4];
-  const int* count[4];
+  const int* list[kMaxSweepChains];
+  const int* count[kMaxSweepChains];
   int n;
 };
 template <int kDummy>
