@@ -46,6 +46,12 @@ namespace {
 // Oracle-only dtype code (next to ALTRO_F64 = 0 / ALTRO_F32 = 1 of include/altro_hip.h): fp64 arithmetic with
 // the expansion and gain records rounded to fp32 -- what the product's ALTRO_F32 engine computes.
 constexpr int ORACLE_F64_F32REC = 2;
+// STUDY modes (scripts/study_fp32_trials.py; nothing in the product computes this way): as
+// ORACLE_F64_F32REC, but the line search evaluates its TRIALS in fp32 -- rollout and cost on an all-fp32 shadow of the
+// instance -- and only an accepted trial is rolled out and costed again in fp64.
+//   3: the fp64 re-evaluation replaces the trial's numbers and the step is taken whatever it says
+//   4: the fp64 re-evaluation must pass the acceptance test again, else the search goes on with the next step length
+constexpr int ORACLE_F32_TRIALS = 3, ORACLE_F32_TRIALS_RECHECK = 4;
 
 // ------------------------------------------------------------------------------------------------
 // Continuous-time models.  jac is n x (n+m), column-major, fully written.
@@ -311,6 +317,13 @@ struct SolverBase {
   virtual void GetStats(altro_stats* s) = 0;
   virtual Stats& RawStats() = 0;
   virtual void SetRoundRecords(bool on) = 0;
+  // fp32-trial study: `shadow` = an all-fp32 instance of the same problem that evaluates the trials
+  virtual void SetShadow(SolverBase* shadow, bool recheck) = 0;
+  virtual void ShadowLoad(const double* X, const double* U, const double* K, const double* d, const double* lam,
+                          const double* pen) = 0;
+  virtual bool ShadowTrial(double alpha, double* J, double* cvals) = 0;
+  virtual void SetConVals(const double* in) = 0;
+  long long trials_f32 = 0, reevaluations = 0, recheck_rejections = 0;  // counters of the study
   altro_options opts;
 };
 
@@ -413,6 +426,33 @@ struct Instance final : SolverBase {
   }
   Stats& RawStats() override { return stats; }
   void SetRoundRecords(bool on) override { round_records = on; }
+  // ---- fp32-trial study (ORACLE_F32_TRIALS*) ---------------------------------------------------------------------
+  SolverBase* shadow_ = nullptr;
+  bool shadow_recheck_ = false;
+  void SetShadow(SolverBase* sh, bool recheck) override {
+    shadow_ = sh;
+    shadow_recheck_ = recheck;
+  }
+  void ShadowLoad(const double* Xi, const double* Ui, const double* Ki, const double* di, const double* lam,
+                  const double* pen) override {
+    for (int i = 0; i < (N + 1) * n; ++i) X[i] = T(Xi[i]);
+    for (int i = 0; i < N * m; ++i) U[i] = T(Ui[i]);
+    for (int i = 0; i < N * m * n; ++i) K[i] = T(Ki[i]);
+    for (int i = 0; i < N * m; ++i) d[i] = T(di[i]);
+    ForRows([&](int r, Con& c, int i) {
+      c.lam[i] = T(lam[r]);
+      c.pen[i] = T(pen[r]);
+    });
+  }
+  bool ShadowTrial(double alpha, double* J, double* cvals) override {
+    if (!RolloutClosedLoop(T(alpha))) return false;
+    *J = (double)CostOf(Xb, Ub);
+    ForRows([&](int r, Con& c, int i) { cvals[r] = (double)c.c[i]; });
+    return true;
+  }
+  void SetConVals(const double* in) override {
+    ForRows([&](int r, Con& c, int i) { c.c[i] = T(in[r]); });
+  }
 
   // ---- problem definition -----------------------------------------------------------------
   void SetLQRCost(int k, const double* Q, const double* R, const double* xref, const double* uref) {
@@ -1025,6 +1065,55 @@ struct Instance final : SolverBase {
     for (int k = 0; k <= N; ++k) J0 += costs[k];
     T alpha = 1, z = -1, J = J0;
     bool success = false;
+    if (shadow_) {  // the fp32-trial study: see ORACLE_F32_TRIALS
+      const int R = NumRows();
+      std::vector<double> Xd((N + 1) * n), Ud((N + 1) * m), Kd(N * m * n), dd(N * m), lam(R), pen(R), cv(R), cv_last(R);
+      GetTrajectory(Xd.data(), Ud.data());
+      GetGains(Kd.data(), dd.data());
+      GetDuals(lam.data());
+      GetPenalties(pen.data());
+      shadow_->ShadowLoad(Xd.data(), Ud.data(), Kd.data(), dd.data(), lam.data(), pen.data());
+      bool any_trial = false;
+      for (int it = 0; it < opts.line_search_max_iterations; ++it) {
+        double J32 = 0.0;
+        trials_f32++;
+        if (shadow_->ShadowTrial((double)alpha, &J32, cv.data())) {
+          any_trial = true;
+          cv_last = cv;
+          const T expected = -alpha * (deltaV[0] + alpha * deltaV[1]);
+          const T z32 = expected > T(0) ? (J0 - T(J32)) / expected : T(-1);
+          if (T(opts.line_search_lower_bound) <= z32 && z32 <= T(opts.line_search_upper_bound) && T(J32) < J0) {
+            reevaluations++;
+            const bool ok = RolloutClosedLoop(alpha);  // fp64, this instance: Xb, Ub, c_
+            if (ok) {
+              J = CostOf(Xb, Ub);
+              z = expected > T(0) ? (J0 - J) / expected : T(-1);
+              const bool pass = T(opts.line_search_lower_bound) <= z && z <= T(opts.line_search_upper_bound) && J < J0;
+              if (pass || !shadow_recheck_) {
+                success = true;
+                any_trial = false;  // c_ is the fp64 evaluation of the accepted step
+                stats.Log(F_COST, (double)J);
+                stats.Log(F_ALPHA, (double)alpha);
+                stats.Log(F_Z, (double)z);
+                break;
+              }
+              recheck_rejections++;
+            }
+          }
+        }
+        alpha /= T(opts.line_search_decrease_factor);
+      }
+      if (any_trial) SetConVals(cv_last.data());  // stale c_ of the last trial (quirk Q6), here an fp32 evaluation
+      if (success) {
+        X = Xb;
+        U = Ub;
+      } else {
+        IncreaseRegularization();
+        J = J0;
+      }
+      if (J > J0) status_ = ALTRO_COST_INCREASE;
+      return;
+    }
     for (int it = 0; it < opts.line_search_max_iterations; ++it) {
       if (RolloutClosedLoop(alpha)) {
         J = CostOf(Xb, Ub);
@@ -1318,6 +1407,7 @@ struct oracle_solver_s {
   bool built = false;
   bool ilqr_mode = false;
   std::vector<std::unique_ptr<SolverBase>> inst;
+  std::vector<std::unique_ptr<SolverBase>> shadow;  // fp32-trial study only (ORACLE_F32_TRIALS*)
   std::string err;
   // CPU-baseline runs (oracle_bench_*): wall time between the start barrier of the thread team and its last task,
   // the threads that ran and the slowest / fastest thread's busy time
@@ -1393,13 +1483,24 @@ std::unique_ptr<SolverBase> MakeForModel(oracle_handle h, int b) {
 altro_status Build(oracle_handle h) {
   if (h->built) {
     for (auto& I : h->inst) I->opts = h->opts;
+    for (auto& I : h->shadow) I->opts = h->opts;
     return ALTRO_OK;
   }
   h->inst.clear();
+  h->shadow.clear();
+  const bool f32_trials = h->desc.dtype == ORACLE_F32_TRIALS || h->desc.dtype == ORACLE_F32_TRIALS_RECHECK;
   for (int b = 0; b < h->desc.batch; ++b) {
     std::unique_ptr<SolverBase> I =
         h->desc.dtype == ALTRO_F32 ? MakeForModel<float>(h, b) : MakeForModel<double>(h, b);
-    if (I && h->desc.dtype == ORACLE_F64_F32REC) I->SetRoundRecords(true);
+    if (I && (h->desc.dtype == ORACLE_F64_F32REC || f32_trials)) I->SetRoundRecords(true);
+    if (I && f32_trials) {  // the study: trials on an all-fp32 shadow of the instance
+      std::unique_ptr<SolverBase> S = MakeForModel<float>(h, b);
+      if (S) {
+        S->opts = h->opts;
+        I->SetShadow(S.get(), h->desc.dtype == ORACLE_F32_TRIALS_RECHECK);
+        h->shadow.push_back(std::move(S));
+      }
+    }
     if (!I) {
       h->err = "unsupported (model, n, m) combination";
       return ALTRO_UNSUPPORTED;
@@ -1697,6 +1798,9 @@ altro_status oracle_set_initial_state(oracle_handle h, const double* x0, int per
   if (h->built)
     for (int b = 0; b < h->desc.batch; ++b)
       h->inst[b]->SetInitialState(h->x0.data() + (per_instance ? (size_t)b * n : 0));
+  if (h->built)
+    for (size_t b = 0; b < h->shadow.size(); ++b)
+      h->shadow[b]->SetInitialState(h->x0.data() + (per_instance ? b * n : 0));
   return ALTRO_OK;
 }
 altro_status oracle_set_trajectory(oracle_handle h, const double* X, const double* U, int per_instance) {
@@ -1745,6 +1849,7 @@ altro_status oracle_pack_results_device(oracle_handle h, void* dst) {
 altro_status oracle_set_options(oracle_handle h, const altro_options* o) {
   h->opts = *o;
   for (auto& I : h->inst) I->opts = *o;
+  for (auto& I : h->shadow) I->opts = *o;
   return ALTRO_OK;
 }
 altro_status oracle_get_options(oracle_handle h, altro_options* o) {
@@ -1832,6 +1937,16 @@ altro_status oracle_cost(oracle_handle h, double* J) {
 }
 altro_status oracle_update_expansions(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.UpdateExpansions(); }); }
 altro_status oracle_backward_pass(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.BackwardPass(); }); }
+// fp32-trial study (ORACLE_F32_TRIALS*): fp32 trials evaluated, accepted trials re-evaluated in fp64, re-evaluations
+// that failed the acceptance test (mode 4), summed over the instances
+void oracle_study_counters(oracle_handle h, long long* out) {
+  out[0] = out[1] = out[2] = 0;
+  for (auto& I : h->inst) {
+    out[0] += I->trials_f32;
+    out[1] += I->reevaluations;
+    out[2] += I->recheck_rejections;
+  }
+}
 altro_status oracle_forward_pass(oracle_handle h) { return ForAll(h, [](SolverBase& s, int) { s.ForwardPass(); }); }
 altro_status oracle_update_convergence_statistics(oracle_handle h) {
   return ForAll(h, [](SolverBase& s, int) { s.UpdateConvergenceStatistics(); });
