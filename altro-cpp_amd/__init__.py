@@ -465,6 +465,10 @@ class BatchSolver:
     def pack_results_device(self, device_ptr):
         self._call("pack_results_device", C.c_void_p(device_ptr))
 
+    def pack_trajectory_device(self, x_ptr, u_ptr):
+        """X[B][N+1][n], U[B][N][m] doubles into device memory of this handle's device (either pointer may be 0)."""
+        self._call("pack_trajectory_device", C.c_void_p(x_ptr or None), C.c_void_p(u_ptr or None))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cu = C.c_int()

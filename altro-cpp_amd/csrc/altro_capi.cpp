@@ -854,5 +854,9 @@ altro_status altro_pack_results_device(altro_handle h, void* dst_device) {
   if (!dst_device) return ALTRO_INVALID_ARG;
   return Forward(h, [&](EngineBase& e) { return e.PackResultsDevice(dst_device); });
 }
+altro_status altro_pack_trajectory_device(altro_handle h, void* X_device, void* U_device) {
+  if (!X_device && !U_device) return ALTRO_INVALID_ARG;
+  return Forward(h, [&](EngineBase& e) { return e.PackTrajectoryDevice((double*)X_device, (double*)U_device); });
+}
 
 }  // extern "C"

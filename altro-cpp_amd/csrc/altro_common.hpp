@@ -180,6 +180,7 @@ class EngineBase {
   virtual int GetHistory(int instance, int field, double* out, int cap) = 0;
   virtual int GetHistoryAll(int instance, double* out /*[kHistFields][cap]*/, int cap) = 0;
   virtual altro_status PackResultsDevice(void* dst) = 0;
+  virtual altro_status PackTrajectoryDevice(double* X, double* U) = 0;
   virtual altro_status DeviceInfo(char* name, int name_len, int* cu_count) = 0;
   virtual const char* LastError() = 0;
 };

@@ -489,6 +489,17 @@ class Engine final : public EngineBase {
     hipLaunchKernelGGL(k_pack_results<T>, GridB(), dim3(kBlock), 0, stream_, A_, (double*)dst, last_mode_ilqr_ ? 1 : 0);
     return Sync();
   }
+  // records [knots][Bp][nP] -> the caller's rows [B][knots][n] straight into the caller's DEVICE buffers
+  altro_status PackTrajectoryDevice(double* X, double* U) override {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    if (X)
+      hipLaunchKernelGGL((k_rec_to_rows<T>), dim3((B_ + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, stream_, (const T*)A_.X, X,
+                         N_ + 1, R::nP, 0, n, B_, Bp_);
+    if (U)
+      hipLaunchKernelGGL((k_rec_to_rows<T>), dim3((B_ + kBlock - 1) / kBlock, N_), dim3(kBlock), 0, stream_, (const T*)A_.U, U, N_,
+                         R::mP, 0, m, B_, Bp_);
+    return Sync();
+  }
 
  private:
   // ---- helpers ----------------------------------------------------------------------------------

@@ -22,8 +22,11 @@ struct altro_group_s {
   std::vector<double*> d_send;  // [slot][4] records of the part, padded to the largest part
   std::vector<double*> d_recv;  // [ndev][slot][4]
   std::vector<double> part_ms;
-  double gather_ms = 0.0;
+  double gather_ms = 0.0, traj_gather_ms = 0.0;
   int slot = 0;  // records per part in the gather buffers (= largest batch)
+  // trajectory gather (altro_group_gather_trajectories): [slot][N+1][n] / [slot][N][m] per part, padded like the records
+  std::vector<double*> d_sendX, d_recvX, d_sendU, d_recvU;
+  int tslot = 0, tn = 0, tm = 0, tN = 0;
   bool comms_ok = false;
   std::string err;
 };
@@ -56,6 +59,16 @@ void FreeBuffers(altro_group g) {
     g->d_send[i] = g->d_recv[i] = nullptr;
   }
   g->slot = 0;
+}
+void FreeTrajectoryBuffers(altro_group g) {
+  for (size_t i = 0; i < g->dev.size(); ++i) {
+    if (hipSetDevice(g->dev[i]) != hipSuccess) continue;
+    for (std::vector<double*>* v : {&g->d_sendX, &g->d_recvX, &g->d_sendU, &g->d_recvU}) {
+      if ((*v)[i]) hipFree((*v)[i]);
+      (*v)[i] = nullptr;
+    }
+  }
+  g->tslot = 0;
 }
 
 altro_status EnsureBuffers(altro_group g) {
@@ -103,6 +116,10 @@ altro_status altro_group_create(const int* device_ids, int ndev, altro_group* ou
   g->d_send.assign(ndev, nullptr);
   g->d_recv.assign(ndev, nullptr);
   g->part_ms.assign(ndev, 0.0);
+  g->d_sendX.assign(ndev, nullptr);
+  g->d_recvX.assign(ndev, nullptr);
+  g->d_sendU.assign(ndev, nullptr);
+  g->d_recvU.assign(ndev, nullptr);
   auto fail = [&](const std::string& what) {
     g_create_err = what;
     altro_group_destroy(g);
@@ -166,6 +183,86 @@ altro_status altro_group_gather(altro_group g) {
   g->gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return ALTRO_OK;
 }
+
+altro_status altro_group_gather_trajectories(altro_group g, int n, int m, int N) {
+  if (!g || n < 1 || m < 1 || N < 1) return ALTRO_INVALID_ARG;
+  const int ndev = (int)g->dev.size();
+  int slot = 0;
+  for (int i = 0; i < ndev; ++i) {
+    if (!g->handle[i]) {
+      g->err = "part " + std::to_string(i) + " has no handle attached (altro_group_attach)";
+      return ALTRO_NOT_READY;
+    }
+    slot = std::max(slot, g->batch[i]);
+  }
+  const size_t xrow = (size_t)(N + 1) * n, urow = (size_t)N * m;
+  if (slot != g->tslot || n != g->tn || m != g->tm || N != g->tN) {
+    FreeTrajectoryBuffers(g);
+    for (int i = 0; i < ndev; ++i) {
+      GROUP_HIP(hipSetDevice(g->dev[i]));
+      GROUP_HIP(hipMalloc((void**)&g->d_sendX[i], slot * xrow * sizeof(double)));
+      GROUP_HIP(hipMalloc((void**)&g->d_recvX[i], (size_t)ndev * slot * xrow * sizeof(double)));
+      GROUP_HIP(hipMalloc((void**)&g->d_sendU[i], slot * urow * sizeof(double)));
+      GROUP_HIP(hipMalloc((void**)&g->d_recvU[i], (size_t)ndev * slot * urow * sizeof(double)));
+      GROUP_HIP(hipMemsetAsync(g->d_sendX[i], 0, slot * xrow * sizeof(double), g->stream[i]));  // (the padding of a smaller part)
+      GROUP_HIP(hipMemsetAsync(g->d_sendU[i], 0, slot * urow * sizeof(double), g->stream[i]));
+      GROUP_HIP(hipStreamSynchronize(g->stream[i]));
+    }
+    g->tslot = slot;
+    g->tn = n;
+    g->tm = m;
+    g->tN = N;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < ndev; ++i) {
+    const altro_status st = altro_pack_trajectory_device(g->handle[i], g->d_sendX[i], g->d_sendU[i]);
+    if (st != ALTRO_OK) {
+      g->err = std::string("altro_pack_trajectory_device on part ") + std::to_string(i) + ": " + altro_last_error(g->handle[i]);
+      return st;
+    }
+  }
+  GROUP_NCCL(ncclGroupStart());
+  for (int i = 0; i < ndev; ++i) {
+    GROUP_HIP(hipSetDevice(g->dev[i]));
+    GROUP_NCCL(ncclAllGather(g->d_sendX[i], g->d_recvX[i], slot * xrow, ncclDouble, g->comm[i], g->stream[i]));
+    GROUP_NCCL(ncclAllGather(g->d_sendU[i], g->d_recvU[i], slot * urow, ncclDouble, g->comm[i], g->stream[i]));
+  }
+  GROUP_NCCL(ncclGroupEnd());
+  for (int i = 0; i < ndev; ++i) {
+    GROUP_HIP(hipSetDevice(g->dev[i]));
+    GROUP_HIP(hipStreamSynchronize(g->stream[i]));
+  }
+  g->traj_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return ALTRO_OK;
+}
+
+altro_status altro_group_get_trajectories(altro_group g, int part, double* X, double* U, int capacity_instances) {
+  if (!g || (!X && !U) || part < 0 || part >= (int)g->dev.size()) return ALTRO_INVALID_ARG;
+  const int ndev = (int)g->dev.size();
+  if (capacity_instances < altro_group_total(g)) {
+    g->err = "altro_group_get_trajectories: the buffers hold fewer instances than the global batch";
+    return ALTRO_INVALID_ARG;
+  }
+  if (!g->tslot || !g->d_recvX[part]) {
+    g->err = "no trajectories gathered yet (altro_group_gather_trajectories)";
+    return ALTRO_NOT_READY;
+  }
+  const size_t xrow = (size_t)(g->tN + 1) * g->tn, urow = (size_t)g->tN * g->tm;
+  GROUP_HIP(hipSetDevice(g->dev[part]));
+  size_t o = 0;
+  for (int i = 0; i < ndev; ++i) {  // one copy per part: the padding of the smaller parts is skipped
+    if (X)
+      GROUP_HIP(hipMemcpyAsync(X + o * xrow, g->d_recvX[part] + (size_t)i * g->tslot * xrow, g->batch[i] * xrow * sizeof(double),
+                               hipMemcpyDeviceToHost, g->stream[part]));
+    if (U)
+      GROUP_HIP(hipMemcpyAsync(U + o * urow, g->d_recvU[part] + (size_t)i * g->tslot * urow, g->batch[i] * urow * sizeof(double),
+                               hipMemcpyDeviceToHost, g->stream[part]));
+    o += g->batch[i];
+  }
+  GROUP_HIP(hipStreamSynchronize(g->stream[part]));
+  return ALTRO_OK;
+}
+double altro_group_trajectory_gather_ms(altro_group g) { return g ? g->traj_gather_ms : 0.0; }
 
 altro_status altro_group_solve_al(altro_group g) {
   if (!g) return ALTRO_INVALID_ARG;
@@ -240,6 +337,7 @@ const char* altro_group_last_error(altro_group g) { return g ? g->err.c_str() : 
 void altro_group_destroy(altro_group g) {
   if (!g) return;
   FreeBuffers(g);
+  FreeTrajectoryBuffers(g);
   for (size_t i = 0; i < g->dev.size(); ++i) {
     if (g->comms_ok && g->comm[i]) ncclCommDestroy(g->comm[i]);
     if (g->stream[i] && hipSetDevice(g->dev[i]) == hipSuccess) hipStreamDestroy(g->stream[i]);

@@ -5,7 +5,8 @@ reference has no batch and no distributed code at all, so there is nothing to tr
 owns a contiguous block of instances, solves it with its own handle on its own device, and the only
 collective is ONE all_gather of the 32-byte per-instance result record {cost, violation,
 iterations_total, status} after the solve (RCCL over xGMI on GPUs: backend "nccl"; gloo on CPU for
-the tests).  No all-reduce, no per-iteration communication.
+the tests).  No all-reduce, no per-iteration communication.  A caller that wants the whole solution on
+every device asks for the optional second collective, ``pack_and_gather_trajectories``.
 
 ``pack_and_gather`` is the one code path of that exchange: bench.py calls it on GPU tensors with RCCL,
 tests/test_sharding_gloo.py calls the very same function on CPU tensors with gloo.
@@ -44,6 +45,23 @@ def pack_and_gather(solver, packed, gathered=None, dist=None, force_collective=F
         dist.all_gather_into_tensor(gathered, packed)
         return gathered
     return packed
+
+
+def pack_and_gather_trajectories(solver, x_packed, u_packed, x_gathered=None, u_gathered=None, dist=None,
+                                 force_collective=False):
+    """The optional SECOND collective of SURVEY.md section 8(e): every rank receives the trajectories of all shards.
+
+    The solver writes X[b][N+1][n] and U[b][N][m] (fp64, the layout of ``get_trajectory``) straight into ``x_packed`` /
+    ``u_packed`` -- memory of the rank's own device -- and, with more than one rank, two ``all_gather_into_tensor``
+    calls assemble [world * b][...] on every rank (C4: 32 768 x 503 doubles = 132 MB per GPU; at one xGMI link of
+    ~153 GB/s per neighbour that is ~1 ms in a ring over several links, against 41 ms of solve).  Equal shard sizes.
+    Returns the two tensors that hold the global trajectories."""
+    solver.pack_trajectory_device(x_packed.data_ptr(), u_packed.data_ptr())
+    if dist is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
+        dist.all_gather_into_tensor(x_gathered, x_packed)
+        dist.all_gather_into_tensor(u_gathered, u_packed)
+        return x_gathered, u_gathered
+    return x_packed, u_packed
 
 
 def gather_variable(local_np, dist):

@@ -575,6 +575,21 @@ def main():
             dist_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                           "records_match_get_stats": bool(np.array_equal(res, want)),
                           "gather_is_separate_buffer": bool(gathered.data_ptr() != packed.data_ptr())}
+            # the optional second collective (whole trajectories on every rank), outside the timed region
+            Nk, nn, mm = solver.N, solver.n, solver.m
+            xp = torch.empty((B, Nk + 1, nn), dtype=torch.float64, device=dev)
+            up = torch.empty((B, Nk, mm), dtype=torch.float64, device=dev)
+            xg, ug = torch.empty_like(xp), torch.empty_like(up)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            Xall, Uall = S.pack_and_gather_trajectories(solver, xp, up, xg, ug, dist, force_collective=True)
+            torch.cuda.synchronize()
+            g_ms = 1e3 * (time.perf_counter() - g0)
+            Xh, Uh = solver.get_trajectory()
+            dist_check.update({"trajectories_match_get_trajectory": bool(np.array_equal(Xall.cpu().numpy(), Xh) and
+                                                                         np.array_equal(Uall.cpu().numpy(), Uh)),
+                               "trajectory_gather_ms": round(g_ms, 3),
+                               "trajectory_bytes": int(xp.numel() * 8 + up.numel() * 8)})
         others, latency = None, None
         if world == 1 and args.pipeline == 1 and (not args.no_other_configs or not args.no_latency):
             solver.close()  # (the other workloads get the device to themselves, like the headline had it)

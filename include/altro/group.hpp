@@ -41,6 +41,9 @@ class BatchGroup {
   template <int n, int m>
   void Attach(int part, augmented_lagrangian::AugmentedLagrangianiLQR<n, m>& solver) {
     Check(altro_group_attach(g_, part, solver.Handle(), solver.BatchSize()), "altro_group_attach");
+    n_ = n;
+    m_ = m;
+    knots_ = solver.NumSegments();
     if ((int)async_.size() <= part) async_.resize(part + 1);
     async_[part] = {[&solver] { solver.SolveAsync(); }, [&solver] { solver.Wait(); }};
   }
@@ -58,6 +61,15 @@ class BatchGroup {
     return out;
   }
   double GatherMilliseconds() const { return altro_group_gather_ms(g_); }
+  // The optional second collective: every device receives the trajectories of all parts.
+  // X[TotalInstances()][N+1][n], U[TotalInstances()][N][m] in part order, as device `part` received them.
+  void GatherTrajectories() { Check(altro_group_gather_trajectories(g_, n_, m_, knots_), "altro_group_gather_trajectories"); }
+  std::pair<std::vector<double>, std::vector<double>> Trajectories(int part = 0) {
+    std::vector<double> X((size_t)TotalInstances() * (knots_ + 1) * n_), U((size_t)TotalInstances() * knots_ * m_);
+    Check(altro_group_get_trajectories(g_, part, X.data(), U.data(), TotalInstances()), "altro_group_get_trajectories");
+    return {std::move(X), std::move(U)};
+  }
+  double TrajectoryGatherMilliseconds() const { return altro_group_trajectory_gather_ms(g_); }
   altro_group Handle() { return g_; }
 
  private:
@@ -70,6 +82,7 @@ class BatchGroup {
   std::vector<int> devices_;
   altro_group g_ = nullptr;
   std::vector<Async> async_;
+  int n_ = 0, m_ = 0, knots_ = 0;  // dimensions of the attached solvers (the last Attach)
 };
 
 }  // namespace altro

@@ -43,6 +43,15 @@ altro_status altro_group_gather(altro_group g);
 /* The gathered records as the device of part `part` holds them: [sum of batches][4] doubles in part order. */
 altro_status altro_group_get_results(altro_group g, int part, double* out, int capacity_records);
 int altro_group_total(altro_group g);
+/* The optional second collective of SURVEY.md section 8(e): whole trajectories on every device.  Every handle packs
+ * X[b][N+1][n] and U[b][N][m] (doubles, the layout of altro_get_trajectory) on its own device
+ * (altro_pack_trajectory_device), two ncclAllGather calls in one group on the group's streams.  n, m, N: the
+ * dimensions the attached handles were created with.  C4: 32 768 x 503 doubles = 132 MB per device. */
+altro_status altro_group_gather_trajectories(altro_group g, int n, int m, int N);
+/* The gathered trajectories as the device of part `part` holds them, in part order: X[total][N+1][n], U[total][N][m]
+ * (either may be NULL); capacity_instances >= altro_group_total. */
+altro_status altro_group_get_trajectories(altro_group g, int part, double* X, double* U, int capacity_instances);
+double altro_group_trajectory_gather_ms(altro_group g);
 /* Wall time of the last altro_group_solve_al per part (ms; load imbalance is the only scaling loss) and of the
  * exchange. */
 double altro_group_part_ms(altro_group g, int part);

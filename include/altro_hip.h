@@ -389,6 +389,10 @@ int altro_get_history_all(altro_handle h, int instance, double* out, int cap);
  * DEVICE memory dst[B][4] on this handle's device (e.g. a torch tensor's data_ptr) so it can be
  * fed to an RCCL all_gather. */
 altro_status altro_pack_results_device(altro_handle h, void* dst_device);
+/* The trajectories in caller-provided DEVICE memory on this handle's device, in the layout of altro_get_trajectory:
+ * X_device[B][N+1][n], U_device[B][N][m] doubles (either may be NULL) -- the payload of the optional second collective of
+ * SURVEY.md section 8(e), an all-gather of whole trajectories when the caller wants them on one device. */
+altro_status altro_pack_trajectory_device(altro_handle h, void* X_device, void* U_device);
 /* Device name and multiprocessor count of the handle's device. */
 altro_status altro_device_info(altro_handle h, char* name, int name_len, int* cu_count);
 

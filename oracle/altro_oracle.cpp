@@ -1846,6 +1846,15 @@ altro_status oracle_pack_results_device(oracle_handle h, void* dst) {
     out[4 * (size_t)b + 3] = (double)(h->ilqr_mode ? st.status_ilqr : st.status);
   });
 }
+// host-memory counterpart of altro_pack_trajectory_device
+altro_status oracle_pack_trajectory_device(oracle_handle h, void* Xd, void* Ud) {
+  const altro_desc& D = h->desc;
+  double* X = static_cast<double*>(Xd);
+  double* U = static_cast<double*>(Ud);
+  return ForAll(h, [&](SolverBase& s, int b) {  // (every instance writes its own rows: safe from several threads)
+    s.GetTrajectory(X ? X + (size_t)b * (D.N + 1) * D.n : nullptr, U ? U + (size_t)b * D.N * D.m : nullptr);
+  });
+}
 altro_status oracle_set_options(oracle_handle h, const altro_options* o) {
   h->opts = *o;
   for (auto& I : h->inst) I->opts = *o;

@@ -105,6 +105,21 @@ static int SolveSharded(int gpus, int batch_per_gpu, int nruns) {
                 "records %s the per-solver statistics\n",
                 gpus, batch_per_gpu, run, ms, group.GatherMilliseconds(), solved, total, solved / (ms * 1e-3),
                 failures ? "DIFFER from" : "match");
+    if (run == nruns - 1) {
+      // the optional second collective: every device receives all trajectories; compared with each solver's own
+      group.GatherTrajectories();
+      const auto XU = group.Trajectories(0);
+      int traj_failures = 0;
+      size_t inst = 0;
+      for (int part = 0; part < gpus; ++part) {  // (Wait() has copied each solver's solution into its trajectory)
+        for (int b = 0; b < trajs[part]->BatchSize(); ++b, ++inst)
+          for (int k = 0; k <= 100; ++k)
+            for (int i = 0; i < 3; ++i) traj_failures += XU.first[(inst * 101 + k) * 3 + i] != trajs[part]->State(k, b)[i];
+      }
+      std::printf("trajectory all-gather: %.3f ms for %zu doubles per device, trajectories %s the per-solver ones\n",
+                  group.TrajectoryGatherMilliseconds(), XU.first.size() + XU.second.size(), traj_failures ? "DIFFER from" : "match");
+      failures += traj_failures;
+    }
   }
   return failures;
 }

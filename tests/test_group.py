@@ -21,6 +21,7 @@ def _lib():
     lib.altro_group_last_error.argtypes = [ctypes.c_void_p]
     lib.altro_group_part_ms.restype = ctypes.c_double
     lib.altro_group_gather_ms.restype = ctypes.c_double
+    lib.altro_group_trajectory_gather_ms.restype = ctypes.c_double
     return lib
 
 
@@ -83,6 +84,16 @@ def test_group_of_one_device_gathers_the_solver_statistics(A, P, hip_make):
             assert np.array_equal(out, want)
             assert lib.altro_group_total(g) == B and lib.altro_group_part_ms(g, 0) > 0 and lib.altro_group_gather_ms(g) > 0
         assert lib.altro_group_get_results(g, 0, out.ctypes.data_as(ctypes.c_void_p), B - 1) != 0
+        # the optional second collective: whole trajectories (two more ncclAllGather calls), equal to get_trajectory
+        X, U = np.zeros((B, 101, 3)), np.zeros((B, 100, 2))
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.altro_group_get_trajectories(g, 0, vp(X), vp(U), B) != 0 and b"no trajectories gathered" in lib.altro_group_last_error(g)
+        for _ in range(2):
+            assert lib.altro_group_gather_trajectories(g, 3, 2, 100) == 0, lib.altro_group_last_error(g)
+            assert lib.altro_group_get_trajectories(g, 0, vp(X), vp(U), B) == 0, lib.altro_group_last_error(g)
+            Xr, Ur = s.get_trajectory()
+            assert np.array_equal(X, Xr) and np.array_equal(U, Ur)
+        assert lib.altro_group_trajectory_gather_ms(g) > 0
     finally:
         lib.altro_group_destroy(g)
 
@@ -97,3 +108,4 @@ def test_perf_driver_shards_through_the_facade_group():
     assert r.returncode == 0
     lines = [l for l in r.stdout.splitlines() if "GPU(s) x 512 instances" in l]
     assert len(lines) == 2 and all("records match the per-solver statistics" in l for l in lines)
+    assert "trajectories match the per-solver ones" in r.stdout

@@ -26,6 +26,8 @@ def test_bench_nccl_path_with_one_rank(config):
     dc = line["dist_check"]
     assert dc["backend"] == "nccl" and dc["world_size"] == 1
     assert dc["records_match_get_stats"] and dc["gather_is_separate_buffer"]
+    # the optional second collective: all_gather_into_tensor of the whole trajectories, packed on the device
+    assert dc["trajectories_match_get_trajectory"] and dc["trajectory_bytes"] == 4096 * (101 * 3 + 100 * 2) * 8
     assert line["value"] > 0 and line["n_gpus"] == 1
     # the chains of sweeps still run side by side with RCCL's streams in the process (created after the solver's)
     assert line["roofline"]["concurrent_chains"] == 4

@@ -39,6 +39,14 @@ if total % world == 0:
     gathered = torch.empty((world * b, 4), dtype=torch.float64)
     allrec = S.pack_and_gather(s, packed, gathered, dist).numpy()
     assert np.array_equal(packed.numpy(), S.result_records(s.get_stats()))
+    # the optional second collective: whole trajectories on every rank
+    xp, up = torch.empty((b, 101, 3), dtype=torch.float64), torch.empty((b, 100, 2), dtype=torch.float64)
+    xg, ug = torch.empty((world * b, 101, 3), dtype=torch.float64), torch.empty((world * b, 100, 2), dtype=torch.float64)
+    Xall, Uall = S.pack_and_gather_trajectories(s, xp, up, xg, ug, dist)
+    Xl, Ul = s.get_trajectory()
+    assert np.array_equal(xp.numpy(), Xl) and np.array_equal(up.numpy(), Ul)
+    if rank == 0:
+        np.savez(sys.argv[3] + ".traj.npz", X=Xall.numpy(), U=Uall.numpy())
 else:
     allrec = S.gather_variable(S.result_records(s.get_stats()), dist)
 if rank == 0:
@@ -76,6 +84,10 @@ def test_two_rank_gloo_matches_single_process(tmp_path, A, P, oracle_make, total
     ref = S.result_records(s.get_stats())
     assert gathered.shape == ref.shape
     assert (gathered == ref).all()  # bitwise: instances are independent of how they are sharded
+    if total % 2 == 0:  # the trajectory all-gather of the equal-shard path
+        t = np.load(str(out) + ".traj.npz")
+        Xr, Ur = s.get_trajectory()
+        assert np.array_equal(t["X"], Xr) and np.array_equal(t["U"], Ur)
 
 
 def test_shard_range_partitions(A):
