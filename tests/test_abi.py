@@ -85,6 +85,15 @@ def test_argument_validation(A):
         s.set_penalty(-1.0)
     with pytest.raises(A.AltroError):  # ALTRO_ASSERT(phi >= 1), constraint_values.hpp:85
         s.set_penalty_scaling(0.5)
+    # the typed user functors and the device-side packing entry points validate before they touch a device
+    with pytest.raises(A.AltroError):
+        s.set_user_cost(0, 5, np.zeros(3), type=-1)
+    with pytest.raises(A.AltroError):
+        s.add_user_constraint(0, 5, np.zeros(2), type=-1)
+    with pytest.raises(A.AltroError):
+        s.add_user_constraint(0, 12, np.zeros(2), type=0)   # past the last knot
+    with pytest.raises(A.AltroError):
+        s.pack_trajectory_device(0, 0)
 
 
 def test_no_cpu_fallback(A, P):
