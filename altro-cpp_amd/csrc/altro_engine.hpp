@@ -216,7 +216,7 @@ class Engine final : public EngineBase {
   altro_status AlInit(const altro_options& o) override {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     const DevOpts d = ToDevOpts(o);
-    hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+    hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
     hipLaunchKernelGGL((k_knot_costs<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_);
     hipLaunchKernelGGL(k_log_viol_pen<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_);
     return Sync();
@@ -505,6 +505,7 @@ class Engine final : public EngineBase {
   // ---- helpers ----------------------------------------------------------------------------------
   dim3 GridB() const { return dim3((B_ + kBlock - 1) / kBlock); }
   dim3 GridBK() const { return dim3((B_ + kBlock - 1) / kBlock, N_ + 1); }
+  dim3 GridAlInit() const { return dim3((B_ + kBlock - 1) / kBlock, std::max(1, (pd_.total_rows + kAlInitRows - 1) / kAlInitRows)); }
   // Backward pass launch: fp64 unicycle-sized problems run on the matrix cores (4 instances per
   // wavefront), everything else on the one-lane-per-instance VALU kernel.
   // The MFMA backward pass computes in fp64 whatever the storage type of the engine is
@@ -1367,7 +1368,7 @@ class Engine final : public EngineBase {
     size_t nev = 0;
     cur_ = stream_;
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-    if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+    if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
     hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, d, 1);
     hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     timing_.launches += (mode == kFwdAL) ? 3 : 2;
