@@ -74,7 +74,8 @@ class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("init_ms", C.c_double), ("expansions_ms", C.c_double),
                 ("backward_pass_ms", C.c_double), ("forward_pass_ms", C.c_double), ("fused_ms", C.c_double),
                 ("sweeps", C.c_int), ("fused_sweeps", C.c_int), ("launches", C.c_int), ("sweep_launches", C.c_int),
-                ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong)]
+                ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong),
+                ("host_naps", C.c_int), ("reserved", C.c_int)]
 
 
 class AltroError(RuntimeError):
@@ -187,6 +188,12 @@ class BatchSolver:
     def set_model(self, kind, params=()):
         p = _f64(list(params)) if len(params) else None
         self._call("set_model", C.c_int(kind), _dp(p), C.c_int(0 if p is None else p.size))
+
+    def set_knot_models(self, model_of_knot):
+        """Problem::SetDynamics(model, k) with models that differ along the horizon (problem.hpp:155-166): index of knot
+        k's model (k = 0 .. N-1) in the user source's ALTRO_USER_MODELS list."""
+        km = np.ascontiguousarray(model_of_knot, dtype=np.int32)
+        self._call("set_knot_models", km.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(km.size))
 
     def set_uniform_step(self, h):
         self._call("set_uniform_step", C.c_float(np.float32(h)))

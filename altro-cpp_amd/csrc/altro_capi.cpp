@@ -35,7 +35,7 @@ using namespace altro_hip;
 
 extern "C" int altro_chain_claim(int device, int delta);
 
-#define ALTRO_USER_PLUGIN_ABI_HOST 5  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
+#define ALTRO_USER_PLUGIN_ABI_HOST 6  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -137,9 +137,10 @@ std::string SafeName(const char* name) {
 }
 
 // FunctionBase::CheckJacobian (functionbase.cpp:35-73) on the device: 64 points uniform in [-1, 1]^(n+m)
-// (VectorXd::Random), central differences with 1e-6, tolerance kDefaultTolerance = 1e-4 (functionbase.hpp:86) on the error
-// relative to max(1, ||J||): the reference's forward-difference helper is an opt-in test utility, this check gates
-// registration and must not reject a correct Jacobian of a model with large second derivatives
+// (VectorXd::Random), central differences with 1e-6, tolerance kDefaultTolerance = 1e-4 (functionbase.hpp:86) on every
+// ENTRY's error relative to max(1, |J_ij|): the reference's forward-difference helper is an opt-in test utility, this
+// check gates registration and must not reject a correct Jacobian of a model with large second derivatives -- nor let a
+// wrong entry of order one hide behind a large norm of the whole matrix
 altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) {
   if (e.checked) return ALTRO_OK;
   const int samples = 64, nm = e.n + e.m;
@@ -154,7 +155,7 @@ altro_status CheckUserJacobian(UserModelEntry& e, int device, std::string* err) 
   }
   if (!(max_err < 1e-4)) {
     char buf[256];
-    snprintf(buf, sizeof(buf), "user model '%s': jac() does not match finite differences of f(): ||J_fd - J|| / max(1, ||J||) = %.3g >= 1e-4 "
+    snprintf(buf, sizeof(buf), "user model '%s': jac() does not match finite differences of f(): max_ij |J_fd - J|_ij / max(1, |J_ij|) = %.3g >= 1e-4 "
              "(FunctionBase::CheckJacobian)", e.name.c_str(), max_err);
     *err = buf;
     return ALTRO_INVALID_ARG;
@@ -232,6 +233,12 @@ altro_status altro_create(const altro_desc* desc, altro_handle* out) {
 }
 
 void altro_destroy(altro_handle h) { delete h; }
+
+altro_status altro_get_desc(altro_handle h, altro_desc* out) {
+  if (!h || !out) return ALTRO_INVALID_ARG;
+  *out = h->spec.desc;
+  return ALTRO_OK;
+}
 
 const char* altro_last_error(altro_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -418,7 +425,16 @@ altro_status altro_register_model_source(const char* name, const char* source, i
     args.push_back(tmp);
     args.push_back(src);
     const int rc = RunTool(args, log);
-    if ((rc != 0 && !(rc == -1 && access(tmp.c_str(), R_OK) == 0)) || rename(tmp.c_str(), so.c_str()) != 0) {
+    // (rc == -1 with a result file: waitpid failed because the host application reaps its children itself -- the exit
+    //  code is unknown, so the file must prove itself before it gets the cached name: it loads and carries this hash)
+    bool tmp_ok = rc == 0;
+    if (rc == -1 && access(tmp.c_str(), R_OK) == 0) {
+      if (void* probe = dlopen(tmp.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+        tmp_ok = embedded_hash_ok(probe);
+        dlclose(probe);
+      }
+    }
+    if (!tmp_ok || rename(tmp.c_str(), so.c_str()) != 0) {
       std::string out;
       ReadFile(log, &out);
       err = "compiling the user model '" + safe + "' failed:\n" + Tail(out, 1500);
@@ -489,6 +505,21 @@ altro_status altro_set_model(altro_handle h, int kind, const double* params, int
   if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
   h->spec.model_kind = kind;
   h->spec.dof = (kind == ALTRO_MODEL_TRIPLE_INTEGRATOR && params && nparams > 0) ? (int)params[0] : 0;
+  return ALTRO_OK;
+}
+altro_status altro_set_knot_models(altro_handle h, const int* model_of_knot, int count) {
+  if (!h || !model_of_knot) return ALTRO_INVALID_ARG;
+  if (DefChanged(h) != ALTRO_OK) return ALTRO_NOT_READY;
+  if (count != h->spec.desc.N) {
+    h->err = "altro_set_knot_models: expected N = " + std::to_string(h->spec.desc.N) + " indices (the terminal knot has no dynamics)";
+    return ALTRO_INVALID_ARG;
+  }
+  for (int k = 0; k < count; ++k)
+    if (model_of_knot[k] < 0) {
+      h->err = "altro_set_knot_models: index " + std::to_string(k) + " is negative";
+      return ALTRO_INVALID_ARG;
+    }
+  h->spec.knot_model.assign(model_of_knot, model_of_knot + count);  // (checked against the model's list at the upload)
   return ALTRO_OK;
 }
 altro_status altro_set_uniform_step(altro_handle h, float hstep) {

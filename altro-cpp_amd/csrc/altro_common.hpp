@@ -41,6 +41,9 @@ struct ProblemSpec {
   // Trajectory::SetStep(k, h) / SetTime(k, t) (trajectory.hpp:119-120): per-knot steps hk[N] and times tk[N + 1]; empty =
   // the uniform step above with t_k = float(k) * h, t_N = h * N (trajectory.hpp:122-130)
   std::vector<float> hk, tk;
+  // Problem::SetDynamics(model, k) with different models along the horizon (problem.hpp:155-166): knot k uses model
+  // knot_model[k] of the user source's ALTRO_USER_MODELS list; empty = model 0 everywhere
+  std::vector<int> knot_model;
   std::vector<CostSpec> costs;
   std::vector<ConSpec> cons;
   std::vector<double> x0;  // [n] or [B][n]

@@ -261,6 +261,7 @@ struct DevArrays {
   // 179-180): nullptr for a uniform step and a time-invariant model (the hot kernels then use ProblemDesc::hstep);
   // set by altro_set_steps / altro_set_times or by a time-varying user model -- see Engine::knot_times_
   const float *hk, *tk;
+  const int* knot_model;  // model of the source's ALTRO_USER_MODELS list that knot k uses (Problem::SetDynamics(model, k)); null: 0
 };
 // step and time of knot k (k wave-uniform where it matters: scalar loads)
 template <class T>
@@ -270,6 +271,10 @@ ALTRO_DEV T step_of(const DevArrays<T>& A, const ProblemDesc* pd, int k) {
 template <class T>
 ALTRO_DEV float time_of(const DevArrays<T>& A, int k) {
   return A.tk ? A.tk[k] : 0.0f;
+}
+template <class T>
+ALTRO_DEV int model_of(const DevArrays<T>& A, int k) {
+  return A.knot_model ? A.knot_model[k] : 0;
 }
 
 template <class T>
@@ -780,6 +785,105 @@ ALTRO_DEV void rk4_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f) 
   for (int e = 0; e < n * m; ++e) J[n * n + e] = ALTRO_SZ(sB[e]) ? T(0) : sB[e] / 6;
 }
 #undef ALTRO_SZ
+
+// -------------------------------------------------------------------------------------------------
+// What stands behind Problem::SetDynamics(model, k) (altro/problem/problem.hpp:155-166) for one knot: the reference
+// stores a problem::DiscreteDynamics per knot, which is either
+//   * DiscretizedModel<Model, RungeKutta4>   (discretized_model.hpp:24-65, integration.hpp:123-169) -- every built-in
+//     model and the default for a user model (f, jac);
+//   * DiscretizedModel<Model, ExplicitEuler> (integration.hpp:87-104): a user model that declares
+//     `static constexpr int integrator = 1` (or a source compiled with -D / #define ALTRO_USER_INTEGRATOR 1);
+//   * the caller's own DiscreteDynamics subclass (dynamics.hpp:148-187: Evaluate(x, u, t, h, xnext),
+//     Jacobian(x, u, t, h, jac)): a user model that declares `static constexpr bool discrete = true` and defines
+//     step(x, u, t, h, xnext) / step_jac(x, u, t, h, J) with 32-bit float t, h;
+// and may be a different one on every knot: a source that lists several models of equal dimensions
+// (#define ALTRO_USER_MODELS A, B -> struct with `using Models = UserTypeList<A, B>`) is dispatched on the knot's index
+// (DevArrays::knot_model, altro_set_knot_models), each arm being any of the three kinds.
+// -------------------------------------------------------------------------------------------------
+#ifndef ALTRO_USER_INTEGRATOR
+#define ALTRO_USER_INTEGRATOR 0
+#endif
+constexpr int kIntegratorRk4 = 0, kIntegratorEuler = 1;
+template <class M, class = void>
+struct model_discrete : std::false_type {};
+template <class M>
+struct model_discrete<M, std::void_t<decltype(M::discrete)>> : std::integral_constant<bool, M::discrete> {};
+template <class M, class = void>
+struct model_integrator : std::integral_constant<int, ALTRO_USER_INTEGRATOR> {};
+template <class M>
+struct model_integrator<M, std::void_t<decltype(M::integrator)>> : std::integral_constant<int, M::integrator> {};
+template <class M, class = void>
+struct model_list {
+  using type = UserTypeList<M>;
+  static constexpr bool is_list = false;
+};
+template <class M>
+struct model_list<M, std::void_t<typename M::Models>> {
+  using type = typename M::Models;
+  static constexpr bool is_list = true;
+};
+// true when knots cannot share one (step, time, model): the engine then runs its general kernels (SetKnotTimes)
+template <class L>
+struct list_knot_path;
+template <class... Ms>
+struct list_knot_path<UserTypeList<Ms...>> {
+  static constexpr bool value = ((model_time_varying<Ms>::value || model_discrete<Ms>::value) || ...);
+};
+template <class M>
+struct model_knot_path {
+  static constexpr bool value = model_list<M>::is_list || list_knot_path<typename model_list<M>::type>::value;
+};
+
+// one model S, one step: x_{k+1} = F(x_k, u_k, t_k, h_k)
+template <class T, class S>
+ALTRO_DEV void single_step(const T* x, const T* u, T hh, T* xn, float t) {
+  if constexpr (model_discrete<S>::value) {
+    S::step(x, u, t, (float)hh, xn);  // DiscreteDynamics::Evaluate (hh is the knot's 32-bit step, promoted: the narrowing is exact)
+  } else if constexpr (model_integrator<S>::value == kIntegratorEuler) {
+    // ExplicitEuler::Integrate (integration.hpp:90-94): Evaluate(x, u, t, xnext); xnext = x + xnext * h
+    constexpr int n = S::n;
+    T xd[n];
+    model_f<T, S>(x, u, t, xd);
+#pragma unroll
+    for (int i = 0; i < n; ++i) xn[i] = x[i] + xd[i] * hh;
+  } else {
+    rk4_step<T, S>(x, u, hh, xn, t);
+  }
+}
+// ... and its Jacobian [A | B], n x (n + m) column-major
+template <class T, class S>
+ALTRO_DEV void single_jacobian(const T* x, const T* u, T hh, T* J, float t) {
+  if constexpr (model_discrete<S>::value) {
+    S::step_jac(x, u, t, (float)hh, J);  // DiscreteDynamics::Jacobian
+  } else if constexpr (model_integrator<S>::value == kIntegratorEuler) {
+    // ExplicitEuler::Jacobian (integration.hpp:95-101): jac = Identity(n, n + m) + jac * h
+    constexpr int n = S::n, m = S::m;
+    model_jac<T, S>(x, u, t, J);
+#pragma unroll
+    for (int j = 0; j < n + m; ++j)
+#pragma unroll
+      for (int i = 0; i < n; ++i) J[i + j * n] = (i == j ? T(1) : T(0)) + J[i + j * n] * hh;
+  } else {
+    rk4_jacobian<T, S>(x, u, hh, J, t);
+  }
+}
+// the discrete dynamics of knot k of model M (`which` = the knot's index into M's list of models; 0 without a list)
+template <class T, class M>
+ALTRO_DEV void discrete_step(const T* x, const T* u, T hh, T* xn, float t = 0.0f, int which = 0) {
+  if constexpr (model_list<M>::is_list) {
+    UserDispatch<typename model_list<M>::type>::call(which, [&](auto tag) { single_step<T, typename decltype(tag)::type>(x, u, hh, xn, t); });
+  } else {
+    single_step<T, M>(x, u, hh, xn, t);
+  }
+}
+template <class T, class M>
+ALTRO_DEV void discrete_jacobian(const T* x, const T* u, T hh, T* J, float t = 0.0f, int which = 0) {
+  if constexpr (model_list<M>::is_list) {
+    UserDispatch<typename model_list<M>::type>::call(which, [&](auto tag) { single_jacobian<T, typename decltype(tag)::type>(x, u, hh, J, t); });
+  } else {
+    single_jacobian<T, M>(x, u, hh, J, t);
+  }
+}
 
 // -------------------------------------------------------------------------------------------------
 // Per-knot problem access

@@ -18,6 +18,7 @@
 #include <limits>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "altro_kernels.hpp"
@@ -79,6 +80,7 @@ class Engine final : public EngineBase {
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
+    ALTRO_HIP_CHECK(hipEventCreateWithFlags(&tail_ev_, hipEventDisableTiming | hipEventBlockingSync));
     cur_ = stream_;
     ALTRO_HIP_CHECK(hipDeviceGetAttribute(&num_cus_, hipDeviceAttributeMultiprocessorCount, desc_.device_id));
     // (round 3, tail iteration at 39 us: hand-over at 1x .. 8x the CUs measured, 2x .. 4x best by ~1 %: workgroups beyond
@@ -156,7 +158,10 @@ class Engine final : public EngineBase {
     altro_status st = Sync();
     if (st != ALTRO_OK) return st;
     const bool per_knot = !s.hk.empty() || kTimeVarying;
-    if (!per_knot) {
+    // (a time-varying model whose trajectory has no step yet -- the facade uploads the problem before it hands the
+    //  trajectory over -- stays without knot times: StepOk() refuses every integrating call until altro_set_uniform_step /
+    //  altro_set_steps come, and both end up here again)
+    if (!per_knot || (s.hk.empty() && !(s.hstep > 0.0f))) {
       A_.hk = nullptr;
       A_.tk = nullptr;
       return ALTRO_OK;
@@ -621,6 +626,25 @@ class Engine final : public EngineBase {
     allocs_.push_back((void*)*p);
     return ALTRO_OK;
   }
+  // undo a (partial) UploadImpl: device buffers, chain streams and the chain booking go; the engine's own stream stays
+  void DropUpload() {
+    uploaded_ = false;
+    if (hipSetDevice(desc_.device_id) != hipSuccess) return;
+    hipStreamSynchronize(stream_);
+    for (void* p : allocs_) hipFree(p);
+    allocs_.clear();
+    d_hk_ = d_tk_ = nullptr;
+    if (counted_chained_) ChainClaim(desc_.device_id, -1);
+    counted_chained_ = false;
+    for (int c = 1; c < kMaxChains; ++c) {
+      if (chain_stream_[c]) hipStreamDestroy(chain_stream_[c]);
+      if (chain_ev_[c]) hipEventDestroy(chain_ev_[c]);
+      chain_stream_[c] = nullptr;
+      chain_ev_[c] = nullptr;
+    }
+    chains_ = 1;
+    std::memset(&A_, 0, sizeof(A_));
+  }
   void Release() {
     if (hipSetDevice(desc_.device_id) != hipSuccess) return;
     for (void* p : allocs_) hipFree(p);
@@ -642,6 +666,7 @@ class Engine final : public EngineBase {
       chain_ev_[c] = nullptr;
     }
     if (start_ev_) hipEventDestroy(start_ev_);
+    if (tail_ev_) hipEventDestroy(tail_ev_);
     if (stream2_) hipStreamDestroy(stream2_);
     if (spec_ev_) hipEventDestroy(spec_ev_);
     if (stream_) hipStreamDestroy(stream_);
@@ -1315,17 +1340,40 @@ class Engine final : public EngineBase {
         }
       }
     }
+    if (!s.knot_model.empty()) {
+      // per-knot models (Problem::SetDynamics(model, k), problem.hpp:155-166): indices into the source's ALTRO_USER_MODELS
+      bool any = false;
+      for (int k = 0; k < N_; ++k) {
+        const int w = s.knot_model[k];
+        if (w < 0 || w >= kModelCount) {
+          err_ = "altro_set_knot_models: knot " + std::to_string(k) + " asks for model " + std::to_string(w) + ", this handle's model " +
+                 (kModelCount > 1 ? "source lists " + std::to_string(kModelCount) + " models (ALTRO_USER_MODELS)"
+                                  : std::string("is a single model (a user source with #define ALTRO_USER_MODELS A, B, ... holds several)"));
+          return ALTRO_INVALID_ARG;
+        }
+        any = any || w != 0;
+      }
+      if (any) {
+        int* dkm = nullptr;
+        ALTRO_ALLOC(dkm, (size_t)N_ + 1);
+        std::vector<int> km(s.knot_model.begin(), s.knot_model.begin() + N_);
+        km.push_back(0);
+        ALTRO_HIP_CHECK(CopySync(dkm, km.data(), km.size() * sizeof(int), hipMemcpyHostToDevice));
+        A_.knot_model = dkm;
+      }
+    }
     uploaded_ = true;
     // penalties start at one (constraint_values.hpp:44); an earlier SetPenalty overrides
     hipLaunchKernelGGL(k_set_rows<T>, GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 0, 1,
                        T(s.penalty >= 0 ? s.penalty : 1.0));
     altro_status st = Sync();
-    if (st != ALTRO_OK) return st;
-    st = SetInitialStateImpl(s);
-    if (st != ALTRO_OK) return st;
-    st = SetKnotTimesImpl(s);
-    if (st != ALTRO_OK) return st;
-    return SetTrajectoryImpl(s);
+    if (st == ALTRO_OK) st = SetInitialStateImpl(s);
+    if (st == ALTRO_OK) st = SetKnotTimesImpl(s);
+    if (st == ALTRO_OK) st = SetTrajectoryImpl(s);
+    // (a failed upload leaves the engine as it was before it: the C-ABI keeps the handle "not uploaded" and the next
+    //  call uploads again instead of meeting "problem definition changed")
+    if (st != ALTRO_OK) DropUpload();
+    return st;
 #undef ALTRO_ALLOC
   }
 
@@ -1491,7 +1539,14 @@ class Engine final : public EngineBase {
     }
     // Every chain: enqueue sweep s, then wait for the count sweep s-1 left (published by sweep s, which is already
     // enqueued), then enqueue sweep s+1 ... -- the chains polled in turn, none of them ever blocking the others.
-    unsigned spins = 0;
+    // The host waits for words the device writes into pinned memory.  It is ONE SWEEP AHEAD -- the sweep it is about to
+    // enqueue only has to be in the queue before the one in flight ends, a hundred microseconds or more away -- so it
+    // need not burn a core on the poll: a short spin (the word usually lands within microseconds of a neighbouring
+    // chain's), then naps of ~50 us (eight ranks of a node, or the worker threads of libaltro_group.so, share the
+    // container's CPU quota with RCCL's proxy threads).  A small batch -- the latency path -- keeps spinning, and so
+    // does ALTRO_HIP_HOST_WAIT=spin.
+    const bool nap = host_wait_backoff_ && B_ >= kHostNapMinBatch;
+    unsigned spins = 0, naps = 0;
     for (;;) {
       bool any = false, progressed = false;
       for (int c = 0; c < C; ++c) {
@@ -1522,9 +1577,19 @@ class Engine final : public EngineBase {
         ch.waiting = true;
       }
       if (!any) break;
+      bool check_streams = false;
       if (progressed) {
         spins = 0;
-      } else if ((++spins & 0x3ff) == 0) {
+        naps = 0;
+      } else if (nap && spins >= kHostSpinsBeforeNap) {
+        std::this_thread::sleep_for(std::chrono::microseconds(20));  // (timer slack makes it ~70 us)
+        timing_.host_naps += 1;
+        check_streams = (++naps & 0xf) == 0;
+      } else {
+        __builtin_ia32_pause();
+        check_streams = (++spins & 0x3ff) == 0 && !nap;
+      }
+      if (check_streams) {
         for (int c = 0; c < C; ++c) {
           Chain& ch = chain[c];
           if (ch.done || ch.tail || !ch.waiting) continue;
@@ -1627,6 +1692,12 @@ class Engine final : public EngineBase {
         timing_.launches += 1;
       }
     }
+    if (nap && tail_ev_) {
+      // the persistent launch runs for milliseconds: wait for it on an event that blocks in the driver (interrupt) instead
+      // of spinning in hipStreamSynchronize
+      ALTRO_HIP_CHECK(hipEventRecord(tail_ev_, stream_));
+      ALTRO_HIP_CHECK(hipEventSynchronize(tail_ev_));
+    }
     for (int c = 1; c < C; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(chain[c].st));
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
     if (spec_helper_running_) {
@@ -1674,7 +1745,9 @@ class Engine final : public EngineBase {
   }
 
   static constexpr int kNumScalarT = 15, kNumScalarI = 7;
-  static constexpr bool kTimeVarying = model_time_varying<M>::value;
+  // (time-varying dynamics, user discrete dynamics and per-knot model lists: every knot has its own (step, time, model))
+  static constexpr bool kTimeVarying = model_knot_path<M>::value;
+  static constexpr int kModelCount = model_list<M>::type::size;
   float *d_hk_ = nullptr, *d_tk_ = nullptr;  // per-knot steps / times (SetKnotTimes), owned through allocs_
   altro_desc desc_;
   int B_ = 0, Bp_ = 0, N_ = 0;
@@ -1734,6 +1807,14 @@ class Engine final : public EngineBase {
   hipStream_t chain_stream_[kMaxChains] = {};
   hipEvent_t chain_ev_[kMaxChains] = {};
   hipEvent_t start_ev_ = nullptr;
+  hipEvent_t tail_ev_ = nullptr;  // blocking-sync event behind the last launch of a large batch's solve
+  // host side of the sweep loop: spin briefly, then nap (see Solve); ALTRO_HIP_HOST_WAIT=spin restores the pure spin
+  static constexpr int kHostNapMinBatch = 256;
+  static constexpr unsigned kHostSpinsBeforeNap = 400;  // ~10 us of pause instructions
+  bool host_wait_backoff_ = [] {
+    const char* e = std::getenv("ALTRO_HIP_HOST_WAIT");
+    return !(e && std::string(e) == "spin");
+  }();
   int* d_iota_ = nullptr;    // 0, 1, 2, ...: the active list of a chain's first sweep
   int* d_merged_ = nullptr;  // the lists of all chains, concatenated for the persistent kernel
   hipStream_t cur_ = nullptr;  // the stream the launch helpers enqueue on (a chain's, otherwise the engine's)

@@ -18,6 +18,7 @@ struct altro_group_s {
   std::vector<ncclComm_t> comm;
   std::vector<hipStream_t> stream;
   std::vector<altro_handle> handle;
+  std::vector<altro_desc> desc;  // what each attached handle says about itself (altro_get_desc)
   std::vector<int> batch;
   std::vector<double*> d_send;  // [slot][4] records of the part, padded to the largest part
   std::vector<double*> d_recv;  // [ndev][slot][4]
@@ -112,6 +113,7 @@ altro_status altro_group_create(const int* device_ids, int ndev, altro_group* ou
   g->comm.assign(ndev, nullptr);
   g->stream.assign(ndev, nullptr);
   g->handle.assign(ndev, nullptr);
+  g->desc.assign(ndev, altro_desc{});
   g->batch.assign(ndev, 0);
   g->d_send.assign(ndev, nullptr);
   g->d_recv.assign(ndev, nullptr);
@@ -149,10 +151,35 @@ int altro_group_total(altro_group g) {
   return t;
 }
 
+// The gather buffers are sized from what the HANDLE says (altro_get_desc): altro_pack_results_device and
+// altro_pack_trajectory_device write the handle's own batch x (N, n, m), so a caller-supplied size that disagrees
+// would let them write past the group's buffers.
 altro_status altro_group_attach(altro_group g, int part, altro_handle h, int batch) {
   if (!g || !h || part < 0 || part >= (int)g->dev.size() || batch < 1) return ALTRO_INVALID_ARG;
+  altro_desc d{};
+  if (altro_get_desc(h, &d) != ALTRO_OK) return ALTRO_INVALID_ARG;
+  if (d.batch != batch) {
+    g->err = "altro_group_attach: part " + std::to_string(part) + " was given batch " + std::to_string(batch) +
+             " but its handle was created with batch " + std::to_string(d.batch);
+    return ALTRO_INVALID_ARG;
+  }
+  if (d.device_id != g->dev[part]) {
+    g->err = "altro_group_attach: the handle of part " + std::to_string(part) + " lives on device " + std::to_string(d.device_id) +
+             ", the part on device " + std::to_string(g->dev[part]);
+    return ALTRO_INVALID_ARG;
+  }
+  for (size_t i = 0; i < g->handle.size(); ++i) {
+    if ((int)i == part || !g->handle[i]) continue;
+    if (g->desc[i].n != d.n || g->desc[i].m != d.m || g->desc[i].N != d.N) {
+      g->err = "altro_group_attach: part " + std::to_string(part) + " has (n, m, N) = (" + std::to_string(d.n) + ", " +
+               std::to_string(d.m) + ", " + std::to_string(d.N) + "), part " + std::to_string(i) + " (" +
+               std::to_string(g->desc[i].n) + ", " + std::to_string(g->desc[i].m) + ", " + std::to_string(g->desc[i].N) + ")";
+      return ALTRO_INVALID_ARG;
+    }
+  }
   g->handle[part] = h;
-  g->batch[part] = batch;
+  g->batch[part] = d.batch;
+  g->desc[part] = d;
   return ALTRO_OK;
 }
 
@@ -192,6 +219,13 @@ altro_status altro_group_gather_trajectories(altro_group g, int n, int m, int N)
     if (!g->handle[i]) {
       g->err = "part " + std::to_string(i) + " has no handle attached (altro_group_attach)";
       return ALTRO_NOT_READY;
+    }
+    // (the buffers below are sized from n, m, N; the pack kernels write the handle's own dimensions)
+    if (g->desc[i].n != n || g->desc[i].m != m || g->desc[i].N != N) {
+      g->err = "altro_group_gather_trajectories: (n, m, N) = (" + std::to_string(n) + ", " + std::to_string(m) + ", " +
+               std::to_string(N) + ") but the handle of part " + std::to_string(i) + " has (" + std::to_string(g->desc[i].n) +
+               ", " + std::to_string(g->desc[i].m) + ", " + std::to_string(g->desc[i].N) + ")";
+      return ALTRO_INVALID_ARG;
     }
     slot = std::max(slot, g->batch[i]);
   }
@@ -300,7 +334,8 @@ altro_status altro_group_solve_al(altro_group g) {
       done[i] = 1;
       --left;
     }
-    if (left > 0) std::this_thread::yield();
+    // (a sleeping poll: the parts' worker threads and the device do the work; this thread only stamps completion times)
+    if (left > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
   if (first != ALTRO_OK) return first;
   return altro_group_gather(g);

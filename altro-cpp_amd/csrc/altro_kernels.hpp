@@ -44,6 +44,7 @@ constexpr int kFwdWaves = 3;  // k_forward2 / k_sweep_fused: rollout wave, cost 
 #define ALTRO_SYNC_FUSED 4
 #endif
 constexpr int kSyncFused = ALTRO_SYNC_FUSED;
+constexpr int kEAheadToErrWord = -7;      // kSyErr - kSyEAhead0 (FwdSyncWord, asserted there)
 constexpr int kFwdSpinLimit = 1 << 22;   // polls of an LDS sequence word (~0.1 us each) before a wave gives up
 // Debugging aid (ALTRO_HIP_DEBUG_POISON): fills the LDS of the CU it lands on with a pattern, so that a kernel that reads
 // LDS it has not written computes with the pattern instead of with whatever the previous kernel happened to leave there.
@@ -139,7 +140,7 @@ ALTRO_DEV T expansion_body(const DevArrays<T>& A, const ProblemDesc* __restrict_
   const T J = knot_cost_expansion<T, n, m>(C, pd, kc, rb, xr, ur, E + R::oLx, E + R::oLu, E + R::oLxx, E + R::oLxu,
                                            E + R::oLuu);
   A.costs[(unsigned)k * Bp + (unsigned)b] = J;
-  if (k < N) rk4_jacobian<T, M>(xr, ur, step_of(A, pd, k), E + R::oAB, time_of(A, k));
+  if (k < N) discrete_jacobian<T, M>(xr, ur, step_of(A, pd, k), E + R::oAB, time_of(A, k), model_of(A, k));
   store_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP((RS*)A.EXP, k, RR::EP), E);
   return J;
 }
@@ -1257,7 +1258,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(DevArrays<T> A, const Proble
   for (int k = 0; k < A.N; ++k) {
     store_rec<T, R::nP>(RECP(A.X, k, R::nP), x);
     load_rec<T, R::mP>(RECP(A.U, k, R::mP), u);
-    rk4_step<T, M>(x, u, step_of(A, pd, k), xn, time_of(A, k));
+    discrete_step<T, M>(x, u, step_of(A, pd, k), xn, time_of(A, k), model_of(A, k));
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = xn[i];
   }
@@ -1700,9 +1701,16 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
       //  the inner solve ends, but the records they leave in memory must be this iteration's, not a mixture: wait
       //  until they are through.  Bounded like every poll of the kernel.)
       if (eahead_words && !accepted) {
-        for (int w = 0; w < eahead_waves; ++w)
-          for (int tries = 0; tries < kFwdSpinLimit; ++tries)
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(eahead_words + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= eahead_tag) break;
+        bool seen = true;
+        for (int w = 0; w < eahead_waves; ++w) {
+          bool ok = false;
+          for (int tries = 0; tries < kFwdSpinLimit && !ok; ++tries)
+            ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load(eahead_words + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= eahead_tag;
+          seen = seen && ok;
+        }
+        // (gave up: the sweeps below would rewrite multipliers that the expansion waves still read -- the launch reports
+        //  it like every other poll that times out, FwdSync::wait_for)
+        if (!seen) __hip_atomic_store(const_cast<int*>(eahead_words) + kEAheadToErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       // AugmentedLagrangianiLQR: UpdateDuals, UpdateConvergenceStatistics, IsDone, UpdatePenalties
       // (al_solver.hpp:313-401); each lane sweeps the rows of knots t, t+20, ...
@@ -1908,7 +1916,7 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
 #pragma unroll
         for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
       }
-      rk4_step<T, M>(xb, ub, A.hk ? T(A.hk[k]) : hh, xn, time_of(A, k));  // (per-knot steps / times: this kernel only)
+      discrete_step<T, M>(xb, ub, A.hk ? T(A.hk[k]) : hh, xn, time_of(A, k), model_of(A, k));  // (per-knot steps / times: this kernel only)
       if (check_bounds) {
         // ||x||_2 > state_max  <=>  ||x||^2 > state_max^2 (ilqr.hpp:484-495), no sqrt needed
         T sx = T(0), su = T(0);
@@ -2269,6 +2277,7 @@ constexpr int kFwdSeqStride = 1 << 12;   // > stretches of one forward pass (N /
 enum FwdSyncWord { kSyPub = 0, kSyErr = 1, kSyCons0 = 2, kSyCons1 = 3, kSyA = 4, kSyS = 5, kSyV0 = 6, kSyV1 = 7,
                    kSyEAhead0 = 8,  // + wave index 0..2: iteration whose expansions-ahead that wave has finished (all modes)
                    kSyWords = 16 };
+static_assert(kSyErr - kSyEAhead0 == kEAheadToErrWord, "forward_phase3 raises the error word relative to the E-ahead words");
 template <bool SOFT>
 struct FwdSync {
   int* w;    // kSyWords ints in LDS, 8-byte aligned (SOFT only)
@@ -2976,7 +2985,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if ((k % M::kTrigResync) == 0) sincos_(xb[2], &trig_s, &trig_c);
         M::template rk4_fused_sc<T, false>(xb, ub, hh, xn, trig_s, trig_c);
       } else {
-        rk4_step<T, M>(xb, ub, hh, xn);
+        discrete_step<T, M>(xb, ub, hh, xn);
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
@@ -3283,7 +3292,7 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
                                                E + R::oLuu);
       A.costs[(unsigned)k * Bp + (unsigned)b] = J;
       sCost[k] = J;
-      if (k < N) rk4_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
+      if (k < N) discrete_jacobian<T, M>(xr, ur, T(pd->hstep), E + R::oAB);
       using RS = rec_scalar_t<T, M>;
       using RR = Rec<RS, n, m>;
       store_rec_as<T, RS, R::EP, RR::EP, R::eE>(RECP((RS*)A.EXP, k, RR::EP), E);

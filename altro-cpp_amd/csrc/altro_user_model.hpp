@@ -33,21 +33,56 @@
 
 namespace altro_hip {
 
-#define ALTRO_USER_PLUGIN_ABI 5  // bump when EngineBase or the entry points below change
+#define ALTRO_USER_PLUGIN_ABI 6  // bump when EngineBase or the entry points below change
 
-struct UserM : altro_user::UserModel {
+// a user's model struct with the flags the engine asks every model for (no hand-fused RK4 / carried trigonometry)
+template <class S>
+struct UserSub : S {
   static constexpr bool kHasFusedRk4 = false;
   static constexpr bool kHasCarriedTrig = false;
   static constexpr bool kHasFusedJacobian = false;
 };
+#if defined(ALTRO_USER_MODELS)
+// SEVERAL models of equal dimensions, one per knot (Problem::SetDynamics(model, k), problem.hpp:155-166, 187-191): the
+// index of a model in the list is what altro_set_knot_models assigns to a knot.  Each may be continuous (RK4 or
+// explicit Euler) or discrete, time-varying or not (altro_device.hpp: discrete_step / discrete_jacobian).
+namespace user_models_ {
+using namespace ::altro_user;
+template <class... Ms>
+struct Wrap {
+  using type = UserTypeList<UserSub<Ms>...>;
+};
+template <class M0, class... Ms>
+struct First {
+  using type = M0;
+  static constexpr bool same_dims = ((Ms::n == M0::n && Ms::m == M0::m) && ...);
+};
+using List = Wrap<ALTRO_USER_MODELS>::type;
+using Head = First<ALTRO_USER_MODELS>;
+}  // namespace user_models_
+static_assert(user_models_::Head::same_dims, "the models of ALTRO_USER_MODELS must share n and m");
+struct UserM {
+  using Models = user_models_::List;
+  static constexpr int n = user_models_::Head::type::n, m = user_models_::Head::type::m;
+  static constexpr bool kHasFusedRk4 = false;
+  static constexpr bool kHasCarriedTrig = false;
+  static constexpr bool kHasFusedJacobian = false;
+};
+#else
+struct UserM : UserSub<altro_user::UserModel> {};
+#endif
+using UserModelTypes = model_list<UserM>::type;
 
 // FunctionBase::CheckJacobian (functionbase.cpp:42-73) for the continuous dynamics, one sample point per thread:
-// finite differences with step eps against the user's Jacobian; err[s] = Frobenius norm of the difference
-// (MatrixComparison, functionbase.cpp:15-30) RELATIVE to max(1, ||J||_F).  The reference's helper differences forward
+// finite differences with step eps against the user's Jacobian; err[s] = the largest ENTRY-WISE error
+// |J_fd - J|_ij / max(1, |J_ij|) (an absolute 1e-4 for entries of order one, as MatrixComparison's tolerance,
+// functionbase.cpp:15-30, relative for large ones: a norm-wise relative error would let a wrong O(1) entry through
+// once the Jacobian as a whole is large).  The reference's helper differences forward
 // (utils::FiniteDiffJacobian, derivative_checker.hpp:10-40) and is an opt-in test utility that returns a bool; here the
 // check gates registration, so it must not reject a CORRECT Jacobian: central differences (truncation error of order
 // eps^2 times the third derivative instead of eps times the second: a model with large second derivatives passes)
 // and a relative tolerance.
+// A model with `discrete = true` (DiscreteDynamics) is checked the same way on step() / step_jac() with a step of 0.05.
 template <class M>
 __global__ void k_check_jacobian(const double* __restrict__ z, double* __restrict__ err, int samples, double eps) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -57,31 +92,36 @@ __global__ void k_check_jacobian(const double* __restrict__ z, double* __restric
 #pragma unroll
   for (int i = 0; i < nm; ++i) x[i] = z[(size_t)s * nm + i];
   const float t = 0.37f + 0.01f * (float)(s & 15);  // (a time-varying model is checked at a few knot times)
-  model_jac<double, M>(x, x + n, t, J);
-  double e2 = 0.0, j2 = 0.0;
+  constexpr float hcheck = 0.05f;
+  auto eval = [&](double* out) {
+    if constexpr (model_discrete<M>::value) M::step(x, x + n, t, hcheck, out);
+    else model_f<double, M>(x, x + n, t, out);
+  };
+  if constexpr (model_discrete<M>::value) M::step_jac(x, x + n, t, hcheck, J);
+  else model_jac<double, M>(x, x + n, t, J);
+  double emax = 0.0;
 #pragma unroll
   for (int j = 0; j < nm; ++j) {
     const double keep = x[j];
     x[j] = keep + eps;
-    model_f<double, M>(x, x + n, t, f1);
+    eval(f1);
     x[j] = keep - eps;
-    model_f<double, M>(x, x + n, t, f0);
+    eval(f0);
     x[j] = keep;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       const double d = (f1[i] - f0[i]) / (2.0 * eps) - J[i + j * n];
-      e2 += d * d;
-      j2 += J[i + j * n] * J[i + j * n];
+      emax = fmax(emax, fabs(d) / fmax(1.0, fabs(J[i + j * n])));
     }
   }
-  err[s] = sqrt(e2) / fmax(1.0, sqrt(j2));
+  err[s] = emax;
 }
 
 // ScalarFunction::CheckGradient, FunctionBase::CheckHessian (functionbase.cpp:75-125) for one of the user's cost types
 // and FunctionBase::CheckJacobian for one of the user's constraint types (indices into ALTRO_USER_COSTS /
 // ALTRO_USER_CONSTRAINTS, -1: none), one sample (x, u, parameters) per thread, central differences:
-// err[3 s + 0] = ||fd(eval) - gradient||, [3 s + 1] = ||fd(gradient) - hessian||_F,
-// [3 s + 2] = ||fd(eval) - jacobian||_F, each relative to max(1, norm of the user's derivative).
+// err[3 s + 0] = max_j |fd(eval) - gradient|_j, [3 s + 1] = max_ij |fd(gradient) - hessian|_ij,
+// [3 s + 2] = max_rj |fd(eval) - jacobian|_rj, each entry relative to max(1, |the user's entry|).
 template <int n, int m>
 __global__ void k_check_functors(const double* __restrict__ z, const double* __restrict__ par_cost,
                                  const double* __restrict__ par_con, double* __restrict__ err, int samples, double eps,
@@ -105,7 +145,6 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
       for (int i = 0; i < nm; ++i)
         H[i + j * nm] = (i < n && j < n) ? hxx[i + j * n] : (i < n) ? hxu[i + (j - n) * n] : (j < n) ? hxu[j + (i - n) * n]
                                                                                                      : huu[(i - n) + (j - n) * m];
-    double g2 = 0.0, h2 = 0.0;
     for (int j = 0; j < nm; ++j) {  // central differences, see k_check_jacobian
       const double keep = x[j];
       x[j] = keep + eps;
@@ -117,16 +156,12 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
       F::gradient(x, x + n, par, gm, gm + n);
       x[j] = keep;
       const double dg = (Jp - Jm) / (2.0 * eps) - g0[j];
-      eg += dg * dg;
-      g2 += g0[j] * g0[j];
+      eg = fmax(eg, fabs(dg) / fmax(1.0, fabs(g0[j])));
       for (int i = 0; i < nm; ++i) {
         const double dh = (g1[i] - gm[i]) / (2.0 * eps) - H[i + j * nm];
-        eh += dh * dh;
-        h2 += H[i + j * nm] * H[i + j * nm];
+        eh = fmax(eh, fabs(dh) / fmax(1.0, fabs(H[i + j * nm])));
       }
     }
-    eg /= fmax(1.0, g2);
-    eh /= fmax(1.0, h2);
   });
   UserDispatch<UserConList>::call(con_type, [&](auto tag) {
     using F = typename decltype(tag)::type;
@@ -135,7 +170,6 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
     for (int i = 0; i < NP; ++i) par[i] = par_con[(size_t)s * NP + i];
     double c0[P], c1[P], J[P * nm];
     F::jacobian(x, x + n, par, J);
-    double j2 = 0.0;
     for (int j = 0; j < nm; ++j) {
       const double keep = x[j];
       x[j] = keep + eps;
@@ -145,15 +179,13 @@ __global__ void k_check_functors(const double* __restrict__ z, const double* __r
       x[j] = keep;
       for (int r = 0; r < P; ++r) {
         const double dj = (c1[r] - c0[r]) / (2.0 * eps) - J[r + j * P];
-        ej += dj * dj;
-        j2 += J[r + j * P] * J[r + j * P];
+        ej = fmax(ej, fabs(dj) / fmax(1.0, fabs(J[r + j * P])));
       }
     }
-    ej /= fmax(1.0, j2);
   });
-  err[3 * s + 0] = sqrt(eg);
-  err[3 * s + 1] = sqrt(eh);
-  err[3 * s + 2] = sqrt(ej);
+  err[3 * s + 0] = eg;
+  err[3 * s + 1] = eh;
+  err[3 * s + 2] = ej;
 }
 
 }  // namespace altro_hip
@@ -171,6 +203,8 @@ void altro_user_dims(int* n, int* m) {
   *n = altro_hip::UserM::n;
   *m = altro_hip::UserM::m;
 }
+// models the source defines (ALTRO_USER_MODELS; 1 without a list): the valid indices of altro_set_knot_models
+int altro_user_model_count() { return altro_hip::UserModelTypes::size; }
 
 // ALTRO_F64: everything fp64; ALTRO_F32: fp32 expansion / gain records (WithRec32<>), like the built-in models
 altro_hip::EngineBase* altro_user_make_engine(const altro_desc* d, std::string* err) {
@@ -267,15 +301,18 @@ int altro_user_check_jacobian(int device, const double* z_host, int samples, dou
   int rc = 0;
   std::vector<double> herr(samples, 0.0);
   if (hipMemcpy(dz, z_host, (size_t)samples * nm * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = 3;
-  if (!rc) {
-    hipLaunchKernelGGL((k_check_jacobian<UserM>), dim3((samples + 63) / 64), dim3(64), 0, nullptr, dz, derr, samples, eps);
+  double mx = 0.0;
+  for (int which = 0; !rc && which < UserModelTypes::size; ++which) {  // every model of the source (one without a list)
+    UserDispatch<UserModelTypes>::call(which, [&](auto tag) {
+      using S = typename decltype(tag)::type;
+      hipLaunchKernelGGL((k_check_jacobian<S>), dim3((samples + 63) / 64), dim3(64), 0, nullptr, dz, derr, samples, eps);
+    });
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = 4;
+    if (!rc && hipMemcpy(herr.data(), derr, (size_t)samples * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
+    for (double e : herr) mx = (e > mx || e != e) ? e : mx;
   }
-  if (!rc && hipMemcpy(herr.data(), derr, (size_t)samples * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 3;
   hipFree(dz);
   hipFree(derr);
-  double mx = 0.0;
-  for (double e : herr) mx = (e > mx || e != e) ? e : mx;
   *max_err = mx;
   return rc;
 }

@@ -175,6 +175,52 @@ def cartpole_move(make, model_kind, batch=1, N=60, dtype=F64, goal=None, **kw):
     return s
 
 
+def cartpole_steps(make, model_kind, knot_models, batch=1, N=60, dtype=F64, goal=None, **kw):
+    """The cart-pole move with a DIFFERENT discrete dynamics per knot (tests/models/cartpole_steps.hpp: 0 RK4, 1 explicit
+    Euler, 2 the user's own discrete map) -- Problem::SetDynamics(model, k), problem.hpp:155-166.  ``knot_models``: [N]
+    indices into the source's ALTRO_USER_MODELS list, or None (every knot model 0)."""
+    n, m = 4, 1
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.05)
+    hd = float(h)
+    goal = np.full(batch, 1.0) if goal is None else np.broadcast_to(np.asarray(goal, dtype=np.float64), (batch,))
+    xf = np.zeros((batch, n))
+    xf[:, 0] = goal
+    s.set_model(model_kind)
+    if knot_models is not None:
+        s.set_knot_models(knot_models)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, np.eye(n) * (1e-1 * hd), np.eye(m) * (1e-2 * hd), xf, np.zeros(m))
+    s.set_lqr_cost(N, N + 1, np.eye(n) * 100.0, np.zeros((m, m)), xf, np.zeros(m))
+    s.add_control_bound(0, N, [-3.0], [3.0])
+    s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
+def pendulum_swing(make, model_kind, batch=1, N=80, dtype=F64, goal=None, **kw):
+    """tests/models/pendulum_discrete.hpp (a user model that is only a DiscreteDynamics): bring the damped pendulum from
+    rest at theta = 0 to theta = goal and hold it there (n = 2, m = 1), torque bounded by +-6."""
+    n, m = 2, 1
+    s = make(n, m, N, batch, dtype)
+    h = np.float32(0.04)
+    hd = float(h)
+    goal = np.full(batch, 0.8) if goal is None else np.broadcast_to(np.asarray(goal, dtype=np.float64), (batch,))
+    xf = np.zeros((batch, n))
+    xf[:, 0] = goal
+    uf = (9.81 * np.sin(goal)).reshape(batch, 1)  # the torque that holds the pendulum at the goal
+    s.set_model(model_kind)
+    s.set_uniform_step(h)
+    s.set_lqr_cost(0, N, np.eye(n) * (1.0 * hd), np.eye(m) * (1e-2 * hd), xf, uf)
+    s.set_lqr_cost(N, N + 1, np.eye(n) * 100.0, np.zeros((m, m)), xf, uf)
+    s.add_control_bound(0, N, [-6.0], [6.0])
+    s.add_constraint(CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(n))
+    s.set_trajectory(None, np.zeros((N, m)))
+    return s
+
+
 def cartpole_track(make, model_kind, batch=1, N=60, dtype=F64, goal=None, sway=0.04, **kw):
     """The cart-pole move with the user's own cost and constraint (tests/models/cartpole_track.hpp): stage and
     terminal cost = UserCost (with the non-quadratic pendulum term), the sway of the pole tip limited to +-sway by

@@ -25,8 +25,9 @@ threads, instances built outside the timed region), ``host_boundary`` (the same 
 batch of 1 / 8 / 64 -- the MPC use case -- next to one host core).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--batch B] [--no-cpu-baseline]
-                        [--no-other-configs] [--no-latency]
-        (N > 1: launched by torch.distributed.run, one rank per GPU)
+                        [--no-other-configs] [--no-latency] [--no-fast-forward]
+        (N > 1: one rank per GPU -- under torch.distributed.run as the driver launches it, or started plainly: bench.py
+         then launches its N ranks itself, `self_launch`.  `--launch-check`: the rank plumbing alone, no GPU, gloo.)
 """
 import argparse
 import ctypes
@@ -159,6 +160,8 @@ def dominant_kernel_roofline(cfg, tm, config_index):
         "sweep_launches": tm.get("sweep_launches", 0),
         "concurrent_chains": max(1, round(tm.get("sweep_launches", 0) / max(1, tm["sweeps"] - tm["fused_sweeps"]))),
         "tail_iterations": tm["fused_sweeps"],
+        # the OTHER roof: how close the kernel's fp64 vector work comes to the fp64 VALU peak (PMC pass in profiles/)
+        "compute": compute_side(key, config_index, 1e3 * avg_launch_ms),
     }
     if tm["fused_sweeps"] > 0 and n == 3 and m == 2:
         # the real limiter of the dominant launch: the dependent chain of one instance's iteration
@@ -282,6 +285,112 @@ def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
         "parallel_efficiency_vs_physical_cores": round(best["iterations_per_s"] / (it_rate_1 * phys), 4),
         "teams": runs,
     }
+
+
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks ourselves --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>
+    bench.py <the same arguments>` -- one rank per GPU; rank 0 of that job prints the ONE JSON line on our stdout."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it)
+    env["ALTRO_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank, local_rank, world):
+    """`--launch-check`: the rank / shard plumbing of the N-rank launch WITHOUT a GPU (gloo): every rank reports what it
+    would do -- its rank, local rank, device ordinal, block of the global seeded batch -- one all_gather, and rank 0
+    prints one JSON line with the checks (tests/test_bench_launch.py runs it with two ranks)."""
+    import torch
+    import torch.distributed as dist
+    graft.load_package()
+    S = importlib.import_module("altro_cpp_amd.sharding")
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["batch"]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    lo, hi = S.shard_range(world * B, world, rank)
+    mine = torch.tensor([rank, local_rank, lo, hi, os.getpid(), dist.get_world_size()], dtype=torch.int64)
+    rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    rows = [r.tolist() for r in rows]
+    out = None
+    if rank == 0:
+        blocks = [(r[2], r[3]) for r in rows]
+        out = {"launch_check": {
+            "backend": dist.get_backend(), "world_size": dist.get_world_size(), "env_world_size": world,
+            "ranks": [r[0] for r in rows], "local_ranks": [r[1] for r in rows], "blocks": blocks,
+            "distinct_processes": len({r[4] for r in rows}) == len(rows),
+            "blocks_tile_the_global_batch": blocks[0][0] == 0 and blocks[-1][1] == world * B and
+                                            all(blocks[i][1] == blocks[i + 1][0] for i in range(len(blocks) - 1)),
+            "every_rank_saw_the_same_world": all(r[5] == dist.get_world_size() for r in rows),
+            "self_launched": os.environ.get("ALTRO_BENCH_SELF_LAUNCHED") == "1",
+            "args": {"gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "config": args.config, "batch": B}},
+            "n_gpus": dist.get_world_size()}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def measure_hbm_copy_gbs(torch, dev, mib=1024, reps=10):
+    """The achievable HBM ceiling of THIS device next to the 8 000 GB/s of the data sheet: a
+    device-to-device copy of `mib` MiB (far beyond the 256 MiB Infinity Cache), bytes read + bytes written per second."""
+    n = mib * 1024 * 1024 // 8
+    a = torch.empty(n, dtype=torch.float64, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * n * 8 / (ms * 1e-3) / 1e9
+
+
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+
+
+def compute_side(key, config_index, avg_launch_us):
+    """The compute-side fraction of the dominant kernel: fp64 vector flops per launch from the committed rocprofv3 PMC pass
+    (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: wave-level instruction counts x 64 lanes, FMA = 2 flop; MFMA fp64 flops from
+    SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 are listed beside them), divided by the LIVE launch duration and the 78.6 TFLOP/s
+    fp64 vector peak.  None when profiles/ has no such pass for this kernel."""
+    tag = "" if config_index == 2 else f"_config{config_index}"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}_traffic.json")), reverse=True):
+        if config_index == 2 and "_config" in os.path.basename(f):
+            continue
+        try:
+            tj = json.load(open(f)).get(key)
+            if not tj or tj.get("fp64_valu_flop_per_launch") is None:
+                continue
+            flop = float(tj["fp64_valu_flop_per_launch"])
+            # the profile's launch may differ in size from the live one: scale by the time, i.e. use the PROFILE's own
+            # duration for its own flops (both from the same launches)
+            us = float(tj["avg_launch_us"])
+            tf = flop / (us * 1e-6) / 1e12
+            return {"bound": "valu_f64", "achieved": round(tf, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 5), "fp64_valu_flop_per_launch": round(flop),
+                    "profile_avg_launch_us": round(us, 2), "live_avg_launch_us": round(avg_launch_us, 2),
+                    "valu_busy_frac": tj.get("valu_busy_frac"), "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            pass
+    return None
 
 
 def solve_once(s_, mode):
@@ -410,13 +519,27 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="EXTRA measurement, not the headline: keep this many solver handles in flight (asynchronous "
                          "solves on their own streams), so the latency-bound tail of one batch overlaps the next batch")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU: every rank reports its rank / device / block of the global batch over gloo and rank 0 prints "
+                         "one JSON line (the CPU-side test of the N-rank launch)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: the records travel through host tensors -- lets N ranks SHARE one GPU (--share-devices), the "
+                         "1-GPU test of the world-size-N path; nccl (= RCCL) is the product path")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="device = local_rank %% visible devices (several ranks on one GPU; tests only, needs --dist-backend gloo)")
+    ap.add_argument("--no-fast-forward", action="store_true", help="skip the secondary `fast_forward` key")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: launch the ranks ourselves (the driver's own torch.distributed.run line sets WORLD_SIZE)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
+    if args.launch_check:
+        return launch_check(args, rank, local_rank, world)
 
     import numpy as np
     import torch
@@ -427,6 +550,10 @@ def main():
     S = importlib.import_module("altro_cpp_amd.sharding")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.share_devices:
+        if args.dist_backend != "gloo":
+            raise SystemExit("--share-devices needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     cfg = CONFIGS[args.config]
@@ -452,17 +579,28 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()  # (what the process group really has, not what the environment claims)
     dev = f"cuda:{local_rank}"
     packed = torch.empty((B, 4), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if use_dist else packed
+    host_gather = use_dist and args.dist_backend == "gloo"
+    gathered = torch.empty((world * B, 4), dtype=torch.float64, device="cpu" if host_gather else dev) if use_dist else packed
+    packed_host = torch.empty((B, 4), dtype=torch.float64).pin_memory() if host_gather else None
 
     def solve(s_):
         solve_once(s_, cfg["mode"])
 
     def step():
         solve(solver)
-        S.pack_and_gather(solver, packed, gathered, dist, force_collective=args.force_dist)  # RCCL over xGMI: 32 B per instance
+        if host_gather:  # (tests: N ranks on one GPU -- the records go through the host)
+            solver.pack_results_device(packed.data_ptr())
+            packed_host.copy_(packed)
+            dist.all_gather_into_tensor(gathered, packed_host)
+        else:
+            S.pack_and_gather(solver, packed, gathered, dist, force_collective=args.force_dist)  # RCCL over xGMI: 32 B per instance
 
     if args.pipeline > 1:
         if cfg["mode"] != "al":
@@ -502,18 +640,39 @@ def main():
         drain()
     barrier()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     for _ in range(args.steps):
         step()
     if args.pipeline > 1:
         drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_cores = (time.process_time() - c0) / max(elapsed, 1e-9)  # CPU time of ALL threads of this rank per wall second
+    rank_elapsed = [elapsed]
+    cdev = "cpu" if host_gather else dev
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed, host_cpu_cores], dtype=torch.float64, device=cdev)
+        allr = torch.empty((world, 2), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().numpy()
+        rank_elapsed = [float(v) for v in allr[:, 0]]
+        elapsed = max(rank_elapsed)  # MAX over ranks
+        host_cpu_cores = float(allr[:, 1].max())
 
     res = gathered.cpu().numpy()
+    # ---- dist_check at EVERY world size: the block of the gathered records that belongs to this rank is this rank's own
+    #      altro_get_stats of the last timed solve, field for field; all ranks agree (all_reduce MIN) ----
+    dist_check = None
+    if use_dist and args.pipeline == 1:
+        want = S.result_records(solver.get_stats())
+        ok_local = bool(np.array_equal(res[rank * B:(rank + 1) * B], want))
+        flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "env_world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                      "records_match_get_stats": bool(flag.item() == 1.0),
+                      "gather_is_separate_buffer": bool(gathered.data_ptr() != packed.data_ptr()),
+                      "rank_ms_per_step": [round(1e3 * e / args.steps, 3) for e in rank_elapsed]}
     status = res[:, 3].astype(int)
     iters = res[:, 2]
     solved = int((status == 0).sum())
@@ -566,15 +725,7 @@ def main():
                         "altro_get_trajectory + altro_get_stats into host arrays (the caller's buffers, reused)",
             }
         name, cus = solver.device_info()
-        dist_check = None
-        if args.force_dist and world == 1:
-            # the records RCCL delivered are the solver's own statistics of the last timed solve, field for field
-            # (the profiled solve above repeats the same solve: same statistics)
-            stt = solver.get_stats()
-            want = S.result_records(stt)
-            dist_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                          "records_match_get_stats": bool(np.array_equal(res, want)),
-                          "gather_is_separate_buffer": bool(gathered.data_ptr() != packed.data_ptr())}
+        if args.force_dist and world == 1 and dist_check is not None:
             # the optional second collective (whole trajectories on every rank), outside the timed region
             Nk, nn, mm = solver.N, solver.n, solver.m
             xp = torch.empty((B, Nk + 1, nn), dtype=torch.float64, device=dev)
@@ -600,6 +751,46 @@ def main():
                         others[f"configs[{ci}]"] = measure_other_config(A, P, S, torch, ci, 3, 1, local_rank)
             if not args.no_latency:
                 latency = measure_latency(A, P, local_rank, with_cpu=not args.no_cpu_baseline)
+        # ---- SECONDARY, never `value`: the same step with ALTRO_HIP_FAST_FORWARD_STALLS -- the stragglers' bit-identical
+        #      repetitions of a rejected line search are counted and logged instead of recomputed (results bit-identical,
+        #      tests/test_fused_gpu.py), i.e. work the reference performs is skipped ----
+        fast_forward = None
+        if (world == 1 and args.pipeline == 1 and cfg["mode"] == "al" and not args.no_fast_forward
+                and not os.environ.get("ALTRO_HIP_FAST_FORWARD_STALLS")):
+            if others is None and latency is None:
+                solver.close()
+            os.environ["ALTRO_HIP_FAST_FORWARD_STALLS"] = "1"  # (read when the engine is created)
+            try:
+                sf = new_solver()
+                for _ in range(max(1, args.warmup)):
+                    solve(sf)
+                    S.pack_and_gather(sf, packed, packed, None)
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                fsteps = max(1, min(args.steps, 5))
+                for _ in range(fsteps):
+                    solve(sf)
+                    S.pack_and_gather(sf, packed, packed, None)
+                torch.cuda.synchronize()
+                fel = time.perf_counter() - f0
+                fres = packed.cpu().numpy()
+                fsolved = int((fres[:, 3].astype(int) == 0).sum())
+                fast_forward = {"ms_per_step": round(1e3 * fel / fsteps, 3), "value": round(fsolved * fsteps / fel, 1),
+                                "unit": "trajectories/s", "steps": fsteps,
+                                "records_identical_to_headline": bool(np.array_equal(fres, res[:B])),
+                                "note": "NOT the headline: ALTRO_HIP_FAST_FORWARD_STALLS=1 skips recomputing the stragglers' "
+                                        "bit-identical rejected iterations (the reference recomputes them)"}
+                sf.close()
+            finally:
+                del os.environ["ALTRO_HIP_FAST_FORWARD_STALLS"]
+        # ---- the achievable HBM ceiling of this device beside the data-sheet peak ----
+        try:
+            copy_gbs = measure_hbm_copy_gbs(torch, dev)
+            roofline["peak_measured_copy"] = round(copy_gbs, 1)
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5)
+        except Exception as e:  # (never fail the line for the side measurement)
+            roofline["peak_measured_copy"] = None
+            roofline["peak_measured_copy_error"] = str(e)[:200]
         out = {
             "metric": "trajectories solved/sec (AL-iLQR to tol), unicycle 101 knots, batched" if args.config in (2, 3)
                       else "trajectories solved/sec (to tol), batched",
@@ -611,7 +802,9 @@ def main():
             "config": {
                 "workload": cfg["name"], "baseline_config_index": args.config,
                 "batch_per_gpu": B, "global_batch": total_inst, "knot_points": N + 1,
-                "parallelism": f"instance-sharded x{world} (no data-path collective; RCCL all_gather of result records)",
+                "parallelism": f"instance-sharded x{world} (no data-path collective; "
+                               f"{'RCCL' if args.dist_backend == 'nccl' else 'gloo (host)'} all_gather of result records)",
+                "host_cpu_cores_per_rank": round(host_cpu_cores, 3),
                 "solved_fraction": round(solved / total_inst, 5),
                 "ms_per_ilqr_iter_sweep": round(ms_per_step / max(tm["sweeps"], 1), 4),
                 "us_per_instance_iter": round(1e3 * ms_per_step / max(float(iters.sum()) / world, 1.0), 4),
@@ -628,6 +821,7 @@ def main():
             "host_boundary": host,
             "other_configs": others,
             "latency": latency,
+            "fast_forward": fast_forward,
             **({"dist_check": dist_check} if dist_check is not None else {}),
         }
         print(json.dumps(out), flush=True)

@@ -222,6 +222,8 @@ struct Unicycle {  // examples/unicycle.hpp
   int StateDimension() const { return 3; }
   int ControlDimension() const { return 2; }
   std::vector<double> Params() const { return {}; }
+  int ModelIndex() const { return 0; }
+  int Integrator() const { return 0; }
 };
 struct TripleIntegrator {  // examples/triple_integrator.hpp
   static constexpr int kind = ALTRO_MODEL_TRIPLE_INTEGRATOR;
@@ -230,6 +232,8 @@ struct TripleIntegrator {  // examples/triple_integrator.hpp
   int StateDimension() const { return 3 * dof_; }
   int ControlDimension() const { return dof_; }
   std::vector<double> Params() const { return {static_cast<double>(dof_)}; }
+  int ModelIndex() const { return 0; }
+  int Integrator() const { return 0; }
   int dof_;
 };
 struct Quadrotor12 {  // build-defined model of BASELINE config 5
@@ -238,6 +242,8 @@ struct Quadrotor12 {  // build-defined model of BASELINE config 5
   int StateDimension() const { return 12; }
   int ControlDimension() const { return 4; }
   std::vector<double> Params() const { return {}; }
+  int ModelIndex() const { return 0; }
+  int Integrator() const { return 0; }
 };
 
 // The caller's own plug-in classes.  In the reference a user subclasses problem::ContinuousDynamics
@@ -248,22 +254,48 @@ struct Quadrotor12 {  // build-defined model of BASELINE config 5
 // or several classes of each, listed by ALTRO_USER_COSTS / ALTRO_USER_CONSTRAINTS and picked by their index (`type`).
 // The constructor compiles (or loads from the on-disk cache) the plugin and runs the device-side
 // CheckJacobian / CheckGradient / CheckHessian; errors (compiler output included) are thrown.
+//
+// The source may also hold the other things Problem::SetDynamics accepts in the reference (include/altro_hip.h):
+//   * SEVERAL models of one (n, m), listed by `#define ALTRO_USER_MODELS A, B` -- Model(i) is the descriptor of the i-th,
+//     and Problem::SetDynamics(DiscretizedModel<UserModel>(model.Model(i)), k) puts it on knot k (problem.hpp:155-166);
+//   * a model under problem::ExplicitEuler (integration.hpp:87-104): UserModel::Euler(...) compiles the source with
+//     ALTRO_USER_INTEGRATOR = 1 (every model of the source that does not choose its own `integrator`), to be wrapped in
+//     DiscretizedModel<UserModel, ExplicitEuler>;
+//   * the caller's own problem::DiscreteDynamics (dynamics.hpp:148-187): a struct with `discrete = true`, step / step_jac.
 struct UserModel {
   UserModel(const std::string& name, const std::string& source, int n, int m, bool check_derivatives = true)
       : n_(n), m_(m) {
+    Register(name, source, check_derivatives);
+  }
+  static UserModel Euler(const std::string& name, const std::string& source, int n, int m, bool check_derivatives = true) {
+    UserModel um(n, m);
+    um.integrator_ = 1;
+    um.Register(name, "#define ALTRO_USER_INTEGRATOR 1\n" + source, check_derivatives);
+    return um;
+  }
+  // the index-th model of the source's ALTRO_USER_MODELS list (same plugin, same handle: another knot's dynamics)
+  UserModel Model(int index) const {
+    UserModel um = *this;
+    um.index_ = index;
+    return um;
+  }
+  int Kind() const { return kind_; }
+  int StateDimension() const { return n_; }
+  int ControlDimension() const { return m_; }
+  std::vector<double> Params() const { return {}; }
+  int ModelIndex() const { return index_; }
+  int Integrator() const { return integrator_; }
+
+ private:
+  UserModel(int n, int m) : n_(n), m_(m) {}
+  void Register(const std::string& name, const std::string& source, bool check_derivatives) {
     const altro_status st = altro_register_model_source(name.c_str(), source.c_str(), check_derivatives ? 1 : 0, &kind_);
     if (st != ALTRO_OK) {
       const char* msg = altro_last_error(nullptr);
       throw std::runtime_error("altro_register_model_source failed (" + std::to_string((int)st) + "): " + (msg ? msg : ""));
     }
   }
-  int Kind() const { return kind_; }
-  int StateDimension() const { return n_; }
-  int ControlDimension() const { return m_; }
-  std::vector<double> Params() const { return {}; }
-
- private:
-  int kind_ = 0, n_, m_;
+  int kind_ = 0, n_, m_, index_ = 0, integrator_ = 0;
 };
 
 // examples/quadratic_cost.hpp:29-39.  xref may hold one reference or `batch` references.
@@ -384,17 +416,34 @@ struct CircleConstraint : ConstraintDesc {
 }  // namespace examples
 
 namespace problem {
-// problem/discretized_model.hpp:24-65: RK4 is the only integrator of the device path.
-template <class Model>
+// altro/problem/integration.hpp:87-169: the two explicit integrators of the reference, as tags
+struct RungeKutta4 {
+  static constexpr int kind = 0;
+};
+struct ExplicitEuler {
+  static constexpr int kind = 1;
+};
+// problem/discretized_model.hpp:24-65.  RungeKutta4 (the default) for every model; ExplicitEuler for a user model whose
+// plugin was compiled for it (examples::UserModel::Euler): the integrator is part of the compiled device code, not a
+// run-time switch.
+template <class Model, class Integrator = RungeKutta4>
 struct DiscretizedModel {
-  explicit DiscretizedModel(const Model& m) : model(m) {}
+  explicit DiscretizedModel(const Model& m) : model(m) {
+    if (Integrator::kind != m.Integrator())
+      throw std::runtime_error(Integrator::kind == 1
+                                   ? "DiscretizedModel<Model, ExplicitEuler>: the device code of this model integrates with "
+                                     "RungeKutta4 (a user model is compiled for ExplicitEuler by examples::UserModel::Euler)"
+                                   : "DiscretizedModel<Model, RungeKutta4>: this user model was compiled for ExplicitEuler "
+                                     "(examples::UserModel::Euler): wrap it in DiscretizedModel<Model, ExplicitEuler>");
+  }
   Model model;
 };
 
 // altro/problem/problem.hpp:65-307
 class Problem {
  public:
-  explicit Problem(int N) : N_(N), costs_(N + 1), has_cost_(N + 1, false), cons_(N + 1), has_dyn_(N + 1, false) {}
+  explicit Problem(int N)
+      : N_(N), costs_(N + 1), has_cost_(N + 1, false), cons_(N + 1), has_dyn_(N + 1, false), knot_model_(N + 1, 0) {}
   int NumSegments() const { return N_; }
   void SetBatch(int B) { batch_ = B; }
   int BatchSize() const { return batch_; }
@@ -407,26 +456,34 @@ class Problem {
     costs_[k] = cost;
     has_cost_[k] = true;
   }
-  template <class Model>
-  void SetDynamics(const DiscretizedModel<Model>& dm, int k) {
+  template <class Model, class Integrator>
+  void SetDynamics(const DiscretizedModel<Model, Integrator>& dm, int k) {
     Range(k);
     if (k >= N_) throw std::runtime_error("dynamics are set on knots 0..N-1");
-    // The reference keeps one model PER KNOT (models_[k], problem.hpp:155-166).  A handle of this build carries one model
-    // for the whole horizon: setting a different one on another knot would silently solve the wrong dynamics, so it
-    // is refused.  Dynamics that change along the horizon are written as ONE time-varying user model
-    // (`static constexpr bool time_varying = true`; f(x, u, t, xdot) switches on the knot time t).
+    // The reference keeps one model PER KNOT (models_[k], problem.hpp:155-166).  A handle of this build carries one
+    // compiled model source for the whole horizon; knots may use DIFFERENT models of that source (a user source that
+    // lists several: ALTRO_USER_MODELS, examples::UserModel::Model(i)) -- the knot's index travels through
+    // altro_set_knot_models.  A model of another kind / source on another knot would silently solve the wrong dynamics, so
+    // it is refused (the state and control dimensions could not change along the horizon either).
     bool any = false;
     for (int j = 0; j < N_; ++j) any = any || has_dyn_[j];
     if (any && (model_kind_ != dm.model.Kind() || model_params_ != dm.model.Params()))
-      throw std::runtime_error("Problem::SetDynamics: a different model on knot " + std::to_string(k) +
-                               " -- one model per problem (use a time-varying user model for dynamics that change "
-                               "along the horizon)");
+      throw std::runtime_error("Problem::SetDynamics: a model of another kind on knot " + std::to_string(k) +
+                               " -- the models of one problem come from ONE source (a user source may list several: "
+                               "#define ALTRO_USER_MODELS A, B and examples::UserModel::Model(i))");
     model_kind_ = dm.model.Kind();
     model_params_ = dm.model.Params();
     n_ = dm.model.StateDimension();
     m_ = dm.model.ControlDimension();
     has_dyn_[k] = true;
+    knot_model_[k] = dm.model.ModelIndex();
     if (k == N_ - 1) has_dyn_[N_] = true;  // IdentityDynamics at the terminal knot (problem.hpp:161-164)
+  }
+  // the vector overload (problem.hpp:187-191): models[k] on knot k, k = 0 .. N-1
+  template <class Model, class Integrator>
+  void SetDynamics(const std::vector<DiscretizedModel<Model, Integrator>>& models) {
+    if ((int)models.size() != N_) throw std::runtime_error("Problem::SetDynamics: expected N models");
+    for (int k = 0; k < N_; ++k) SetDynamics(models[k], k);
   }
   void SetConstraint(const examples::ConstraintDesc& con, int k) {
     Range(k);
@@ -466,6 +523,9 @@ class Problem {
     using detail::Check;
     Check(h, altro_set_model(h, model_kind_, model_params_.empty() ? nullptr : model_params_.data(),
                              (int)model_params_.size()), "altro_set_model");
+    bool per_knot_models = false;
+    for (int k = 0; k < N_; ++k) per_knot_models = per_knot_models || knot_model_[k] != 0;
+    if (per_knot_models) Check(h, altro_set_knot_models(h, knot_model_.data(), N_), "altro_set_knot_models");
     for (int k = 0; k <= N_;) {
       int e = k + 1;
       while (e <= N_ && costs_[e] == costs_[k]) ++e;
@@ -517,6 +577,7 @@ class Problem {
   std::vector<bool> has_cost_;
   std::vector<std::vector<examples::ConstraintDesc>> cons_;
   std::vector<bool> has_dyn_;
+  std::vector<int> knot_model_;  // per knot: index of its model in the user source's ALTRO_USER_MODELS list
 };
 }  // namespace problem
 
@@ -556,6 +617,7 @@ struct Core {
   std::vector<std::vector<examples::ConstraintDesc>> cons;  // per knot, solver order (empty without AL)
   // cache
   unsigned gains_epoch = ~0u, ctg_epoch = ~0u;
+  bool ctg_read = false;  // a KnotPointFunctions view has asked for the cost-to-go: whole solves record it from now on
   std::vector<double> K, d, P, p;
   ~Core() {
     if (h) altro_destroy(h);
@@ -633,9 +695,14 @@ class KnotPointFunctions {
   }
   void Ctg() const {
     if (c_->ctg_epoch == c_->epoch) return;
+    c_->ctg_read = true;  // (iLQR::PrepareSolve: every later Solve() keeps P, p -- as the reference does after its Solve())
     c_->P.resize((size_t)c_->B * (c_->N + 1) * n * n);
     c_->p.resize((size_t)c_->B * (c_->N + 1) * n);
-    detail::Check(c_->h, altro_get_ctg(c_->h, c_->P.data(), c_->p.data()), "altro_get_ctg");
+    if (altro_get_ctg(c_->h, c_->P.data(), c_->p.data()) != ALTRO_OK)
+      throw std::runtime_error(std::string("altro_get_ctg failed: ") + altro_last_error(c_->h) +
+                               " -- the last whole Solve() ran without recording the cost-to-go (default for small batches: the "
+                               "persistent kernel keeps P, p in registers).  Solves from now on record it; or call "
+                               "SetRecordCostToGo(true) before Solve(), or read it after a step-level BackwardPass().");
     c_->ctg_epoch = c_->epoch;
   }
   static std::vector<double> Slice(const std::vector<double>& v, size_t off, size_t len) {
@@ -705,7 +772,9 @@ class iLQR {
   // facade user solves -- only runs without the recording).  Default for batches of up to kHistoryBatchLimit instances:
   // the STEP-LEVEL BackwardPass() records (that is where the reference's tests read the cost-to-go:
   // test/ilqr/unicycle_ilqr_test.cpp:39-54), Solve() does not.  SetRecordCostToGo(true) records everywhere (a Solve()
-  // then takes the batched kernels only), SetRecordCostToGo(false) nowhere.
+  // then takes the batched kernels only), SetRecordCostToGo(false) nowhere.  DIFFERENCE FROM THE REFERENCE, where P and p
+  // stay readable after every Solve(): here the first GetCostToGo*() behind a default Solve() throws (with this
+  // explanation); from that read on the solver knows its user wants them and every later Solve() records (Core::ctg_read).
   void SetRecordCostToGo(bool on) {
     ctg_auto_ = false;
     ApplyRecordCtg(on);
@@ -718,7 +787,7 @@ class iLQR {
   // called in front of every whole solve (also by AugmentedLagrangianiLQR::Solve): recording policy and a history
   // buffer large enough for the iteration caps in force
   void PrepareSolve() {
-    if (ctg_auto_) ApplyRecordCtg(false);
+    if (ctg_auto_) ApplyRecordCtg(c_->ctg_read);
     if (c_->record_history && HistoryRowsNeeded() > c_->hist_cap) SetRecordHistory(true);
   }
 

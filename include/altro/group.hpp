@@ -8,6 +8,7 @@
 // iterations_total, status}.  Link libaltro_group.so (which links librccl.so) next to libaltro_hip.so.
 #pragma once
 
+#include <exception>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -40,6 +41,8 @@ class BatchGroup {
   // the solver of part `part` (constructed with device_id = Device(part)); stays the caller's
   template <int n, int m>
   void Attach(int part, augmented_lagrangian::AugmentedLagrangianiLQR<n, m>& solver) {
+    // (the library reads batch, device and dimensions from the handle itself and rejects a part whose (n, m, N) differ
+    //  from the parts already attached: the gather buffers are sized from them)
     Check(altro_group_attach(g_, part, solver.Handle(), solver.BatchSize()), "altro_group_attach");
     n_ = n;
     m_ = m;
@@ -49,8 +52,30 @@ class BatchGroup {
   }
   // AugmentedLagrangianiLQR::Solve on every part at once, then the exchange
   void Solve() {
-    for (auto& a : async_) a.start();
-    for (auto& a : async_) a.wait();
+    // exception-safe: when part k fails to start, the parts already in flight are waited for before the error leaves
+    // (a solve left pending would keep its handle busy for good)
+    size_t started = 0;
+    try {
+      for (; started < async_.size(); ++started)
+        if (async_[started].start) async_[started].start();
+    } catch (...) {
+      for (size_t i = 0; i < started; ++i) {
+        try {
+          async_[i].wait();
+        } catch (...) {
+        }
+      }
+      throw;
+    }
+    std::exception_ptr first;
+    for (auto& a : async_) {
+      try {
+        if (a.wait) a.wait();
+      } catch (...) {
+        if (!first) first = std::current_exception();
+      }
+    }
+    if (first) std::rethrow_exception(first);
     Check(altro_group_gather(g_), "altro_group_gather");
   }
   int TotalInstances() const { return altro_group_total(g_); }

@@ -163,6 +163,9 @@ typedef struct altro_timing {
   int sweep_launches;      /* batched sweeps launched (all chains of sweeps together)       */
   long long instance_iterations; /* sum over instances of iterations_total                  */
   long long fused_instance_iterations; /* (instance, iteration) units run by the fused launch */
+  int host_naps;           /* times the host thread slept (~50 us) instead of spinning while it    */
+                           /* waited for a sweep counter (large batches; ALTRO_HIP_HOST_WAIT=spin: 0) */
+  int reserved;
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -171,6 +174,11 @@ typedef struct altro_timing {
  * (al_solver.hpp:35, ilqr.hpp:50-55) with a batch dimension. */
 altro_status altro_create(const altro_desc* desc, altro_handle* out);
 void altro_destroy(altro_handle h);
+/* The descriptor the handle was created with (iLQR::NumSegments / StateDimension / ControlDimension,
+ * altro/ilqr/ilqr.hpp:140-166, plus batch, dtype and device): callers that size device buffers for
+ * altro_pack_results_device / altro_pack_trajectory_device read the dimensions from the handle instead of trusting
+ * their own copy (libaltro_group.so does). */
+altro_status altro_get_desc(altro_handle h, altro_desc* out);
 /* Text of the last error on this handle (or of the last failed altro_create when h == NULL). */
 const char* altro_last_error(altro_handle h);
 /* Fill *opts with the reference defaults (solver_options.hpp:23-56). */
@@ -220,8 +228,31 @@ altro_status altro_set_model(altro_handle h, int kind, const double* params, int
  *     #define ALTRO_USER_CONSTRAINT UserConstraint
  * With check_jacobian != 0 the gradient, the Hessian and the constraint Jacobian are checked against finite
  * differences on the device as well (FunctionBase::CheckGradient / CheckHessian / CheckJacobian,
- * functionbase.cpp:42-125).  At the terminal knot u is the zero vector, as in the reference. */
+ * functionbase.cpp:42-125).  At the terminal knot u is the zero vector, as in the reference.
+ *
+ * OTHER DISCRETISATIONS AND PER-KNOT MODELS -- what else Problem::SetDynamics accepts in the reference:
+ *   - DiscretizedModel<Model, ExplicitEuler> (altro/problem/integration.hpp:87-104): the model struct declares
+ *         static constexpr int integrator = 1;       // 0 / absent: RungeKutta4
+ *     (or the source starts with `#define ALTRO_USER_INTEGRATOR 1`, the default for every model of the source):
+ *     x+ = x + f(x, u, t) h, [A | B] = Identity(n, n + m) + jac h -- on every kernel of the solver, like RK4.
+ *   - the caller's own problem::DiscreteDynamics subclass (altro/problem/dynamics.hpp:148-187: Evaluate(x, u, t, h,
+ *     xnext), Jacobian(x, u, t, h, jac)): the struct declares `static constexpr bool discrete = true` and defines,
+ *     instead of f / jac,
+ *         template <class T> ALTRO_MODEL_FN static void step(const T* x, const T* u, float t, float h, T* xnext);
+ *         template <class T> ALTRO_MODEL_FN static void step_jac(const T* x, const T* u, float t, float h, T* J);  // n x (n+m)
+ *     with the knot's 32-bit float time and step (knotpoint.hpp:179-180); step_jac is checked against finite differences
+ *     of step.  Such a model runs on the general kernels, like a time-varying one.
+ *   - a DIFFERENT model on every knot (problem.hpp:155-166, 187-191), all of one (n, m): the source defines several
+ *     structs (each continuous / Euler / discrete, time-varying or not) and lists them,
+ *         #define ALTRO_USER_MODELS ModelA, ModelB
+ *     (no `struct UserModel` needed then), and altro_set_knot_models assigns each knot its index in the list. */
 altro_status altro_register_model_source(const char* name, const char* source, int check_jacobian, int* kind_out);
+
+/* Problem::SetDynamics(model, k) with models that differ along the horizon (problem.hpp:155-166; the vector overload
+ * :187-191): model_of_knot[k], k = 0 .. N-1 (`count` must be N), is the index of knot k's model in the ALTRO_USER_MODELS
+ * list of the handle's user-model source.  Part of the problem definition (before the first compute call); without it
+ * every knot uses model 0.  A handle whose model is not a list accepts only zeros (checked at the first compute call). */
+altro_status altro_set_knot_models(altro_handle h, const int* model_of_knot, int count);
 
 /* Path of the compiled plugin of a registered user model (the on-disk cache entry: <cache>/altro_user_<hash>.so, next
  * to its generated .hip and the compiler's .log).  Returns the length of the path, -1 for an unknown kind.  A deployment

@@ -143,28 +143,8 @@ using std::cos;
 using std::sin;
 #include ORACLE_USER_MODEL
 }  // namespace altro_user
-template <class U, class = void>
-struct UserTimeVarying : std::false_type {};
-template <class U>
-struct UserTimeVarying<U, std::void_t<decltype(U::time_varying)>> : std::integral_constant<bool, U::time_varying> {};
 template <class T>
-struct UserModelAdapter {
-  static constexpr int n = altro_user::UserModel::n, m = altro_user::UserModel::m;
-  static constexpr bool time_varying = UserTimeVarying<altro_user::UserModel>::value;
-  int dof = 0;
-  void f(const T* x, const T* u, T* xd) const {
-    if constexpr (!time_varying) altro_user::UserModel::f(x, u, xd);
-  }
-  void jac(const T* x, const T* u, T* J) const {
-    if constexpr (!time_varying) altro_user::UserModel::jac(x, u, J);
-  }
-  void f(const T* x, const T* u, float t, T* xd) const {
-    if constexpr (time_varying) altro_user::UserModel::f(x, u, t, xd);
-  }
-  void jac(const T* x, const T* u, float t, T* J) const {
-    if constexpr (time_varying) altro_user::UserModel::jac(x, u, t, J);
-  }
-};
+struct UserModelAdapter;  // (defined below, behind Pick<>)
 #endif
 template <class M>
 struct IsUserModel : std::false_type {};
@@ -233,6 +213,88 @@ inline bool UserConShape(int t, int* nparams, int* p, bool* equality) {
     *equality = F::equality;
   });
 }
+
+#ifdef ORACLE_USER_MODEL
+// What a user source may put behind Problem::SetDynamics(model, k) (problem.hpp:155-166), as include/altro_hip.h lists it:
+// a continuous model f / jac under RungeKutta4 (default) or ExplicitEuler (`integrator = 1`, integration.hpp:87-104), a
+// DiscreteDynamics of its own (`discrete = true`: step / step_jac, dynamics.hpp:148-187), time-varying or not, and
+// SEVERAL of them, one per knot (#define ALTRO_USER_MODELS A, B; `which` = the knot's index into the list).
+#ifndef ALTRO_USER_INTEGRATOR
+#define ALTRO_USER_INTEGRATOR 0
+#endif
+template <class U, class = void>
+struct UserTimeVarying : std::false_type {};
+template <class U>
+struct UserTimeVarying<U, std::void_t<decltype(U::time_varying)>> : std::integral_constant<bool, U::time_varying> {};
+template <class U, class = void>
+struct UserDiscrete : std::false_type {};
+template <class U>
+struct UserDiscrete<U, std::void_t<decltype(U::discrete)>> : std::integral_constant<bool, U::discrete> {};
+template <class U, class = void>
+struct UserIntegrator : std::integral_constant<int, ALTRO_USER_INTEGRATOR> {};
+template <class U>
+struct UserIntegrator<U, std::void_t<decltype(U::integrator)>> : std::integral_constant<int, U::integrator> {};
+namespace user_models_ {
+using namespace ::altro_user;
+template <class M0, class...>
+struct Head {
+  using type = M0;
+};
+#if defined(ALTRO_USER_MODELS)
+using Models = FunctorTypes<ALTRO_USER_MODELS>;
+using First = Head<ALTRO_USER_MODELS>::type;
+#else
+using Models = FunctorTypes<UserModel>;
+using First = UserModel;
+#endif
+}  // namespace user_models_
+template <class T>
+struct UserModelAdapter {
+  using Models = user_models_::Models;
+  static constexpr int n = user_models_::First::n, m = user_models_::First::m;
+  static constexpr bool time_varying = true;  // (the adapter always takes the knot time; the model decides whether it reads it)
+  int dof = 0;
+  mutable int which = 0;  // the model of the knot being evaluated (Instance::Dynamics sets it)
+  void f(const T* x, const T* u, float t, T* xd) const {
+    Pick<Models>::at(which, [&](auto* p) {
+      using S = std::remove_pointer_t<decltype(p)>;
+      if constexpr (UserDiscrete<S>::value) std::fill(xd, xd + n, T(0));  // (never reached: Instance::Dynamics takes step())
+      else if constexpr (UserTimeVarying<S>::value) S::f(x, u, t, xd);
+      else S::f(x, u, xd);
+    });
+  }
+  void jac(const T* x, const T* u, float t, T* J) const {
+    Pick<Models>::at(which, [&](auto* p) {
+      using S = std::remove_pointer_t<decltype(p)>;
+      if constexpr (UserDiscrete<S>::value) std::fill(J, J + n * (n + m), T(0));
+      else if constexpr (UserTimeVarying<S>::value) S::jac(x, u, t, J);
+      else S::jac(x, u, J);
+    });
+  }
+  // 0: RungeKutta4, 1: ExplicitEuler, 2: the model's own DiscreteDynamics
+  int Kind() const {
+    int kind = 0;
+    Pick<Models>::at(which, [&](auto* p) {
+      using S = std::remove_pointer_t<decltype(p)>;
+      kind = UserDiscrete<S>::value ? 2 : (UserIntegrator<S>::value == 1 ? 1 : 0);
+    });
+    return kind;
+  }
+  void step(const T* x, const T* u, float t, float h, T* xn) const {
+    Pick<Models>::at(which, [&](auto* p) {
+      using S = std::remove_pointer_t<decltype(p)>;
+      if constexpr (UserDiscrete<S>::value) S::step(x, u, t, h, xn);
+    });
+  }
+  void step_jac(const T* x, const T* u, float t, float h, T* J) const {
+    Pick<Models>::at(which, [&](auto* p) {
+      using S = std::remove_pointer_t<decltype(p)>;
+      if constexpr (UserDiscrete<S>::value) S::step_jac(x, u, t, h, J);
+    });
+  }
+  static int Count() { return Models::count; }
+};
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Host-side problem specification (dtype independent, fp64).
@@ -354,6 +416,7 @@ struct Instance final : SolverBase {
   int N;
   std::vector<float> h;  // N+1 entries, h[N] = 0 (trajectory.hpp:122-130)
   std::vector<float> tm;  // N+1 knot times (KnotPoint::t_, knotpoint.hpp:179)
+  std::vector<int> km;    // N+1: model of the user source's list that knot k uses (Problem::SetDynamics(model, k)); all 0 by default
 
   struct QCost {  // examples/quadratic_cost.hpp:13-27
     T Q[n * n], R[m * m], H[n * m], q[n], r[m], c;
@@ -402,6 +465,7 @@ struct Instance final : SolverBase {
   Instance(int N_, const Model& mdl) : model(mdl), N(N_) {
     h.assign(N + 1, 0.0f);
     tm.assign(N + 1, 0.0f);
+    km.assign(N + 1, 0);
     cost.resize(N + 1);
     cons.resize(N + 1);
     x0.assign(n, T(0));
@@ -731,10 +795,26 @@ struct Instance final : SolverBase {
   // ---- dynamics ------------------------------------------------------------------------------
   // RungeKutta4::Integrate, altro/problem/integration.hpp:123-131
   // (the stage times: `t + 0.5 * h` with float t, h is evaluated in double and narrowed to Evaluate's float parameter)
-  void Dynamics(const T* x, const T* u, float hf, T* xn, float t = 0.0f) const {
+  // (`which`: the knot's model when the user source lists several; the other DiscreteDynamics kinds of a user model --
+  //  ExplicitEuler::Integrate, integration.hpp:90-94, and the caller's own Evaluate(x, u, t, h, xnext), dynamics.hpp:148-187)
+  void Dynamics(const T* x, const T* u, float hf, T* xn, float t = 0.0f, int which = 0) const {
     const T hh = T(hf);
+    if constexpr (IsUserModel<Model>::value) {
+      model.which = which;
+      const int kind = model.Kind();
+      if (kind == 2) {
+        model.step(x, u, t, hf, xn);
+        return;
+      }
+      if (kind == 1) {
+        T xd[n];
+        model.f(x, u, t, xd);
+        for (int i = 0; i < n; ++i) xn[i] = x[i] + xd[i] * hh;
+        return;
+      }
+    }
     const float th = (float)((double)t + 0.5 * (double)hf), t1 = (float)((double)t + (double)hf);
-    T k1[n], k2[n], k3[n], k4[n], xt[n];
+    T k1[n] = {}, k2[n] = {}, k3[n] = {}, k4[n] = {}, xt[n];  // (zeroed: a user-model index outside the list evaluates nothing)
     ModelF(model, x, u, t, k1);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
     ModelF(model, xt, u, th, k2);
@@ -746,11 +826,25 @@ struct Instance final : SolverBase {
   }
   // RungeKutta4::Jacobian, integration.hpp:132-169
   // (the middle Jacobians are taken at time 0.5 * t and the last one at t -- integration.hpp:144-150, as written)
-  void DynamicsJacobian(const T* x, const T* u, float hf, T* J, float t = 0.0f) const {
+  void DynamicsJacobian(const T* x, const T* u, float hf, T* J, float t = 0.0f, int which = 0) const {
     const T hh = T(hf);
+    if constexpr (IsUserModel<Model>::value) {
+      model.which = which;
+      const int kind = model.Kind();
+      if (kind == 2) {  // DiscreteDynamics::Jacobian(x, u, t, h, jac)
+        model.step_jac(x, u, t, hf, J);
+        return;
+      }
+      if (kind == 1) {  // ExplicitEuler::Jacobian (integration.hpp:95-101): Identity(n, n + m) + jac * h
+        model.jac(x, u, t, J);
+        for (int j = 0; j < nm; ++j)
+          for (int i = 0; i < n; ++i) J[i + j * n] = (i == j ? T(1) : T(0)) + J[i + j * n] * hh;
+        return;
+      }
+    }
     const float th = (float)((double)t + 0.5 * (double)hf), tj = (float)(0.5 * (double)t);
-    T k1[n], k2[n], k3[n], xt[n];
-    T Jc[4][n * nm];
+    T k1[n] = {}, k2[n] = {}, k3[n] = {}, xt[n];
+    T Jc[4][n * nm] = {};
     ModelF(model, x, u, t, k1);
     for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] * T(0.5) * hh;
     ModelF(model, xt, u, th, k2);
@@ -816,7 +910,7 @@ struct Instance final : SolverBase {
   // iLQR::Rollout, ilqr.hpp:453-459
   void Rollout() override {
     for (int i = 0; i < n; ++i) X[i] = x0[i];
-    for (int k = 0; k < N; ++k) Dynamics(&X[k * n], &U[k * m], h[k], &X[(k + 1) * n], tm[k]);
+    for (int k = 0; k < N; ++k) Dynamics(&X[k * n], &U[k * m], h[k], &X[(k + 1) * n], tm[k], km[k]);
   }
   // iLQR::Cost / CalcIndividualCosts, ilqr.hpp:326-334, 758-763
   T CostOf(const std::vector<T>& Xs, const std::vector<T>& Us) {
@@ -835,7 +929,7 @@ struct Instance final : SolverBase {
       const T* x = &X[k * n];
       const T* u = &U[k * m];
       CostExpansion(k, x, u);
-      if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm], tm[k]);
+      if (k < N) DynamicsJacobian(x, u, h[k], &AB[k * n * nm], tm[k], km[k]);
       costs[k] = KnotCost(k, x, u);
       if (round_records) {
         RoundRec(&AB[k * n * nm], n * nm);
@@ -1040,7 +1134,7 @@ struct Instance final : SolverBase {
         for (int l = 0; l < n; ++l) s += Kk[i + l * m] * dx[l];
         Ub[k * m + i] = U[k * m + i] + s + dk[i] * alpha;
       }
-      Dynamics(&Xb[k * n], &Ub[k * m], h[k], &Xb[(k + 1) * n], tm[k]);
+      Dynamics(&Xb[k * n], &Ub[k * m], h[k], &Xb[(k + 1) * n], tm[k], km[k]);
       if (opts.check_forwardpass_bounds) {
         T sx = 0, su = 0;
         for (int i = 0; i < n; ++i) sx += Xb[(k + 1) * n + i] * Xb[(k + 1) * n + i];
@@ -1394,6 +1488,7 @@ struct oracle_solver_s {
   int dof = 0;
   float hstep = 0.0f;
   std::vector<float> hk, tk;  // per-knot steps [N] / times [N + 1] (Trajectory::SetStep / SetTime); empty: uniform
+  std::vector<int> knot_model;  // per-knot model indices [N] (altro_set_knot_models); empty: model 0
   std::vector<CostSpec> costs;
   std::vector<ConSpec> cons;
   std::vector<double> x0;
@@ -1438,6 +1533,7 @@ std::unique_ptr<SolverBase> MakeInstance(oracle_handle h, int b, const Model& md
   Instance<T, Model>& I = *up;
   constexpr int n = Model::n, m = Model::m;
   ApplyKnotTimes(h, I.h, I.tm);
+  for (int k = 0; k < D.N && !h->knot_model.empty(); ++k) I.km[k] = h->knot_model[k];
   for (const CostSpec& c : h->costs) {
     if (c.user) {
       int np = 0;
@@ -1684,6 +1780,11 @@ altro_status oracle_create(const altro_desc* desc, oracle_handle* out) {
   return ALTRO_OK;
 }
 void oracle_destroy(oracle_handle h) { delete h; }
+altro_status oracle_get_desc(oracle_handle h, altro_desc* out) {
+  if (!h || !out) return ALTRO_INVALID_ARG;
+  *out = h->desc;
+  return ALTRO_OK;
+}
 const char* oracle_last_error(oracle_handle h) { return h ? h->err.c_str() : ""; }
 altro_status oracle_set_threads(oracle_handle h, int nthreads) {
   h->nthreads = nthreads;
@@ -1711,6 +1812,12 @@ altro_status oracle_set_steps(oracle_handle h, const float* hk, int count) {  //
     h->tk[count] = h->hstep * count;
   }
   h->hk.assign(hk, hk + count);
+  h->built = false;
+  return ALTRO_OK;
+}
+altro_status oracle_set_knot_models(oracle_handle h, const int* model_of_knot, int count) {  // Problem::SetDynamics(model, k)
+  if (count != h->desc.N) return ALTRO_INVALID_ARG;
+  h->knot_model.assign(model_of_knot, model_of_knot + count);
   h->built = false;
   return ALTRO_OK;
 }

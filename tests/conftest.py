@@ -30,6 +30,11 @@ def P(A):
 
 
 @pytest.fixture(scope="session")
+def S(A):
+    return importlib.import_module("altro_cpp_amd.sharding")
+
+
+@pytest.fixture(scope="session")
 def oracle_lib():
     if not os.path.exists(ORACLE_LIB):
         graft.build_oracle()

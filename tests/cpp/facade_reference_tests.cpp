@@ -2,6 +2,7 @@
 // the C++ facade (include/altro/) on the MI355X solver.  Each CASE cites the test it replays; the expected
 // values are the reference's constants (tests/golden/reference_constants.json holds the same data).
 //   build: make -C tests/cpp        run: tests/cpp/facade_reference_tests   (needs a GPU; exit code = failures)
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -426,6 +427,132 @@ static void KnotTimeTests() {
   }
 }
 
+// ---- what else Problem::SetDynamics accepts (VERDICT r3 missing #1 / #2): a time-varying model through the facade, a
+//      different model per knot, DiscretizedModel<Model, ExplicitEuler> ----------------------------------------------------
+static std::string ReadSource(const char* path) {
+  std::ifstream f(path);
+  std::stringstream src;
+  src << f.rdbuf();
+  return src.str();
+}
+static void CartpoleProblem(problem::Problem& prob, int N, double goal, double h) {
+  const std::vector<double> Q = {1e-1 * h, 0, 0, 0, 0, 1e-1 * h, 0, 0, 0, 0, 1e-1 * h, 0, 0, 0, 0, 1e-1 * h};
+  std::vector<double> Qf(16, 0.0);
+  for (int i = 0; i < 4; ++i) Qf[i * 5] = 100.0;
+  const std::vector<double> xf = {goal, 0.0, 0.0, 0.0};
+  for (int k = 0; k < N; ++k) {
+    prob.SetCostFunction(examples::QuadraticCost::LQRCost(Q, {1e-2 * h}, xf, {0.0}), k);
+    prob.SetConstraint(examples::ControlBound({-3.0}, {3.0}), k);
+  }
+  prob.SetCostFunction(examples::QuadraticCost::LQRCost(Qf, {0.0}, xf, {0.0}, true), N);
+  prob.SetConstraint(examples::GoalConstraint(xf), N);
+  prob.SetInitialState({0.0, 0.0, 0.0, 0.0});
+}
+static void cartpole_f(const double* x, double F, double* xd) {  // tests/models/cartpole.hpp
+  const double mc = 1.0, mp = 0.2, l = 0.5, g = 9.81, s = std::sin(x[1]), c = std::cos(x[1]), q = x[3], D = mc + mp * s * s;
+  xd[0] = x[2];
+  xd[1] = q;
+  xd[2] = (F + mp * s * (l * q * q + g * c)) / D;
+  xd[3] = (-F * c - mp * l * q * q * c * s - (mc + mp) * g * s) / (l * D);
+}
+static void DynamicsKindTests() {
+  const int N = 60;
+  const float hf = 0.05f;
+  const double h = hf;
+  CASE("A time-varying user model through the facade: the solver is built from the problem BEFORE the trajectory (and its "
+       "step) exists (ContinuousDynamics::Evaluate(x, u, t, xdot), dynamics.hpp:59-95; ADVICE r3)");
+  {
+    examples::UserModel wind("cartpole_wind", ReadSource(WIND_SOURCE_PATH), 4, 1);
+    problem::Problem prob(N);
+    for (int k = 0; k < N; ++k) prob.SetDynamics(problem::DiscretizedModel<examples::UserModel>(wind), k);
+    CartpoleProblem(prob, N, 1.0, h);
+    augmented_lagrangian::AugmentedLagrangianiLQR<4, 1> solver(prob);  // uploads the problem: no step known yet
+    auto Z = std::make_shared<Trajectory<4, 1>>(N);
+    Z->SetUniformStep(hf);
+    solver.SetTrajectory(Z);
+    solver.Solve();
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.MaxViolation() < 1e-4);
+    EXPECT(std::abs(Z->State(N)[0] - 1.0) < 1e-3);
+  }
+  CASE("Problem::SetDynamics(model, k) with a different model per knot (problem.hpp:155-166): RK4 / explicit Euler / the "
+       "caller's own discrete map, from one user source");
+  {
+    examples::UserModel steps("cartpole_steps", ReadSource(STEPS_SOURCE_PATH), 4, 1);
+    problem::Problem prob(N);
+    for (int k = 0; k < N; ++k)
+      prob.SetDynamics(problem::DiscretizedModel<examples::UserModel>(steps.Model(k < 20 ? 0 : (k < 40 ? 1 : 2))), k);
+    CartpoleProblem(prob, N, 0.9, h);
+    EXPECT(prob.IsFullyDefined());
+    augmented_lagrangian::AugmentedLagrangianiLQR<4, 1> solver(prob);
+    auto Z = std::make_shared<Trajectory<4, 1>>(N);
+    Z->SetUniformStep(hf);
+    solver.SetTrajectory(Z);
+    solver.Solve();
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.MaxViolation() < 1e-4);
+    // knot 25 steps with explicit Euler: x+ = x + f(x, u) h (integration.hpp:90-94)
+    double xd[4], worst = 0.0;
+    cartpole_f(Z->State(25), Z->Control(25)[0], xd);
+    for (int i = 0; i < 4; ++i) worst = std::max(worst, std::abs(Z->State(26)[i] - (Z->State(25)[i] + xd[i] * h)));
+    EXPECT(worst < 1e-12);
+    // knot 45 with the symplectic map and its gust at t_45 = float(45) * h
+    const double t = static_cast<float>(45) * hf;
+    cartpole_f(Z->State(45), Z->Control(45)[0] + 0.3 * std::sin(1.7 * t), xd);
+    const double v0 = Z->State(45)[2] + xd[2] * h, v1 = Z->State(45)[3] + xd[3] * h;
+    worst = std::max({std::abs(Z->State(46)[2] - v0), std::abs(Z->State(46)[3] - v1),
+                      std::abs(Z->State(46)[0] - (Z->State(45)[0] + v0 * h)), std::abs(Z->State(46)[1] - (Z->State(45)[1] + v1 * h))});
+    EXPECT(worst < 1e-12);
+    // a model of another SOURCE on another knot is still refused
+    bool threw = false;
+    try {
+      prob.SetDynamics(problem::DiscretizedModel<examples::Unicycle>(examples::Unicycle()), 3);
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+  }
+  CASE("DiscretizedModel<Model, ExplicitEuler> (integration.hpp:87-104; test/problem/triple_integrator_test.cpp:135-156)");
+  {
+    const std::string src = ReadSource(CARTPOLE_SOURCE_PATH);
+    examples::UserModel euler = examples::UserModel::Euler("cartpole_euler", src, 4, 1);
+    bool threw = false;
+    try {
+      problem::DiscretizedModel<examples::UserModel> wrong(euler);  // compiled for Euler: not an RK4 model
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+      problem::DiscretizedModel<examples::Unicycle, problem::ExplicitEuler> wrong{examples::Unicycle()};
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    problem::Problem prob(N);
+    std::vector<problem::DiscretizedModel<examples::UserModel, problem::ExplicitEuler>> models(
+        N, problem::DiscretizedModel<examples::UserModel, problem::ExplicitEuler>(euler));
+    prob.SetDynamics(models);  // the vector overload, problem.hpp:187-191
+    CartpoleProblem(prob, N, 0.8, h);
+    ilqr::iLQR<4, 1> solver(prob);
+    auto Z = std::make_shared<Trajectory<4, 1>>(N);
+    Z->SetUniformStep(hf);
+    for (int k = 0; k < N; ++k) Z->Control(k)[0] = 0.4;
+    solver.SetTrajectory(Z);
+    solver.Rollout();
+    double xd[4], worst = 0.0;
+    for (int k : {0, 17, 59}) {
+      cartpole_f(Z->State(k), 0.4, xd);
+      for (int i = 0; i < 4; ++i) worst = std::max(worst, std::abs(Z->State(k + 1)[i] - (Z->State(k)[i] + xd[i] * h)));
+    }
+    EXPECT(worst < 1e-13);
+    // [A | B] = Identity(n, n + m) + jac h: column 2 of A is e_0 h + e_2, the B column is (0, 0, 1 / D, -c / (l D)) h
+    solver.UpdateExpansions();
+    const std::vector<double> AB = solver.GetKnotPointFunction(0).GetDynamicsExpansion();
+    EXPECT(AB.size() == 20 && std::abs(AB[0 + 2 * 4] - h) < 1e-15 && std::abs(AB[2 + 2 * 4] - 1.0) < 1e-15);
+    EXPECT(std::abs(AB[2 + 4 * 4] - h / 1.0) < 1e-15 && std::abs(AB[3 + 4 * 4] + h / 0.5) < 1e-15);  // x0 = 0: s = 0, c = 1, D = mc
+  }
+}
+
 // ---- what the facade records by default (cost-to-go, history) and what that costs ------------------------------------
 static void RecordingPolicyTests() {
   CASE("Solve() of a small batch takes the persistent kernel; the step-level BackwardPass() records the cost-to-go");
@@ -444,6 +571,15 @@ static void RecordingPolicyTests() {
     threw = true;  // not recorded by a whole solve unless asked for
   }
   EXPECT(threw);
+  // ... but the read told the solver that its user wants P, p: every later Solve() keeps them, as the reference does
+  solver.SetTrajectory(def.InitialTrajectory());
+  solver.Solve();
+  EXPECT(solver.GetStats().iterations_total == 11 && solver.GetTiming().fused_sweeps == 0);
+  EXPECT(solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient().size() == 3);
+  solver.GetiLQRSolver().SetRecordCostToGo(false);  // explicit: never
+  solver.SetTrajectory(def.InitialTrajectory());
+  solver.Solve();
+  EXPECT(solver.GetTiming().fused_sweeps > 0);
   solver.GetiLQRSolver().SetRecordCostToGo(true);
   solver.SetTrajectory(def.InitialTrajectory());
   solver.Solve();
@@ -466,6 +602,7 @@ int main() {
     ExampleTests();
     UserFunctorTests();
     UserTypeListTests();
+    DynamicsKindTests();
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 100;
