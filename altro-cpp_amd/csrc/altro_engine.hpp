@@ -517,7 +517,12 @@ class Engine final : public EngineBase {
   static constexpr bool kMfmaBackward = n == 3 && m == 2;
   // larger models: one instance per wavefront -- on the 16x16x4 fp64 matrix cores (k_backward_mfma16), or with
   // the matrices in LDS and the products on the vector ALUs (k_backward_coop: ALTRO_HIP_BACKWARD=coop)
-  static constexpr bool kMfma16Backward = n > 4 && n <= 12 && m <= 4;
+  // (n = 4 -- the cart-pole class of user models -- takes the 16x16 tile too while the launch has few instances: one
+  //  instance per wavefront at ~0.4 us per knot against ~1.5 us for the one-lane-per-instance kernel, which only wins on
+  //  throughput once the instances outnumber the SIMDs several times: kMfma16SmallMax.  Decided by the handle's batch,
+  //  not by the instances still active, so that an instance sees the same arithmetic in every sweep of every solve)
+  static constexpr bool kMfma16Backward = n >= 4 && n <= 12 && m <= 4;
+  static constexpr int kMfma16SmallMax = 4096;
   // gain records big enough (m n + m >= 14 elements) that reading K from global memory can pay: see kdg_
   static constexpr bool kKdgEligible = n * m >= 12;
   // rollout inputs from global memory, two knots ahead in three register sets: small records only
@@ -543,7 +548,7 @@ class Engine final : public EngineBase {
       }
     }
     if constexpr (kMfma16Backward) {
-      if (!force_valu_backward_ && !force_coop_backward_ && mfma_offsets_ok_) {
+      if (!force_valu_backward_ && !force_coop_backward_ && mfma_offsets_ok_ && (n > 4 || B_ <= kMfma16SmallMax)) {
         if (A.record_ctg)
           hipLaunchKernelGGL((k_backward_mfma16<T, M, true>), dim3(ninst), dim3(kBlock), 0, cur_, A, d, all);
         else
@@ -1545,7 +1550,8 @@ class Engine final : public EngineBase {
     // chain's), then naps of ~50 us (eight ranks of a node, or the worker threads of libaltro_group.so, share the
     // container's CPU quota with RCCL's proxy threads).  A small batch -- the latency path -- keeps spinning, and so
     // does ALTRO_HIP_HOST_WAIT=spin.
-    const bool nap = host_wait_backoff_ && B_ >= kHostNapMinBatch;
+    const bool nap_ok = host_wait_backoff_ && B_ >= kHostNapMinBatch;
+    bool nap = false;  // (only once the solve has run for kHostNapAfterUs: a 0.3 ms solve of 1024 small problems keeps the spin)
     unsigned spins = 0, naps = 0;
     for (;;) {
       bool any = false, progressed = false;
@@ -1578,6 +1584,8 @@ class Engine final : public EngineBase {
       }
       if (!any) break;
       bool check_streams = false;
+      if (nap_ok && !nap && (spins & 0xff) == 0)
+        nap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostNapAfterUs;
       if (progressed) {
         spins = 0;
         naps = 0;
@@ -1692,6 +1700,7 @@ class Engine final : public EngineBase {
         timing_.launches += 1;
       }
     }
+    if (nap_ok && !nap) nap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostNapAfterUs;
     if (nap && tail_ev_) {
       // the persistent launch runs for milliseconds: wait for it on an event that blocks in the driver (interrupt) instead
       // of spinning in hipStreamSynchronize
@@ -1811,6 +1820,7 @@ class Engine final : public EngineBase {
   // host side of the sweep loop: spin briefly, then nap (see Solve); ALTRO_HIP_HOST_WAIT=spin restores the pure spin
   static constexpr int kHostNapMinBatch = 256;
   static constexpr unsigned kHostSpinsBeforeNap = 400;  // ~10 us of pause instructions
+  static constexpr double kHostNapAfterUs = 500.0;      // a solve shorter than this never naps
   bool host_wait_backoff_ = [] {
     const char* e = std::getenv("ALTRO_HIP_HOST_WAIT");
     return !(e && std::string(e) == "spin");

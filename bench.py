@@ -434,7 +434,7 @@ def measure_other_config(A, P, S, torch, ci, steps, warmup, device_id):
         "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warmup,
         "solved_fraction": round(solved / B, 5),
         "dtype": "f64" if cfg["dtype"] == "F64" else "f64 arithmetic, f32 records (ALTRO_F32)",
-        "dominant_kernel": rl["kernel"], "frac": rl["frac"], "achieved_gbs": rl["achieved"],
+        "dominant_kernel": rl["kernel"], "frac": rl["frac"], "achieved_gbs": rl["achieved"], "compute": rl.get("compute"),
         "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"],
         "all_kernels_frac": rl["all_kernels_frac"], "kernel_wall_ms": rl["kernel_wall_ms"],
         "concurrent_chains": rl["concurrent_chains"], "sweeps": tm["sweeps"], "tail_iterations": tm["fused_sweeps"],
@@ -651,7 +651,7 @@ def main():
     rank_elapsed = [elapsed]
     cdev = "cpu" if host_gather else dev
     if use_dist:
-        mine = torch.tensor([elapsed, host_cpu_cores], dtype=torch.float64, device=cdev)
+        mine = torch.tensor([[elapsed, host_cpu_cores]], dtype=torch.float64, device=cdev)  # (one row per rank)
         allr = torch.empty((world, 2), dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(allr, mine)
         allr = allr.cpu().numpy()

@@ -146,12 +146,12 @@ def test_knot_model_indices_are_validated(A):
 
 
 # ---- GPU: the HIP path against the oracle ------------------------------------------------------------------------------
-def _parity(o, g, xtol=1e-7):
+def _parity(o, g, xtol=1e-7, min_solved=0.9):
     so, sg = o.get_stats(), g.get_stats()
     for f in ("status", "iterations_total", "iterations_outer"):
         assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
     ok = so["status"] == 0
-    assert ok.mean() > 0.9
+    assert ok.mean() > min_solved
     (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
     assert np.allclose(Xg[ok], Xo[ok], rtol=xtol, atol=xtol), np.abs(Xg[ok] - Xo[ok]).max()
     assert np.allclose(Ug[ok], Uo[ok], rtol=10 * xtol, atol=10 * xtol), np.abs(Ug[ok] - Uo[ok]).max()
@@ -221,7 +221,7 @@ def test_discrete_only_model_matches_the_oracle(A, P, hip_make, pend_oracle):
     g = P.pendulum_swing(hip_make, kind, batch=B, goal=goals)
     o = P.pendulum_swing(pend_oracle, kind, batch=B, goal=goals)
     g.solve(); o.solve()
-    so = _parity(o, g)
+    so = _parity(o, g, min_solved=0.8)  # (4 of the 32 swings run into max_iterations_inner on both sides, same schedule)
     print("discrete-only pendulum: iterations", np.unique(so["iterations_total"], return_counts=True))
     Xg, _ = g.get_trajectory()
     ok = so["status"] == 0
