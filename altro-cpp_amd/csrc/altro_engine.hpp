@@ -1345,6 +1345,12 @@ class Engine final : public EngineBase {
         }
       }
     }
+    // candidates of the batched line search: the first 6 trials and the last live one own a slot, deeper winners are
+    // replayed (CandLayout); ALTRO_HIP_CAND_FRONT=19 stores every trial (round 3), 0 replays every accepted trial (tests).
+    // Measured (ms per solve, configs 2 / 3 / 4): front 19: 8.31 / 39.9 / 5.78; 12: 8.15 / 39.5 / 5.75; 8: 8.04 / 38.8 / 5.70;
+    // 6: 7.91 / 38.7 / 5.65; 4: 7.96 / 38.8 / 5.62 (profiles/r04_experiments.txt)
+    A_.cand_front = 6;
+    if (const char* e = std::getenv("ALTRO_HIP_CAND_FRONT")) A_.cand_front = std::max(0, std::min(kLineSearchLanes - 1, atoi(e)));
     if (!s.knot_model.empty()) {
       // per-knot models (Problem::SetDynamics(model, k), problem.hpp:155-166): indices into the source's ALTRO_USER_MODELS
       bool any = false;

@@ -969,7 +969,7 @@ constexpr int kM16Chunk = 32;  // knots of gains buffered in LDS between two bul
 template <class T, class M, bool CTG>
 __global__ __launch_bounds__(kBlock) void k_backward_mfma16(DevArrays<T> A, DevOpts o, int all) {
   constexpr int n = M::n, m = M::m;
-  static_assert(n > 4 && n <= 12 && m >= 1 && m <= 4, "16x16 MFMA backward pass: 4 < n <= 12 (one spare column for the vectors), m <= 4");
+  static_assert(n >= 4 && n <= 12 && m >= 1 && m <= 4, "16x16 MFMA backward pass: 4 <= n <= 12 (one spare column for the vectors), m <= 4");
   using R = Rec<T, n, m>;
   using RS = rec_scalar_t<T, M>;
   using RR = Rec<RS, n, m>;
@@ -2143,6 +2143,27 @@ __global__ __launch_bounds__(kBlock) void k_forward(DevArrays<T> A, const Proble
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // make the cost wave wait for its (scattered, never re-read in the loop) candidate stores at every
 // knot -- and the rollout wave with it.
+// CANDIDATE SCRATCH OF THE BATCHED FORWARD KERNEL (round 4).  Storing the (xbar, ubar) of all 20 speculative trials of every
+// knot -- 81 KB per instance and launch, 331 MB per sweep of 4096 instances -- made k_forward2 the one kernel whose HBM
+// traffic was 11 - 23 x its algorithmic bytes, written at 1.5 - 2.5 TB/s while the knot loops run: the
+// write bandwidth, not the CUs, bounded the throughput phase (more resident workgroups did not help).  What phase 2 reads
+// back is ONE trial: the accepted one -- trial 0 .. 7 in 99.3 % (kTurn90) / 95 % (obstacles) of the accepted steps -- or,
+// when every trial was rejected, the LAST live one (quirk Q6: c_ of the last evaluated candidate).  So only the first
+// `front` trials and the last live trial get a slot (front + 1 slots per knot, 7 for the default front = 6: 28 KB per
+// instance); a deeper winner is REPLAYED by the rollout wave -- the same code on the same inputs, bit-identical -- into the
+// shared last slot before phase 2 (a workgroup-uniform, rare branch).  front >= 19: one slot per trial, never a replay.
+struct CandLayout {
+  int front, last, slots;  // trials [0, front) own slot t; trial `last` (= live trials - 1) and replayed trials use slot `front`
+  ALTRO_DEV CandLayout(int front_, int nlive) {
+    last = nlive - 1;
+    front = front_ < last ? (front_ < 0 ? 0 : front_) : last;  // (front == last: every live trial has its own slot)
+    slots = front + 1;
+  }
+  ALTRO_DEV int store_slot(int t) const { return t < front ? t : (t == last ? front : -1); }   // -1: not stored by the knot loop
+  ALTRO_DEV int read_slot(int t) const { return t < front ? t : front; }
+  ALTRO_DEV bool needs_replay(int t) const { return t >= front && t != last; }
+};
+
 // Phase 2 of the forward pass for the knots k0, k0 + stride, ...: copy the replayed trial (the accepted
 // one, or the last whose rollout succeeded: quirk Q6) out of the candidate scratch, evaluate and store
 // the constraint values it leaves in c_, and -- if accepted -- install it as the new trajectory.
@@ -2163,25 +2184,27 @@ ALTRO_DEV T grad_term(const T* d, const T* u) {
   return gnum / gden;
 }
 
+// `cslots`: candidate slots per knot of the scratch (its knot stride is cslots * (n + m)); the replayed trial sits in
+// slot cand_slot_of(t_replay, ...) -- see CandLayout.
 template <class T, class M, class Ctx>
 ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const Ctx& C, int b, int t_replay, bool accepted,
-                           int k0, int stride, const T* cand_base, unsigned cand_off0, T* sXw = nullptr,
+                           int k0, int stride, const T* cand_base, unsigned cand_off0, int cslot, int cslots, T* sXw = nullptr,
                            T* sUw = nullptr, T* rk = nullptr, const T* sKD = nullptr, int kd_stride = 0, int kd_off = 0) {
   constexpr int n = M::n, m = M::m, nm = n + m;
-  constexpr int LS = kLineSearchLanes;
   using R = Rec<T, n, m>;
   const unsigned Bp = A.Bp;
   const int N = A.N;
+  const unsigned LSnm = (unsigned)cslots * (unsigned)nm;
   T viol = T(0);
   if (t_replay >= 0) {
-    const unsigned rbo = cand_off0 + (unsigned)t_replay * (unsigned)nm;
+    const unsigned rbo = cand_off0 + (unsigned)cslot * (unsigned)nm;
     constexpr int kAhead = 3;  // candidates fetched before the first is used
     for (int kb = k0; kb <= N; kb += kAhead * stride) {
       T xs[kAhead][n], us[kAhead][m];
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) {
         const int k = kb + j * stride;
-        const T* cand = cand_base + (rbo + (unsigned)(k <= N ? k : N) * (unsigned)(LS * nm));
+        const T* cand = cand_base + (rbo + (unsigned)(k <= N ? k : N) * LSnm);
 #pragma unroll
         for (int i = 0; i < n; ++i) xs[j][i] = cand[i];
 #pragma unroll
@@ -2424,7 +2447,7 @@ ALTRO_DEV double from_upper_half(double x) {
 // v_permlane32_swap), bit-identical to the one-knot-at-a-time loop.
 template <class T, class M, bool PAIRED, bool SOFT = false>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
-                            bool valid, T* cand_inst, int* flags, double* gsx, bool grad,
+                            bool valid, T* cand_inst, int cand_front, int* flags, double* gsx, bool grad,
                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
                             double* J0_out = nullptr) {
   constexpr int G = PAIRED ? kSyncFused : 2;
@@ -2435,7 +2458,12 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
   const int half = PAIRED ? (lane >> 5) : 0;
   const int col = PAIRED ? (lane & 31) : lane;           // the rollout-wave lane whose trial this lane follows
   const bool mine = PAIRED ? col < LS : valid;  // (a PAIRED workgroup has exactly one, live, instance)
-  T* const candp = cand_inst + (unsigned)(PAIRED ? col : lane % LS) * (unsigned)nm;
+  // the candidate slot of this lane's trial: PAIRED (candidates in LDS) one per trial; batched sweeps: CandLayout
+  const CandLayout CL(PAIRED ? LS : cand_front, o.line_search_max_iterations < LS ? o.line_search_max_iterations : LS);
+  const int cslot = PAIRED ? col : CL.store_slot(lane % LS);
+  const unsigned cstride = (unsigned)(PAIRED ? LS : CL.slots) * (unsigned)nm;
+  const bool stores = mine && cslot >= 0;
+  T* const candp = cand_inst + (unsigned)(cslot >= 0 ? cslot : 0) * (unsigned)nm;
   BoundMasks bm;
   double gs = 0.0;
   // PAIRED (persistent kernel): this wave also sums the running cost of the current trajectory, J0 = costs_.sum() in
@@ -2488,8 +2516,8 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
       gs += r;
       if (PAIRED) gs += from_upper_half(r);
     }
-    if (mine && k <= N) {  // idle lanes must not touch the candidates
-      T* cand = candp + (unsigned)k * (unsigned)(LS * nm);
+    if (stores && k <= N) {  // idle lanes (and trials without a slot) must not touch the candidates
+      T* cand = candp + (unsigned)k * cstride;
 #pragma unroll
       for (int i = 0; i < n; ++i) cand[i] = xb[i];
 #pragma unroll
@@ -2905,6 +2933,18 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     for (int i = 0; i < t; ++i) alpha /= T(o.line_search_decrease_factor);
   }
 
+  // candidate scratch of the batched kernel: which trials own a slot (CandLayout); FUSED keeps all LS in LDS
+  const CandLayout CL(FUSED ? LS : A.cand_front, ls_max < LS ? ls_max : LS);
+  const unsigned cand_inst_off = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)CL.slots * (unsigned)nm;
+  // behind barrier S: does an instance of this workgroup need its winner replayed?  (Every wave holds the same
+  // (valid, grp) pattern over its lanes and reads the same selection words: the answer is workgroup-uniform.)
+  auto wg_replays = [&]() __attribute__((always_inline)) -> bool {
+    if constexpr (FUSED) return false;
+    const int* selr = reinterpret_cast<const int*>(xch);
+    const int trep = valid ? selr[2 * grp] : -1;
+    return __ballot(trep >= 0 && CL.needs_replay(trep)) != 0ull;
+  };
+
   // Phase 2 of the persistent kernel (one instance per workgroup): the knots of the instance over all 64 lanes of the
   // three forward waves -- one knot per lane for N = 100 instead of two per line-search lane -- each knot's copy and
   // constraint evaluation exactly as in the batched kernels; returns the wave's share of the violation (a maximum:
@@ -2914,8 +2954,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     const unsigned Bp = A.Bp;
     (void)Bp;
     CtxL<T> CF(A, bF, sPool, sIp, sLam, sPen);  // (one instance per workgroup: the same LDS block for every lane)
-    T v = forward_phase2<T, M>(A, pdg, CF, bF, t_rep, acc, wi * kBlock + lane, kFwdWaves * kBlock, sCand, 0u, sX, sU, nullptr,
-                               sKD, kKdStride, kKdOff);
+    T v = forward_phase2<T, M>(A, pdg, CF, bF, t_rep, acc, wi * kBlock + lane, kFwdWaves * kBlock, sCand, 0u, t_rep, LS, sX, sU,
+                               nullptr, sKD, kKdStride, kKdOff);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max_(v, __shfl_xor(v, off));
     return v;
@@ -2963,7 +3003,12 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     };
     const long long st_w0 = ALTRO_STAMP_T0();
     long long cons_look = 0;  // (software synchronisation) the consumers' progress words as of the last publish
-    auto knot = [&](int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
+    // (REPLAY -- batched kernel only, see CandLayout: the same knot for the trial phase 2 is about to read, whose depth owned
+    //  no candidate slot: nothing is handed to the consumer waves, lane t = 0 of the instance writes the shared slot)
+    T* rep_cand = nullptr;  // this lane's candidate slot of knot 0 in a replay (null: the lane stores nothing)
+    const unsigned rep_stride = (unsigned)CL.slots * (unsigned)nm;
+    auto knot = [&](auto replay_tag, int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
+      constexpr bool REPLAY = decltype(replay_tag)::value;
       T ub[m], xn[n];
       fetch(k + (RG ? kRgAhead : 1), nxt);
 #pragma unroll
@@ -2973,13 +3018,23 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         for (int l = 0; l < n; ++l) sacc += (T)cur.kd[R::oK + i + l * m] * (xb[l] - cur.xk[l]);
         ub[i] = cur.uk[i] + sacc + (T)cur.kd[R::oD + i] * alpha;
       }
-      T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
-      // (software synchronisation: the slots of stretch j are those of stretch j - 2, which both consumers must have read)
-      if (SOFT && (k & (G - 1)) == 0 && k >= 2 * G) sy.await_consumed(k / G - 2, cons_look);
+      if constexpr (REPLAY) {
+        if (rep_cand) {
+          T* cand = rep_cand + (unsigned)k * rep_stride;
 #pragma unroll
-      for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
+          for (int i = 0; i < n; ++i) cand[i] = xb[i];
 #pragma unroll
-      for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
+          for (int i = 0; i < m; ++i) cand[n + i] = ub[i];
+        }
+      } else {
+        T* slot = xch + fwd_slot(k, G) * (nm * kBlock);
+        // (software synchronisation: the slots of stretch j are those of stretch j - 2, which both consumers must have read)
+        if (SOFT && (k & (G - 1)) == 0 && k >= 2 * G) sy.await_consumed(k / G - 2, cons_look);
+#pragma unroll
+        for (int i = 0; i < n; ++i) slot[i * kBlock + lane] = xb[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) slot[(n + i) * kBlock + lane] = ub[i];
+      }
       if constexpr (M::kHasCarriedTrig) {
         // sin / cos of the heading ride along from the previous step (see rk4_fused_sc)
         if ((k % M::kTrigResync) == 0) sincos_(xb[2], &trig_s, &trig_c);
@@ -2989,34 +3044,39 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) xb[i] = xn[i];
-      if (producer_syncs_after(k, N, G)) {
-        sy.publish(k / G);
-        if (SOFT) cons_look = sy.look_consumed();
+      if constexpr (!REPLAY) {
+        if (producer_syncs_after(k, N, G)) {
+          sy.publish(k / G);
+          if (SOFT) cons_look = sy.look_consumed();
+        }
       }
     };
-    if constexpr (RG && kRgAhead == 2) {
-      // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
-      Nominal q0, q1, q2;
-      fetch(0, q0);
-      fetch(1, q1);
-      int k = 0;
-      for (; k + 2 < N; k += 3) {
-        knot(k, q0, q2);
-        knot(k + 1, q1, q0);
-        knot(k + 2, q2, q1);
+    auto all_knots = [&](auto replay_tag) __attribute__((always_inline)) {
+      if constexpr (RG && kRgAhead == 2) {
+        // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
+        Nominal q0, q1, q2;
+        fetch(0, q0);
+        fetch(1, q1);
+        int k = 0;
+        for (; k + 2 < N; k += 3) {
+          knot(replay_tag, k, q0, q2);
+          knot(replay_tag, k + 1, q1, q0);
+          knot(replay_tag, k + 2, q2, q1);
+        }
+        if (k < N) knot(replay_tag, k, q0, q2);
+        if (k + 1 < N) knot(replay_tag, k + 1, q1, q0);
+      } else {
+        Nominal qa, qb;
+        fetch(0, qa);
+        int k = 0;
+        for (; k + 1 < N; k += 2) {
+          knot(replay_tag, k, qa, qb);
+          knot(replay_tag, k + 1, qb, qa);
+        }
+        if (k < N) knot(replay_tag, k, qa, qb);
       }
-      if (k < N) knot(k, q0, q2);
-      if (k + 1 < N) knot(k + 1, q1, q0);
-    } else {
-      Nominal qa, qb;
-      fetch(0, qa);
-      int k = 0;
-      for (; k + 1 < N; k += 2) {
-        knot(k, qa, qb);
-        knot(k + 1, qb, qa);
-      }
-      if (k < N) knot(k, qa, qb);
-    }
+    };
+    all_knots(std::false_type{});
     // final hand-off: x_N
     T* slot = xch + fwd_slot(N, G) * (nm * kBlock);
     if (SOFT && (N & (G - 1)) == 0 && N >= 2 * G) sy.await_consumed(N / G - 2, cons_look);
@@ -3028,6 +3088,35 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     sy.pass_a();        // barrier A (auxiliary wave -> cost wave)
     // phase 2 is shared by all waves: wait for the selection, take every third block of knots
     sy.await_s();  // barrier S
+    if constexpr (!FUSED) {
+      // REPLAY (CandLayout): the trial phase 2 will read had no candidate slot -- a winner deeper than `front`, rare -- so
+      // the rollout runs once more for it.  All lanes of the instance follow the same trial (same step length, same
+      // operations as the lane that ran it first: same bits), lane t = 0 writes the shared slot; instances of this
+      // workgroup that need no replay ride along without storing.  The other two waves wait at the extra barrier.
+      const int* selr = reinterpret_cast<const int*>(xch);
+      const int trep = valid ? selr[2 * grp] : -1;
+      const bool need = trep >= 0 && CL.needs_replay(trep);
+      if (__ballot(need) != 0ull) {
+        if (need) {
+          alpha = T(1);
+          for (int i = 0; i < trep; ++i) alpha /= T(o.line_search_decrease_factor);
+        }
+        T x0r[R::nP];
+        load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x0r);
+#pragma unroll
+        for (int i = 0; i < n; ++i) xb[i] = x0r[i];
+        trig_s = T(0);
+        trig_c = T(1);
+        rep_cand = (need && t == 0) ? A.trial + (cand_inst_off + (unsigned)CL.front * (unsigned)nm) : nullptr;
+        all_knots(std::true_type{});
+        if (rep_cand) {
+          T* cand = rep_cand + (unsigned)N * rep_stride;
+#pragma unroll
+          for (int i = 0; i < n; ++i) cand[i] = xb[i];
+        }
+        __syncthreads();  // (drains the stores: s_waitcnt vmcnt(0) in front of the barrier) -- "R"
+      }
+    }
     ALTRO_STAMP_ADD(1, st_w0b);
     const long long st_w0c = ALTRO_STAMP_T0();
     {
@@ -3040,10 +3129,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if (lane == 0) vpart[0] = viol;
       } else if (valid) {
         CtxL<T> C0(A, b, sPool, sIp, sLam, sPen);
-        viol = forward_phase2<T, M>(A, pdg, C0, b, sel[2 * grp], sel[2 * grp + 1] != 0, t, kFwdWaves * LS,
-                                    FUSED ? sCand : A.trial,
-                                    FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm,
-                                    FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
+        const int trep = sel[2 * grp];
+        viol = forward_phase2<T, M>(A, pdg, C0, b, trep, sel[2 * grp + 1] != 0, t, kFwdWaves * LS, FUSED ? sCand : A.trial,
+                                    cand_inst_off, CL.read_slot(trep), CL.slots, FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk,
+                                    sKD, kKdStride, kKdOff);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart[grp] = vm;
@@ -3057,13 +3146,13 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   // candidate scratch [k][trial][x|u]: in global memory (instance-major), or -- FUSED, one instance per
   // workgroup and per CU -- in LDS, so that the knot loop issues no global store at all
   T* const cand_base = FUSED ? sCand : A.trial;
-  const unsigned cand_off0 = FUSED ? 0u : (unsigned)b * (unsigned)(N + 1) * (unsigned)LS * (unsigned)nm;
+  const unsigned cand_off0 = cand_inst_off;
   if (wave == 2) {
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
     const long long st_w2 = ALTRO_STAMP_T0();
     double J0_run = 0.0;
-    aux_wave_run<T, M, FUSED, SOFT>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, flags, gsx,
-                                    grad_in_loop, sy, FUSED ? sCost : nullptr, &J0_run);
+    aux_wave_run<T, M, FUSED, SOFT>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, A.cand_front, flags,
+                                    gsx, grad_in_loop, sy, FUSED ? sCost : nullptr, &J0_run);
     if (FUSED && lane == 0) {
       // J0 of the expansion step and, on the first iteration of an inner solve, stats_.initial_cost (ilqr.hpp:298);
       // ff[4] / ff[5]: LDS mirrors of initial_cost / need_init_cost (phase 3 sets ff[5] when a new inner solve begins)
@@ -3082,6 +3171,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     ALTRO_STAMP_ADD(7, st_w2);
     sy.signal_a();  // barrier A
     sy.await_s();   // barrier S
+    if (wg_replays()) __syncthreads();  // barrier R: the rollout wave has rewritten the shared candidate slot
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart2 = xch + 12;
@@ -3090,9 +3180,10 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if (lane == 0) vpart2[0] = viol;
       } else if (valid) {
         CtxL<T> C2(A, b, sPool, sIp, sLam, sPen);
-        const T viol = forward_phase2<T, M>(A, pdg, C2, b, sel[2 * grp], sel[2 * grp + 1] != 0, t + 2 * LS,
-                                            kFwdWaves * LS, cand_base, cand_off0, FUSED ? sX : nullptr,
-                                            FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
+        const int trep = sel[2 * grp];
+        const T viol = forward_phase2<T, M>(A, pdg, C2, b, trep, sel[2 * grp + 1] != 0, t + 2 * LS, kFwdWaves * LS, cand_base,
+                                            cand_off0, CL.read_slot(trep), CL.slots, FUSED ? sX : nullptr, FUSED ? sU : nullptr,
+                                            rk, sKD, kKdStride, kKdOff);
         T vm = viol;
         for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
         if (t == 0) vpart2[grp] = vm;
@@ -3221,6 +3312,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
   }
   sy.signal_s();  // barrier S: selection visible, candidate stores of this wave drained
+  if (wg_replays()) __syncthreads();  // barrier R (see the rollout wave)
   ALTRO_STAMP_ADD(4, st_w1b);
   const long long st_w1c = ALTRO_STAMP_T0();
   T viol = T(0);
@@ -3229,7 +3321,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     viol = phase2_all_lanes(1, __builtin_amdgcn_readfirstlane(t_replay), __builtin_amdgcn_readfirstlane(accepted ? 1 : 0) != 0);
   } else if (valid) {
     viol = forward_phase2<T, M>(A, pdg, C, b, t_replay, accepted, t + LS, kFwdWaves * LS, cand_base, cand_off0,
-                                FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride, kKdOff);
+                                CL.read_slot(t_replay), CL.slots, FUSED ? sX : nullptr, FUSED ? sU : nullptr, rk, sKD, kKdStride,
+                                kKdOff);
     T vm = viol;
     for (int j = 0; j < LS; ++j) vm = max_(vm, __shfl(viol, grp * LS + j));
     viol = vm;

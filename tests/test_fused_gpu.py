@@ -132,3 +132,44 @@ def test_launch_variants_are_bit_identical(tmp_path, switch):
     a, b = run("default", {}), run("switch", switch)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+_SCRIPT_CAND = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+for name, s in (("turn90", P.batch_turn90(make, batch=1024, seed=P.SEED_BASE + 3)),
+                ("obstacles32", P.batch_three_obstacles(make, batch=768, dtype=A.F32)),
+                ("quad12", P.batch_quadrotor12(make, batch=96, dtype=A.F32))):
+    s.solve()
+    X, U = s.get_trajectory()
+    st = s.get_stats()
+    out[name + "_X"] = X; out[name + "_U"] = U; out[name + "_lam"] = s.get_duals(); out[name + "_c"] = s.get_constraint_values()
+    for f in st.dtype.names:
+        out[name + "_st_" + f] = st[f]
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_candidate_layouts_are_bit_identical(tmp_path):
+    """CandLayout (altro_kernels.hpp): the batched forward kernel keeps a candidate slot for the first `front` line-search
+    trials and the last live one, and REPLAYS a deeper winner.  front = 19 stores every trial (the round-3 layout); 8 is the
+    (6 is the default); 2 and 0 replay most / every accepted step -- every layout must produce the same bits (trajectories,
+    multipliers, the stale c_ of quirk Q6, every statistic), with and without the persistent tail kernel."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, env_extra):
+        out = str(tmp_path / f"cand_{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_CAND % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
+        return np.load(out)
+    ref = run("all", {"ALTRO_HIP_CAND_FRONT": "19", "ALTRO_HIP_NO_FUSED_SWEEP": "1"})
+    assert (ref["turn90_st_status"] == 0).mean() > 0.9 and ref["obstacles32_st_iterations_total"].max() > 100
+    for tag, env in (("6", {"ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("8", {"ALTRO_HIP_CAND_FRONT": "8", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("2", {"ALTRO_HIP_CAND_FRONT": "2", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}),
+                     ("0", {"ALTRO_HIP_CAND_FRONT": "0", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("default", {})):
+        got = run(tag, env)
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (tag, k)
