@@ -2270,7 +2270,11 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 // G = knots per barrier: 2 in the batched sweeps (kFwdSlots = 4 slots), kSyncFused in the persistent kernel, whose
 // knot loop runs in lock step with the speculative backward pass of the fourth wave: the longer the stretch between
 // two barriers, the less the slowest of four waves per stretch costs (and the fewer barriers the recursion pays).
-constexpr int kFwdSlots = 4;
+#ifndef ALTRO_SYNC_BATCHED
+#define ALTRO_SYNC_BATCHED 2  // knots per workgroup barrier in the batched forward kernel (A/B builds: 4)
+#endif
+constexpr int kSyncBatched = ALTRO_SYNC_BATCHED;
+constexpr int kFwdSlots = 2 * kSyncBatched;
 ALTRO_DEV bool producer_syncs_after(int k, int N, int G = 2) { return (k & (G - 1)) == G - 1 || k == N; }
 ALTRO_DEV bool consumer_syncs_before(int k, int G = 2) { return (k & (G - 1)) == 0; }
 ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
@@ -2450,7 +2454,7 @@ ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride
                             bool valid, T* cand_inst, int cand_front, int* flags, double* gsx, bool grad,
                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
                             double* J0_out = nullptr) {
-  constexpr int G = PAIRED ? kSyncFused : 2;
+  constexpr int G = PAIRED ? kSyncFused : kSyncBatched;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   const bool check = o.check_forwardpass_bounds != 0;
@@ -2902,7 +2906,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T* sIp = sPen + L.rowsP();
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
-  constexpr int G = FUSED ? kSyncFused : 2;  // knots per workgroup barrier of the knot loop (2 G hand-off slots)
+  constexpr int G = FUSED ? kSyncFused : kSyncBatched;  // knots per workgroup barrier of the knot loop (2 G hand-off slots)
   int* flags = reinterpret_cast<int*>(xch + 2 * G * nm * kBlock);  // [2][64]: ok, status of each trial
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {

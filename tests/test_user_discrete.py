@@ -54,6 +54,15 @@ def _with_model(s, kind, knot_models):
     return s
 
 
+def _euler_answer(h):
+    """jac_ans of TripleIntegratorTest.EulerIntegration (tests/golden/reference_constants.json, K26)."""
+    import json
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constants.json")))["K26_explicit_euler_jacobian"]
+    assert float(np.float32(k["h"])) == h
+    num = lambda rows: np.array([[h if v == "h" else float(v) for v in r] for r in rows])  # noqa: E731
+    return num(k["A_rows"]), num(k["B_rows"])
+
+
 # ---- CPU: the oracle -----------------------------------------------------------------------------------------------
 def test_explicit_euler_known_answer_on_the_oracle(A, P, tieuler_oracle):
     """test/problem/triple_integrator_test.cpp:135-156 (TripleIntegratorTest.EulerIntegration): xnext = x + f(x, u) h and
@@ -70,12 +79,7 @@ def test_explicit_euler_known_answer_on_the_oracle(A, P, tieuler_oracle):
     X, _ = o.get_trajectory()
     h = float(np.float32(0.1))
     e = o.get_expansion(0)
-    Aans = np.eye(6)
-    Bans = np.zeros((6, 2))
-    for i in range(2):
-        Aans[i, i + 2] = h
-        Aans[i + 2, i + 4] = h
-        Bans[i + 4, i] = h
+    Aans, Bans = _euler_answer(h)
     assert np.allclose(e["A"][0], Aans, rtol=1e-12, atol=0) and np.allclose(e["B"][0], Bans, rtol=1e-12, atol=0)
     f0 = np.concatenate([x0[2:4], x0[4:6], U[0]])
     assert np.allclose(X[0, 1], x0 + f0 * h, rtol=1e-12, atol=1e-15)
@@ -173,12 +177,7 @@ def test_explicit_euler_known_answer_on_the_gpu(A, P, hip_make):
     g.update_expansions()
     h = float(np.float32(0.1))
     e = g.get_expansion(3)
-    Aans = np.eye(6)
-    Bans = np.zeros((6, 2))
-    for i in range(2):
-        Aans[i, i + 2] = h
-        Aans[i + 2, i + 4] = h
-        Bans[i + 4, i] = h
+    Aans, Bans = _euler_answer(h)
     assert np.allclose(e["A"][0], Aans, rtol=1e-12, atol=0) and np.allclose(e["B"][0], Bans, rtol=1e-12, atol=0)
     X, _ = g.get_trajectory()
     assert np.allclose(X[0, 1], x0 + np.concatenate([x0[2:4], x0[4:6], U[0]]) * h, rtol=1e-12, atol=1e-15)
