@@ -206,7 +206,7 @@ void altro_default_options(altro_options* o) {  // altro/common/solver_options.h
   o->check_forwardpass_bounds = 1;
   o->state_max = 1e8;
   o->control_max = 1e8;
-  o->line_search_max_iterations = 20;
+  o->line_search_max_iterations = kLineSearchLanes < 20 ? kLineSearchLanes : 20;  // (20; fewer only in experimental ALTRO_LS_LANES builds)
   o->line_search_lower_bound = 1e-8;
   o->line_search_upper_bound = 10.0;
   o->line_search_decrease_factor = 2;

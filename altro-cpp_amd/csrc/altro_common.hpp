@@ -14,7 +14,10 @@ namespace altro_hip {
 constexpr int kMaxConPerKnot = 4;  // constraints attached to one knot point
 constexpr int kMaxClasses = 8;     // distinct (cost, constraint list) combinations over the knots
 constexpr int kMaxCostGroups = 8;
-constexpr int kLineSearchLanes = 20;  // speculative line-search trials evaluated side by side
+#ifndef ALTRO_LS_LANES
+#define ALTRO_LS_LANES 20  // (experimental builds: 10 -- six instances per wavefront, only with line_search_max_iterations <= 10)
+#endif
+constexpr int kLineSearchLanes = ALTRO_LS_LANES;  // speculative line-search trials evaluated side by side
 constexpr int kHistFields = 8;
 constexpr int kMaxRuns = 16;  // maximal runs of consecutive knots sharing one class
 constexpr int kMaxFastCircles = 3;  // circles of one constraint that the specialised cost-wave layouts keep in registers

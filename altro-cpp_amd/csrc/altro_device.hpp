@@ -261,6 +261,7 @@ struct DevArrays {
   // 179-180): nullptr for a uniform step and a time-invariant model (the hot kernels then use ProblemDesc::hstep);
   // set by altro_set_steps / altro_set_times or by a time-varying user model -- see Engine::knot_times_
   const float *hk, *tk;
+  int xcd_remap;          // workgroup order of k_forward2 / k_backward_mfma: neighbouring instances on one XCD (xcd_block)
   int cand_front;         // k_forward2: leading line-search trials that own a candidate slot (CandLayout, altro_kernels.hpp)
   const int* knot_model;  // model of the source's ALTRO_USER_MODELS list that knot k uses (Problem::SetDynamics(model, k)); null: 0
 };

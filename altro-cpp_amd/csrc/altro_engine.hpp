@@ -1351,6 +1351,8 @@ class Engine final : public EngineBase {
     // 6: 7.91 / 38.7 / 5.65; 4: 7.96 / 38.8 / 5.62 (profiles/r04_experiments.txt)
     A_.cand_front = 6;
     if (const char* e = std::getenv("ALTRO_HIP_CAND_FRONT")) A_.cand_front = std::max(0, std::min(kLineSearchLanes - 1, atoi(e)));
+    A_.xcd_remap = 1;  // (ALTRO_HIP_XCD_REMAP=0: workgroup i takes slot block i, round 3)
+    if (const char* e = std::getenv("ALTRO_HIP_XCD_REMAP")) A_.xcd_remap = atoi(e) != 0;
     if (!s.knot_model.empty()) {
       // per-knot models (Problem::SetDynamics(model, k), problem.hpp:155-166): indices into the source's ALTRO_USER_MODELS
       bool any = false;

@@ -91,6 +91,19 @@ ALTRO_DEV int instance_of_slot(const DevArrays<T>& A, int idx, int all) {
   return A.act_list ? A.act_list[idx] : idx;
 }
 
+// XCD-AWARE WORKGROUP ORDER (round 4).  The hardware hands workgroup i of a launch to XCD i % 8, each XCD with an L2 of
+// its own.  Neighbouring instances share cache lines -- the constraint rows are [row][b] with 8-byte elements (16
+// instances per 128-byte line), X / U / gain records hold 4 / 8 / 2 instances per line -- so with the natural order the
+// five or six workgroups that cover one line sit on as many XCDs and every one of them pulls the line through its own L2
+// (and writes its own partial copy back).  The remap gives XCD x the x-th contiguous eighth of the slots: neighbours meet
+// in one L2.  A bijection on the first 8 * (nblocks / 8) blocks; the ragged tail keeps its index.
+ALTRO_DEV int xcd_block(int bid, int nblocks, int on) {
+  constexpr int kXcd = 8;
+  const int per = nblocks / kXcd;
+  if (!on || bid >= per * kXcd) return bid;
+  return (bid % kXcd) * per + bid / kXcd;
+}
+
 template <class T>
 ALTRO_DEV const KnotClass& class_of_knot(const DevArrays<T>& A, const ProblemDesc* pd, int k, int* rowbase) {
   *rowbase = A.knot_rowbase[k];
@@ -934,7 +947,8 @@ template <class T, class M, bool CTG>
 __global__ __launch_bounds__(kBlock) void k_backward_mfma(DevArrays<T> A, DevOpts o, int all) {
   using R = Rec<T, M::n, M::m>;
   __shared__ double sKD[kBwdChunk * 4 * R::KP + kBlock];  // + one junk slot per lane
-  backward_mfma_body<T, M, CTG, false>(A, o, all, threadIdx.x, blockIdx.x * 4, sKD, nullptr, 0, nullptr);
+  backward_mfma_body<T, M, CTG, false>(A, o, all, threadIdx.x, xcd_block((int)blockIdx.x, (int)gridDim.x, A.xcd_remap) * 4, sKD, nullptr, 0,
+                                       nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2740,7 +2754,8 @@ enum KdMode { kKdNone = 0, kKdFull = 1, kKdFeedforward = 2 };
 template <class T, class M>
 ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, const FwdLds<T>& L, unsigned char* smem_raw,
                               T* sPool, int per_wave, int all, int tt, int nthreads, int kd_mode,
-                              bool with_traj = true) {
+                              bool with_traj = true, int bid = -1) {
+  if (bid < 0) bid = blockIdx.x;
   const bool with_kd = kd_mode != kKdNone;
   constexpr int LS = kLineSearchLanes;
   using R = Rec<T, M::n, M::m>;
@@ -2769,7 +2784,7 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
       int bgs[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        bgs[g] = g < per_wave ? instance_of_slot(A, blockIdx.x * per_wave + g, all) : -1;
+        bgs[g] = g < per_wave ? instance_of_slot(A, bid * per_wave + g, all) : -1;
         if (bgs[g] < 0) continue;
         const int b = bgs[g];  // RECP / SOA address this instance
         auto ldrec = [&](const T* src, int per, int cnt, int EP, int vi) -> V {
@@ -2885,7 +2900,9 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const int lane = threadIdx.x & 63;
   const int grp = lane / LS;
   const int t = lane - grp * LS;
-  const int b0 = (grp < per_wave) ? instance_of_slot(A, blockIdx.x * per_wave + grp, all) : -1;
+  // (batched kernel: the workgroups that share cache lines of the instance-minor arrays run on one XCD, see xcd_block)
+  const int bid = FUSED ? (int)blockIdx.x : xcd_block((int)blockIdx.x, (int)gridDim.x, A.xcd_remap);
+  const int b0 = (grp < per_wave) ? instance_of_slot(A, bid * per_wave + grp, all) : -1;
   const int N = A.N;
   const bool valid = b0 >= 0;
   if (__ballot(valid) == 0ull) return;  // every wave takes the same decision
@@ -2911,7 +2928,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
     forward2_stage<T, M>(A, pd, L, smem_raw, sPool, per_wave, all, threadIdx.x, kFwdWaves * kBlock,
-                         RG ? kKdNone : (KDG ? kKdFeedforward : kKdFull), !RG);
+                         RG ? kKdNone : (KDG ? kKdFeedforward : kKdFull), !RG, bid);
     __syncthreads();
   }
 

@@ -109,3 +109,59 @@ def test_perf_driver_shards_through_the_facade_group():
     lines = [l for l in r.stdout.splitlines() if "GPU(s) x 512 instances" in l]
     assert len(lines) == 2 and all("records match the per-solver statistics" in l for l in lines)
     assert "trajectories match the per-solver ones" in r.stdout
+
+
+@pytest.mark.gpu
+def test_group_reads_the_handles_dimensions_and_rejects_mismatches(A, P, hip_make):
+    """the gather buffers are sized from what the HANDLE says (altro_get_desc), so a caller-supplied batch or
+    (n, m, N) that disagrees is refused instead of letting the pack kernels write past the group's buffers."""
+    lib = _lib()
+    core = A.load_library()
+    s = P.batch_turn90(hip_make, batch=96)
+    d = A.Desc()
+    assert core.altro_get_desc(s._h, ctypes.byref(d)) == 0
+    assert (d.n, d.m, d.N, d.batch, d.device_id) == (3, 2, 100, 96, 0)
+    g = ctypes.c_void_p()
+    dev = (ctypes.c_int * 1)(0)
+    assert lib.altro_group_create(dev, 1, ctypes.byref(g)) == 0, lib.altro_group_last_error(None)
+    try:
+        assert lib.altro_group_attach(g, 0, s._h, 64) != 0 and b"created with batch 96" in lib.altro_group_last_error(g)
+        assert lib.altro_group_attach(g, 0, s._h, 96) == 0
+        s.solve()
+        assert lib.altro_group_gather(g) == 0, lib.altro_group_last_error(g)
+        # trajectories: the dimensions must be the handle's
+        assert lib.altro_group_gather_trajectories(g, 3, 2, 50) != 0 and b"has (3, 2, 100)" in lib.altro_group_last_error(g)
+        assert lib.altro_group_gather_trajectories(g, 3, 2, 100) == 0, lib.altro_group_last_error(g)
+    finally:
+        lib.altro_group_destroy(g)
+
+
+@pytest.mark.gpu
+def test_group_solve_does_not_spin_a_core_per_handle(A, P, hip_make):
+    """while altro_group_solve_al waits for a 4096-instance solve (8 ms: batched sweeps, then the
+    persistent tail) the process -- the caller's polling thread plus the handle's worker thread -- uses well under one
+    core: the sweep loop naps once the solve has run 0.5 ms, the tail is awaited on a blocking-sync event, the group
+    polls its parts with a sleeping poll."""
+    import time
+    lib = _lib()
+    s = P.batch_turn90(hip_make, batch=4096, seed=P.SEED_BASE + 3)
+    s.num_constraints()
+    g = ctypes.c_void_p()
+    dev = (ctypes.c_int * 1)(0)
+    assert lib.altro_group_create(dev, 1, ctypes.byref(g)) == 0, lib.altro_group_last_error(None)
+    try:
+        assert lib.altro_group_attach(g, 0, s._h, 4096) == 0
+        for _ in range(2):  # warm-up
+            s.reset_trajectory()
+            assert lib.altro_group_solve_al(g) == 0, lib.altro_group_last_error(g)
+        w0, c0 = time.perf_counter(), time.process_time()
+        reps = 10
+        for _ in range(reps):
+            s.reset_trajectory()
+            assert lib.altro_group_solve_al(g) == 0, lib.altro_group_last_error(g)
+        wall, cpu = time.perf_counter() - w0, time.process_time() - c0
+        print(f"group solve of 4096 instances: {1e3 * wall / reps:.2f} ms per solve, {cpu / wall:.2f} cores")
+        assert cpu / wall < 1.0
+        assert s.get_timing()["host_naps"] > 0
+    finally:
+        lib.altro_group_destroy(g)
