@@ -575,7 +575,10 @@ class Engine final : public EngineBase {
   // of one instance's read-only block (X, U, K, d, lambda, rho); see k_forward.
   void LaunchForward(const DevArrays<T>& A, const DevOpts& d, int mode, int all, int ninst, int ninst_all_chains = -1) {
     PoisonLds();
-    if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes && !A.hk) {
+    // (per-knot steps / times / models: the three-wave kernel takes them for every model without a hand-fused RK4 --
+    //  user models, the triple integrator, the 12-state model; the unicycle's fused rollout keeps ONE step as a loop
+    //  invariant and goes to k_forward)
+    if (fwd_lds_bytes_ > 0 && d.line_search_max_iterations <= kLineSearchLanes && (!A.hk || !M::kHasFusedRk4)) {
       // two-wave pipeline (rollout wave + cost wave), inputs staged in LDS.  When the instances left
       // would not even fill the CUs one by one, each gets a workgroup of its own: the prologue and the
       // epilogue of the kernel (staging, winner copy) shrink with the instances per workgroup.

@@ -3060,6 +3060,11 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         // sin / cos of the heading ride along from the previous step (see rk4_fused_sc)
         if ((k % M::kTrigResync) == 0) sincos_(xb[2], &trig_s, &trig_c);
         M::template rk4_fused_sc<T, false>(xb, ub, hh, xn, trig_s, trig_c);
+      } else if constexpr (model_knot_path<M>::value || !M::kHasFusedRk4) {
+        // (round 4: per-knot steps, times and models -- Trajectory::SetStep / SetTime, time-varying or discrete user
+        //  dynamics, a model per knot -- run on this kernel too: three wave-uniform scalar loads per knot.  Models with a
+        //  hand-fused RK4 keep one step as a loop invariant; the engine sends their per-knot trajectories to k_forward.)
+        discrete_step<T, M>(xb, ub, A.hk ? T(A.hk[k]) : hh, xn, time_of(A, k), model_of(A, k));
       } else {
         discrete_step<T, M>(xb, ub, hh, xn);
       }
