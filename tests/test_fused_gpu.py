@@ -169,7 +169,11 @@ def test_candidate_layouts_are_bit_identical(tmp_path):
     ref = run("all", {"ALTRO_HIP_CAND_FRONT": "19", "ALTRO_HIP_NO_FUSED_SWEEP": "1"})
     assert (ref["turn90_st_status"] == 0).mean() > 0.9 and ref["obstacles32_st_iterations_total"].max() > 100
     for tag, env in (("6", {"ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("8", {"ALTRO_HIP_CAND_FRONT": "8", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("2", {"ALTRO_HIP_CAND_FRONT": "2", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}),
-                     ("0", {"ALTRO_HIP_CAND_FRONT": "0", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("default", {})):
+                     ("0", {"ALTRO_HIP_CAND_FRONT": "0", "ALTRO_HIP_NO_FUSED_SWEEP": "1"}), ("default", {}),
+                     # ... and with LDS and the candidate buffer poisoned before every kernel: a replayed winner's slot is
+                     # really rewritten before phase 2 reads it, an unwritten slot would compute with NaN words
+                     ("0_poisoned", {"ALTRO_HIP_CAND_FRONT": "0", "ALTRO_HIP_NO_FUSED_SWEEP": "1", "ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"}),
+                     ("6_poisoned", {"ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"})):
         got = run(tag, env)
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (tag, k)
