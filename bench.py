@@ -554,6 +554,9 @@ def main():
         if args.dist_backend != "gloo":
             raise SystemExit("--share-devices needs --dist-backend gloo (RCCL refuses two ranks on one device)")
         local_rank = local_rank % torch.cuda.device_count()
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible): --gpus N needs N "
+                         f"GPUs on this node (tests: --dist-backend gloo --share-devices lets the ranks share one)")
     torch.cuda.set_device(local_rank)
 
     cfg = CONFIGS[args.config]
