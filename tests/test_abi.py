@@ -128,3 +128,14 @@ def test_get_trajectory_fills_the_callers_buffers(A, P, oracle_make):
         s.get_trajectory(np.zeros(X.shape, dtype=np.float32), U2)
     with pytest.raises(ValueError):
         s.get_trajectory(np.zeros(X.shape[::-1]).T, U2)
+
+
+def test_get_desc_returns_what_the_handle_was_created_with(A):
+    """altro_get_desc (round 4): callers that size device buffers for the pack entry points read the dimensions from the
+    handle (libaltro_group.so does); works before any device state exists."""
+    import ctypes
+    s = A.BatchSolver(6, 2, 50, 37, A.F32)
+    d = A.Desc()
+    assert A.load_library().altro_get_desc(s._h, ctypes.byref(d)) == 0
+    assert (d.n, d.m, d.N, d.batch, d.dtype, d.device_id) == (6, 2, 50, 37, A.F32, 0)
+    assert A.load_library().altro_get_desc(s._h, None) != 0

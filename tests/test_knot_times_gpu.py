@@ -163,3 +163,32 @@ def test_time_varying_user_model_matches_the_oracle(A, P, hip_make, wind_oracle,
     else:  # another phase of the gust: another trajectory
         ref = getattr(test_time_varying_user_model_matches_the_oracle, "ref", None)
         assert ref is None or np.abs(ref - Xg).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_time_varying_model_uploaded_before_its_step_is_known(A, hip_make):
+    """the facade builds the solver from the problem BEFORE the trajectory (and with it the step) is handed over.
+    For a time-varying model that upload used to fail with "the integration step of knot 0 is not set" and left the handle
+    unusable for good.  Now the knot times stay unset until a step arrives, integrating calls are refused meanwhile, and
+    the handle works once altro_set_uniform_step has been called."""
+    kind = A.register_model_source("cartpole_wind", WIND)
+    N, B = 60, 4
+    s = hip_make(4, 1, N, B, A.F64)
+    s.set_model(kind)
+    xf = np.zeros((B, 4)); xf[:, 0] = np.linspace(0.5, 1.1, B)
+    hd = float(np.float32(0.05))
+    s.set_lqr_cost(0, N, np.eye(4) * (1e-1 * hd), np.eye(1) * (1e-2 * hd), xf, np.zeros(1))
+    s.set_lqr_cost(N, N + 1, np.eye(4) * 100.0, np.zeros((1, 1)), xf, np.zeros(1))
+    s.add_control_bound(0, N, [-3.0], [3.0])
+    s.add_constraint(A.CON_GOAL, N, N + 1, xf)
+    s.set_initial_state(np.zeros(4))
+    s.set_trajectory(None, np.zeros((N, 1)))
+    assert s.num_constraints() == 2 * N + 4      # uploads the problem: no step known yet
+    with pytest.raises(A.AltroError, match="integration step is not set"):
+        s.rollout()
+    s.set_uniform_step(np.float32(0.05))          # Trajectory::SetUniformStep arrives: steps AND times t_k = float(k) * h
+    s.solve()
+    st = s.get_stats()
+    assert (st["status"] == 0).all(), st
+    hk, tk = s.get_steps()
+    assert np.all(hk == np.float32(0.05)) and tk[3] == np.float32(3) * np.float32(0.05)

@@ -236,3 +236,16 @@ print("ITERS", s.get_stats()["iterations_total"].tolist())
     shutil.copyfile(other, path1)
     sec3, path3, iters3 = run()
     assert sec3 > 3.0 and path3 == path1 and iters3 == iters1  # noticed and rebuilt
+
+
+@pytest.mark.gpu
+def test_wrong_entry_does_not_hide_behind_a_large_jacobian(A):
+    """the derivative check is per ENTRY, |J_fd - J|_ij / max(1, |J_ij|) < 1e-4.  A norm-wise relative error let a
+    wrong entry of order one through once the Jacobian as a whole was large: here ||J|| ~ 1000 and one entry is off by 1e-2
+    (1e-5 of the norm)."""
+    good = open(os.path.join(ROOT, "tests", "models", "stiff_pair.hpp")).read()
+    assert A.register_model_source("stiff_pair", good) >= A.MODEL_USER_BASE
+    bad = good.replace("J[5] = T(1);", "J[5] = T(1.01);")
+    assert bad != good
+    with pytest.raises(A.AltroError, match="does not match finite differences"):
+        A.register_model_source("stiff_pair_bad", bad)
