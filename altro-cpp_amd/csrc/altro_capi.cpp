@@ -35,7 +35,7 @@ using namespace altro_hip;
 
 extern "C" int altro_chain_claim(int device, int delta);
 
-#define ALTRO_USER_PLUGIN_ABI_HOST 6  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
+#define ALTRO_USER_PLUGIN_ABI_HOST 7  // must equal ALTRO_USER_PLUGIN_ABI of altro_user_model.hpp
 
 struct altro_solver_s {
   ProblemSpec spec;
@@ -408,7 +408,11 @@ altro_status altro_register_model_source(const char* name, const char* source, i
       std::ofstream f(src);
       f << "// generated by altro_register_model_source for the user model '" << safe << "'\n"
         << "#include <hip/hip_runtime.h>\n#define ALTRO_MODEL_FN __device__ __forceinline__\n"
+        // (the user's functions under the language-level contraction rule, like the generic integrators that call them:
+        //  altro_device.hpp, "CONTRACTION MODE OF THE GENERIC DYNAMICS CODE")
+        << "#pragma clang fp contract(on)\n"
         << "namespace altro_user {\n#line 1 \"user model " << safe << "\"\n" << source << "\n}  // namespace altro_user\n"
+        << "#pragma clang fp contract(fast)\n"
         << "#include \"altro_user_model.hpp\"  // (the engine headers see ALTRO_USER_COST / ALTRO_USER_CONSTRAINT)\n"
         << "extern \"C\" unsigned long long altro_user_source_hash() { return 0x" << hx << "ULL; }\n";
       if (!f) {

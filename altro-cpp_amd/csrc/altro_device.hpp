@@ -648,6 +648,13 @@ ALTRO_DEV float stage_time(float t, T hh, double c) {
   return (float)((double)t + c * (double)hh);
 }
 
+// CONTRACTION MODE OF THE GENERIC DYNAMICS CODE.  The library is compiled with -ffp-contract=fast: the optimiser may fuse
+// a multiply and an add across statements, and WHETHER it does depends on what the function was inlined into -- so the
+// same generic RK4 code could round differently in k_expansions and in the persistent kernel's expansion phase.  The
+// hand-fused unicycle paths pin every fma; the generic integrators and the user's f / jac / step get the language-level
+// rule instead (`contract(on)`: a * b + c fuses only inside ONE expression, wherever the function ends up), so that a
+// model that can take both the batched kernels and the persistent kernel (n <= 3, m <= 2) sees one arithmetic.
+#pragma clang fp contract(on)
 // Generic RK4 step.  Models may provide `rk4_fused` (same arithmetic, shared sub-expressions).
 template <class T, class M>
 ALTRO_DEV void rk4_step_generic(const T* x, const T* u, T hh, T* xn, float t = 0.0f) {
@@ -886,6 +893,8 @@ ALTRO_DEV void discrete_jacobian(const T* x, const T* u, T hh, T* J, float t = 0
     single_jacobian<T, M>(x, u, hh, J, t);
   }
 }
+
+#pragma clang fp contract(fast)
 
 // -------------------------------------------------------------------------------------------------
 // Per-knot problem access

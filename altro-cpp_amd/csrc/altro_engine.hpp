@@ -514,7 +514,7 @@ class Engine final : public EngineBase {
   // Backward pass launch: fp64 unicycle-sized problems run on the matrix cores (4 instances per
   // wavefront), everything else on the one-lane-per-instance VALU kernel.
   // The MFMA backward pass computes in fp64 whatever the storage type of the engine is
-  static constexpr bool kMfmaBackward = n == 3 && m == 2;
+  static constexpr bool kMfmaBackward = n <= 3 && m <= 2;  // (round 4: every model that fits the 4 x 4 tiles, not only the unicycle's shape)
   // larger models: one instance per wavefront -- on the 16x16x4 fp64 matrix cores (k_backward_mfma16), or with
   // the matrices in LDS and the products on the vector ALUs (k_backward_coop: ALTRO_HIP_BACKWARD=coop)
   // (n = 4 -- the cart-pole class of user models -- takes the 16x16 tile too while the launch has few instances: one

@@ -662,8 +662,10 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
                                   double* sKD, T* sKDf, int fused_junk, double* fh, double spec_rho = 0.0,
                                   double spec_drho = 0.0, int* nbar = nullptr) {
   static_assert(!SPEC || FUSED, "the speculative pass is a variant of the fused one");
-  static_assert(M::n == 3 && M::m == 2, "MFMA backward pass is specialised for n = 3, m = 2");
-  constexpr int n = 3, m = 2;
+  // 4 x 4 tiles with the vectors riding as column n: n <= 3 states, m <= 2 controls (round 4: was n = 3, m = 2 only -- the
+  // tile offsets below are generic; what m = 1 changes is the 2 x 2 inverse, see qc)
+  static_assert(M::n >= 1 && M::n <= 3 && M::m >= 1 && M::m <= 2, "4x4 MFMA backward pass: n <= 3 (one tile column for the vectors), m <= 2");
+  constexpr int n = M::n, m = M::m;
   using R = Rec<T, n, m>;
   using RS = rec_scalar_t<T, M>;  // storage type of the expansion / gain records in HBM
   using RR = Rec<RS, n, m>;
@@ -813,7 +815,9 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       // its pivots are a and det / a, so the verdict is a <= 0 || det <= 0, and the inverse of the 2x2
       // SPD matrix is the adjugate over det: one reciprocal on the dependent chain instead of two
       // reciprocal square roots in sequence (same O(cond) * eps accuracy as forming L^-T L^-1).
-      const double qa = q00 + rho, qc = q11 + rho;
+      // (m = 1: Quu is the scalar q00; a unit second diagonal entry makes det = qa, the verdict "qa <= 0" and the
+      //  adjugate entry -qc / det = -1 / qa -- Eigen's 1 x 1 LLT up to the rounding of one reciprocal)
+      const double qa = q00 + rho, qc = (m >= 2) ? q11 + rho : 1.0;
       const double det = fma(qa, qc, -(q10 * q10));
       double rd = rcp_nr(det);
       pin(rd);  // computed by every lane, not inside a region of the lanes that hold the 2 x 2 block
@@ -3219,7 +3223,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     return;
   }
 
-  if constexpr (FUSED && M::n == 3 && M::m == 2) {
+  if constexpr (FUSED && M::n <= 3 && M::m <= 2) {
     if (wave == 3) {
       // ============ fourth wave: the backward pass of the NEXT iteration, assuming this line search fails ============
       // (ilqr.hpp:550: a rejected step raises the regularisation; nothing else changes)

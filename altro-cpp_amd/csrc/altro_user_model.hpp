@@ -33,7 +33,7 @@
 
 namespace altro_hip {
 
-#define ALTRO_USER_PLUGIN_ABI 6  // bump when EngineBase or the entry points below change
+#define ALTRO_USER_PLUGIN_ABI 7  // bump when EngineBase or the entry points below change
 
 // a user's model struct with the flags the engine asks every model for (no hand-fused RK4 / carried trigonometry)
 template <class S>
