@@ -648,18 +648,20 @@ def main():
         step()
     if args.pipeline > 1:
         drain()
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others (load imbalance shows here)
     barrier()
     elapsed = time.perf_counter() - t0
     host_cpu_cores = (time.process_time() - c0) / max(elapsed, 1e-9)  # CPU time of ALL threads of this rank per wall second
-    rank_elapsed = [elapsed]
+    rank_elapsed = [own_elapsed]
     cdev = "cpu" if host_gather else dev
     if use_dist:
-        mine = torch.tensor([[elapsed, host_cpu_cores]], dtype=torch.float64, device=cdev)  # (one row per rank)
-        allr = torch.empty((world, 2), dtype=torch.float64, device=cdev)
+        mine = torch.tensor([[elapsed, host_cpu_cores, own_elapsed]], dtype=torch.float64, device=cdev)  # (one row per rank)
+        allr = torch.empty((world, 3), dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(allr, mine)
         allr = allr.cpu().numpy()
-        rank_elapsed = [float(v) for v in allr[:, 0]]
-        elapsed = max(rank_elapsed)  # MAX over ranks
+        elapsed = float(allr[:, 0].max())  # MAX over ranks of the barrier-to-barrier time
+        rank_elapsed = [float(v) for v in allr[:, 2]]
         host_cpu_cores = float(allr[:, 1].max())
 
     res = gathered.cpu().numpy()
