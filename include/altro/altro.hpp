@@ -30,6 +30,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -51,7 +52,25 @@ enum class SolverStatus {
   kBackwardPassRegularizationFailed = 9,
 };
 
-// altro/common/solver_options.hpp:19-57 (same field names and defaults; console fields omitted)
+// altro/common/log_entry.hpp:27-34
+enum class LogLevel {
+  kSilent = 0,
+  kOuter = 1,
+  kOuterDebug = 2,
+  kInner = 3,
+  kInnerDebug = 4,
+  kDebug = 5,
+};
+
+constexpr int kPickHardwareThreads = -1;  // altro/common/solver_options.hpp:13
+
+// altro/common/solver_options.hpp:19-65: every field of the reference, same names and defaults.  What the device solver
+// does with the host-side ones: `verbose` / `header_frequency` -- the kernels do not print; the rows the reference's logger
+// would have printed are recorded on the device and printed AFTER the solve (iLQR::PrintLog; needs the history, which
+// batches of up to ilqr::kHistoryBatchLimit instances record by default).  `profiler_enable` times the kernels (HIP
+// events), `profiler_output_to_file` / `log_directory` / `profile_filename` say where the solver's destructor writes the
+// summed tree (the reference's Timer prints at destruction, timer.cpp:10-14).  `nthreads` / `tasks_per_thread` are accepted
+// and have no effect: every (instance, knot) pair is a GPU thread of its own (ilqr.hpp:183-214 has no counterpart).
 struct SolverOptions {
   int max_iterations_total = 300;
   int max_iterations_outer = 30;
@@ -75,7 +94,19 @@ struct SolverOptions {
   double maximum_penalty = 1e8;
   double initial_penalty = 1.0;
   bool reset_duals = true;
+  int header_frequency = 10;
+  LogLevel verbose = LogLevel::kSilent;
   bool profiler_enable = false;
+  bool profiler_output_to_file = false;
+  std::string log_directory;
+  std::string profile_filename = "profiler.out";
+  int nthreads = 1;
+  int tasks_per_thread = 1;
+
+  int NumThreads() const {  // solver_options.hpp:59-64
+    if (nthreads == kPickHardwareThreads) return static_cast<int>(std::thread::hardware_concurrency());
+    return std::max(nthreads, 1);
+  }
 
   altro_options ToC() const {
     altro_options o;
@@ -152,7 +183,104 @@ struct ConstraintInfo {
     return out + "]";
   }
 };
+
+// altro/constraints/constraint.hpp:60-128: the two cones of the reference, as tags
+struct Equality {};
+struct NegativeOrthant {};
+using Inequality = NegativeOrthant;
+
+// What a constraint IS on this facade: a kind plus parameters (the device evaluates it; a kernel cannot call the
+// host virtual functions of constraint.hpp:173-202).  The typed classes below and in `examples` derive from it.
+struct ConstraintDesc {
+  int kind = 0;
+  std::vector<double> params;  // one instance's block, or batch blocks back to back
+  int nparams = 0;             // length of one instance's block
+  std::string label;
+  int user_p = 0;              // USER: OutputDimension of the source's UserConstraint
+  bool user_equality = false;  // USER: its cone (constraints::Equality / NegativeOrthant)
+  int user_type = 0;           // USER: index of the class in the source's ALTRO_USER_CONSTRAINTS list
+  bool operator==(const ConstraintDesc& o) const {
+    return kind == o.kind && params == o.params && nparams == o.nparams && user_type == o.user_type;
+  }
+  bool IsEquality() const { return kind == ALTRO_CON_GOAL || (kind == ALTRO_CON_USER && user_equality); }
+  // Constraint<ConType>::GetConstraintType, altro/constraints/constraint.hpp:193-201
+  std::string GetConstraintType() const { return IsEquality() ? "Equality Constraint" : "Inequality Constraint"; }
+  std::string GetLabel() const { return label.empty() ? GetConstraintType() : label; }  // constraint.hpp:191
+  int OutputDimension() const {
+    if (kind == ALTRO_CON_USER) return user_p;
+    if (kind == ALTRO_CON_GOAL) return nparams;
+    if (kind == ALTRO_CON_CIRCLE) return nparams / 3;
+    int p = 0;  // CONTROL_BOUND: one row per finite bound (basic_constraints.hpp:138-145)
+    for (int i = 0; i < nparams; ++i)
+      if (std::abs(params[i]) < std::numeric_limits<double>::max()) ++p;
+    return p;
+  }
+};
+
+// altro/constraints/constraint.hpp:173-205: the typed base class a reference caller holds its constraints by
+// (`std::shared_ptr<Constraint<Inequality>> obs = std::make_shared<examples::CircleConstraint>(...)`,
+// `ConstraintPtr<Equality> goal = ...`).  Problem::SetConstraint takes the pointer and keeps the descriptor.
+template <class ConType>
+struct Constraint : ConstraintDesc {
+  using ConstraintType = ConType;
+  virtual ~Constraint() = default;
+};
+template <class ConType>
+using ConstraintPtr = std::shared_ptr<Constraint<ConType>>;
 }  // namespace constraints
+
+namespace problem {
+// altro/problem/costfunction.hpp:52-73: the base class a reference caller holds its cost functions by
+// (`std::shared_ptr<CostFunction>`).  On this facade the only host-side subclasses are descriptors
+// (examples::QuadraticCost, examples::UserCost); the caller's own cost travels as source (UserCost).
+struct CostFunction {
+  virtual ~CostFunction() = default;
+};
+
+// altro/problem/integration.hpp:87-169: the two explicit integrators of the reference, as tags.  RungeKutta4 is a
+// template over the sizes there (`RungeKutta4<NStates, NControls>`), ExplicitEuler is not.
+template <int NStates = -1, int NControls = -1>
+struct RungeKutta4 {
+  static constexpr int kind = 0;
+};
+struct ExplicitEuler {
+  static constexpr int kind = 1;
+};
+
+// altro/problem/dynamics.hpp:148-187: what Problem::SetDynamics stores per knot.  Here it carries what the device needs
+// to pick the compiled model: kind (built-in or the plugin of a user source), parameters, dimensions, index in the source.
+struct DiscreteDynamics {
+  virtual ~DiscreteDynamics() = default;
+  virtual int Kind() const = 0;
+  virtual int StateDimension() const = 0;
+  virtual int ControlDimension() const = 0;
+  virtual std::vector<double> Params() const = 0;
+  virtual int ModelIndex() const = 0;
+};
+
+// problem/discretized_model.hpp:24-65.  RungeKutta4 (the default) for every model; ExplicitEuler for a user model whose
+// plugin was compiled for it (examples::UserModel::Euler): the integrator is part of the compiled device code, not a
+// run-time switch.
+template <class Model, class Integrator = RungeKutta4<Model::NStates, Model::NControls>>
+struct DiscretizedModel : DiscreteDynamics {
+  static constexpr int NStates = Model::NStates;
+  static constexpr int NControls = Model::NControls;
+  explicit DiscretizedModel(const Model& m) : model(m) {
+    if (Integrator::kind != m.Integrator())
+      throw std::runtime_error(Integrator::kind == 1
+                                   ? "DiscretizedModel<Model, ExplicitEuler>: the device code of this model integrates with "
+                                     "RungeKutta4 (a user model is compiled for ExplicitEuler by examples::UserModel::Euler)"
+                                   : "DiscretizedModel<Model, RungeKutta4>: this user model was compiled for ExplicitEuler "
+                                     "(examples::UserModel::Euler): wrap it in DiscretizedModel<Model, ExplicitEuler>");
+  }
+  int Kind() const override { return model.Kind(); }
+  int StateDimension() const override { return model.StateDimension(); }
+  int ControlDimension() const override { return model.ControlDimension(); }
+  std::vector<double> Params() const override { return model.Params(); }
+  int ModelIndex() const override { return model.ModelIndex(); }
+  Model model;
+};
+}  // namespace problem
 
 namespace detail {
 inline void Check(altro_handle h, altro_status st, const char* what) {
@@ -160,6 +288,40 @@ inline void Check(altro_handle h, altro_status st, const char* what) {
     const char* msg = altro_last_error(h);
     throw std::runtime_error(std::string(what) + " failed (" + std::to_string((int)st) + "): " + (msg ? msg : ""));
   }
+}
+// The device timing of a solve (or the sums over several) as a tree in the layout of the reference's Timer
+// (altro/common/timer.cpp:24-94, profile_entry.cpp:36-66; sample: perf/profiler_unicycle.out), with the reference's
+// section names.  "sweep_fused" is this build's persistent tail launch.
+inline void PrintTimingTree(FILE* f, altro_timing t) {
+  const double total = t.total_ms * 1e3;
+  // A large batch runs its batched sweeps as several chains on streams of their own: their launches overlap, and the
+  // summed launch durations of the three sweep kernels can exceed the wall time.  The tree shows wall-time shares:
+  // the three sections share what the solve took outside "init" and the persistent launch.
+  const double sweep_sum = t.expansions_ms + t.backward_pass_ms + t.forward_pass_ms;
+  const double sweep_wall = std::min(sweep_sum, std::max(0.0, t.total_ms - t.init_ms - t.fused_ms));
+  const double scale = sweep_sum > 0 ? sweep_wall / sweep_sum : 1.0;
+  t.expansions_ms *= scale;
+  t.backward_pass_ms *= scale;
+  t.forward_pass_ms *= scale;
+  const double ilqr = (t.expansions_ms + t.backward_pass_ms + t.forward_pass_ms + t.fused_ms) * 1e3;
+  auto row = [&](int depth, const char* name, double us, double parent) {
+    char label[64];
+    std::snprintf(label, sizeof(label), "%*s%s", 2 * depth, "", name);
+    std::fprintf(f, "%-28s %9.0f %8.0f %8.0f\n", label, us, total > 0 ? 100.0 * us / total : 0.0,
+                 parent > 0 ? 100.0 * us / parent : 0.0);
+  };
+  std::fprintf(f, "Description                  Time (us)   %%Total  %%Parent\n");
+  std::fprintf(f, "--------------------------------------------------------\n");
+  row(0, "al", total, total);
+  row(1, "ilqr", ilqr, total);
+  row(3, "backward_pass", t.backward_pass_ms * 1e3, ilqr);
+  row(3, "expansions", t.expansions_ms * 1e3, ilqr);
+  row(3, "forward_pass", t.forward_pass_ms * 1e3, ilqr);
+  row(3, "sweep_fused", t.fused_ms * 1e3, ilqr);
+  row(1, "init", t.init_ms * 1e3, total);
+  std::fprintf(f, "sweeps %d (tail iterations in the fused launch: %d), kernel launches %d (batched sweeps: %d), "
+               "instance-iterations %lld\n",
+               t.sweeps, t.fused_sweeps, t.launches, t.sweep_launches, t.instance_iterations);
 }
 }  // namespace detail
 
@@ -171,6 +333,11 @@ class Trajectory {
   explicit Trajectory(int N, int batch = 1)
       : N_(N), B_(batch), X_((size_t)batch * (N + 1) * n, 0.0), U_((size_t)batch * N * m, 0.0), h_((size_t)N + 1, 0.0f),
         t_((size_t)N + 1, 0.0f) {}
+  // the reference's run-time-size constructor (trajectory.hpp:37-38): Trajectory(n, m, N), one instance
+  Trajectory(int n_rt, int m_rt, int N) : Trajectory(N, 1) {
+    if (n_rt != n || m_rt != m) throw std::runtime_error("Trajectory(n, m, N): sizes disagree with the template arguments.");
+  }
+  // copyable and assignable like the reference's (trajectory.hpp:67-79): `*traj_ptr = prob_def.InitialTrajectory()`
   int NumSegments() const { return N_; }
   int BatchSize() const { return B_; }
   double* State(int k, int b = 0) { return &X_[((size_t)b * (N_ + 1) + k) * n]; }
@@ -217,6 +384,8 @@ class Trajectory {
 // ---- descriptor types with the reference's class names --------------------------------------------
 namespace examples {
 struct Unicycle {  // examples/unicycle.hpp
+  static constexpr int NStates = 3;
+  static constexpr int NControls = 2;
   static constexpr int kind = ALTRO_MODEL_UNICYCLE;
   int Kind() const { return kind; }
   int StateDimension() const { return 3; }
@@ -226,6 +395,8 @@ struct Unicycle {  // examples/unicycle.hpp
   int Integrator() const { return 0; }
 };
 struct TripleIntegrator {  // examples/triple_integrator.hpp
+  static constexpr int NStates = -1;  // Eigen::Dynamic in the reference (triple_integrator.hpp): 3 * dof at run time
+  static constexpr int NControls = -1;
   static constexpr int kind = ALTRO_MODEL_TRIPLE_INTEGRATOR;
   explicit TripleIntegrator(int dof = 1) : dof_(dof) {}
   int Kind() const { return kind; }
@@ -237,6 +408,8 @@ struct TripleIntegrator {  // examples/triple_integrator.hpp
   int dof_;
 };
 struct Quadrotor12 {  // build-defined model of BASELINE config 5
+  static constexpr int NStates = 12;
+  static constexpr int NControls = 4;
   static constexpr int kind = ALTRO_MODEL_QUADROTOR12;
   int Kind() const { return kind; }
   int StateDimension() const { return 12; }
@@ -263,6 +436,8 @@ struct Quadrotor12 {  // build-defined model of BASELINE config 5
 //     DiscretizedModel<UserModel, ExplicitEuler>;
 //   * the caller's own problem::DiscreteDynamics (dynamics.hpp:148-187): a struct with `discrete = true`, step / step_jac.
 struct UserModel {
+  static constexpr int NStates = -1;  // sizes are the source's (run-time here, like Eigen::Dynamic)
+  static constexpr int NControls = -1;
   UserModel(const std::string& name, const std::string& source, int n, int m, bool check_derivatives = true)
       : n_(n), m_(m) {
     Register(name, source, check_derivatives);
@@ -299,7 +474,7 @@ struct UserModel {
 };
 
 // examples/quadratic_cost.hpp:29-39.  xref may hold one reference or `batch` references.
-struct QuadraticCost {
+struct QuadraticCost : problem::CostFunction {
   std::vector<double> Q, R, xref, uref;
   bool terminal = false;
   // the UserCost of the problem's UserModel instead (see UserCost below): its parameters, one block or `batch` blocks
@@ -335,30 +510,7 @@ struct UserCost : QuadraticCost {
   }
 };
 
-struct ConstraintDesc {
-  int kind = 0;
-  std::vector<double> params;  // one instance's block, or batch blocks back to back
-  int nparams = 0;             // length of one instance's block
-  std::string label;
-  int user_p = 0;              // USER: OutputDimension of the source's UserConstraint
-  bool user_equality = false;  // USER: its cone (constraints::Equality / NegativeOrthant)
-  int user_type = 0;           // USER: index of the class in the source's ALTRO_USER_CONSTRAINTS list
-  bool operator==(const ConstraintDesc& o) const {
-    return kind == o.kind && params == o.params && nparams == o.nparams && user_type == o.user_type;
-  }
-  bool IsEquality() const { return kind == ALTRO_CON_GOAL || (kind == ALTRO_CON_USER && user_equality); }
-  // Constraint<ConType>::GetConstraintType, altro/constraints/constraint.hpp:193-201
-  std::string GetConstraintType() const { return IsEquality() ? "Equality Constraint" : "Inequality Constraint"; }
-  int OutputDimension() const {
-    if (kind == ALTRO_CON_USER) return user_p;
-    if (kind == ALTRO_CON_GOAL) return nparams;
-    if (kind == ALTRO_CON_CIRCLE) return nparams / 3;
-    int p = 0;  // CONTROL_BOUND: one row per finite bound (basic_constraints.hpp:138-145)
-    for (int i = 0; i < nparams; ++i)
-      if (std::abs(params[i]) < std::numeric_limits<double>::max()) ++p;
-    return p;
-  }
-};
+using ConstraintDesc = constraints::ConstraintDesc;
 // constraints::Constraint<ConType> of the caller (constraint.hpp:173-202): the `struct UserConstraint` of the
 // UserModel's source with these parameters; p = its OutputDimension, equality = its cone; `type` picks the class when
 // the source lists several (ALTRO_USER_CONSTRAINTS).
@@ -375,7 +527,7 @@ struct UserConstraint : ConstraintDesc {
   }
 };
 // examples/basic_constraints.hpp:15-40
-struct GoalConstraint : ConstraintDesc {
+struct GoalConstraint : constraints::Constraint<constraints::Equality> {
   explicit GoalConstraint(const std::vector<double>& xf, int n = -1) {
     kind = ALTRO_CON_GOAL;
     params = xf;
@@ -384,7 +536,7 @@ struct GoalConstraint : ConstraintDesc {
   }
 };
 // examples/basic_constraints.hpp:42-151
-struct ControlBound : ConstraintDesc {
+struct ControlBound : constraints::Constraint<constraints::Inequality> {
   ControlBound(const std::vector<double>& lb, const std::vector<double>& ub) {
     if (lb.size() != ub.size() || lb.empty())
       throw std::runtime_error("Upper and lower bounds must have the same length.");
@@ -396,7 +548,7 @@ struct ControlBound : ConstraintDesc {
   }
 };
 // examples/obstacle_constraints.hpp:69-127
-struct CircleConstraint : ConstraintDesc {
+struct CircleConstraint : constraints::Constraint<constraints::Inequality> {
   CircleConstraint() {
     kind = ALTRO_CON_CIRCLE;
     label = "Circle Constraint";
@@ -416,29 +568,6 @@ struct CircleConstraint : ConstraintDesc {
 }  // namespace examples
 
 namespace problem {
-// altro/problem/integration.hpp:87-169: the two explicit integrators of the reference, as tags
-struct RungeKutta4 {
-  static constexpr int kind = 0;
-};
-struct ExplicitEuler {
-  static constexpr int kind = 1;
-};
-// problem/discretized_model.hpp:24-65.  RungeKutta4 (the default) for every model; ExplicitEuler for a user model whose
-// plugin was compiled for it (examples::UserModel::Euler): the integrator is part of the compiled device code, not a
-// run-time switch.
-template <class Model, class Integrator = RungeKutta4>
-struct DiscretizedModel {
-  explicit DiscretizedModel(const Model& m) : model(m) {
-    if (Integrator::kind != m.Integrator())
-      throw std::runtime_error(Integrator::kind == 1
-                                   ? "DiscretizedModel<Model, ExplicitEuler>: the device code of this model integrates with "
-                                     "RungeKutta4 (a user model is compiled for ExplicitEuler by examples::UserModel::Euler)"
-                                   : "DiscretizedModel<Model, RungeKutta4>: this user model was compiled for ExplicitEuler "
-                                     "(examples::UserModel::Euler): wrap it in DiscretizedModel<Model, ExplicitEuler>");
-  }
-  Model model;
-};
-
 // altro/problem/problem.hpp:65-307
 class Problem {
  public:
@@ -456,8 +585,24 @@ class Problem {
     costs_[k] = cost;
     has_cost_[k] = true;
   }
-  template <class Model, class Integrator>
-  void SetDynamics(const DiscretizedModel<Model, Integrator>& dm, int k) {
+  // the reference's signature (problem.hpp:113-116): the cost function by shared pointer to its base class.  The
+  // object must be one of the facade's descriptors (examples::QuadraticCost, examples::UserCost); its values are
+  // copied, so later edits through the pointer do not reach the problem.
+  void SetCostFunction(std::shared_ptr<CostFunction> costfun, int k) {
+    if (!costfun) throw std::runtime_error("Cannot pass a nullptr for the cost function.");
+    const auto* q = dynamic_cast<const examples::QuadraticCost*>(costfun.get());
+    if (!q)
+      throw std::runtime_error("Problem::SetCostFunction: a host-side CostFunction subclass cannot run on the device; hand "
+                               "the cost over as source (examples::UserCost, altro_register_model_source)");
+    SetCostFunction(*q, k);
+  }
+  // problem.hpp:133-139: an interval of consecutive knots
+  template <class CostFun>
+  void SetCostFunction(const std::vector<std::shared_ptr<CostFun>>& costfuns, int k_start = 0) {
+    for (size_t i = 0; i < costfuns.size(); ++i) SetCostFunction(std::shared_ptr<CostFunction>(costfuns[i]), (int)i + k_start);
+  }
+
+  void SetDynamics(const DiscreteDynamics& dm, int k) {
     Range(k);
     if (k >= N_) throw std::runtime_error("dynamics are set on knots 0..N-1");
     // The reference keeps one model PER KNOT (models_[k], problem.hpp:155-166).  A handle of this build carries one
@@ -467,27 +612,44 @@ class Problem {
     // it is refused (the state and control dimensions could not change along the horizon either).
     bool any = false;
     for (int j = 0; j < N_; ++j) any = any || has_dyn_[j];
-    if (any && (model_kind_ != dm.model.Kind() || model_params_ != dm.model.Params()))
+    if (any && (model_kind_ != dm.Kind() || model_params_ != dm.Params()))
       throw std::runtime_error("Problem::SetDynamics: a model of another kind on knot " + std::to_string(k) +
                                " -- the models of one problem come from ONE source (a user source may list several: "
                                "#define ALTRO_USER_MODELS A, B and examples::UserModel::Model(i))");
-    model_kind_ = dm.model.Kind();
-    model_params_ = dm.model.Params();
-    n_ = dm.model.StateDimension();
-    m_ = dm.model.ControlDimension();
+    model_kind_ = dm.Kind();
+    model_params_ = dm.Params();
+    n_ = dm.StateDimension();
+    m_ = dm.ControlDimension();
     has_dyn_[k] = true;
-    knot_model_[k] = dm.model.ModelIndex();
+    knot_model_[k] = dm.ModelIndex();
     if (k == N_ - 1) has_dyn_[N_] = true;  // IdentityDynamics at the terminal knot (problem.hpp:161-164)
   }
-  // the vector overload (problem.hpp:187-191): models[k] on knot k, k = 0 .. N-1
+  // the reference's signature (problem.hpp:155-166)
+  void SetDynamics(std::shared_ptr<DiscreteDynamics> model, int k) {
+    if (!model) throw std::runtime_error("Cannot pass a nullptr for the dynamics.");
+    SetDynamics(*model, k);
+  }
+  // problem.hpp:187-193: an interval of consecutive knots, by pointer ...
+  template <class Dynamics>
+  void SetDynamics(const std::vector<std::shared_ptr<Dynamics>>& models, int k_start = 0) {
+    for (size_t i = 0; i < models.size(); ++i) SetDynamics(std::shared_ptr<DiscreteDynamics>(models[i]), (int)i + k_start);
+  }
+  // ... or by value: models[k] on knot k, k = 0 .. N-1
   template <class Model, class Integrator>
   void SetDynamics(const std::vector<DiscretizedModel<Model, Integrator>>& models) {
     if ((int)models.size() != N_) throw std::runtime_error("Problem::SetDynamics: expected N models");
     for (int k = 0; k < N_; ++k) SetDynamics(models[k], k);
   }
-  void SetConstraint(const examples::ConstraintDesc& con, int k) {
+  void SetConstraint(const constraints::ConstraintDesc& con, int k) {
     Range(k);
     cons_[k].push_back(con);
+  }
+  // the reference's signatures (problem.hpp:195-202): a pointer to the constraint class itself or to its typed base
+  // (constraints::ConstraintPtr<ConType>); the descriptor is copied
+  template <class ConstraintObject>
+  void SetConstraint(std::shared_ptr<ConstraintObject> con, int k) {
+    if (!con) throw std::runtime_error("Cannot pass a nullptr for the constraint.");
+    SetConstraint(static_cast<const constraints::ConstraintDesc&>(*con), k);
   }
   // the constraints of knot k in the order the solver stacks them: equalities first, then inequalities,
   // insertion order within each (al_cost.hpp:267-272)
@@ -619,7 +781,23 @@ struct Core {
   unsigned gains_epoch = ~0u, ctg_epoch = ~0u;
   bool ctg_read = false;  // a KnotPointFunctions view has asked for the cost-to-go: whole solves record it from now on
   std::vector<double> K, d, P, p;
+  // sums of the solves' device timings while SolverOptions::profiler_enable is set; written at destruction unless
+  // PrintTimings() was called (the reference's Timer: timer.cpp:10-14, solver_stats.cpp:60-77)
+  altro_timing prof{};
+  int prof_solves = 0;
+  bool prof_printed = false;
   ~Core() {
+    if (h && prof_solves > 0 && opts.profiler_enable && !prof_printed) {
+      FILE* f = stdout;
+      if (opts.profiler_output_to_file) {
+        const std::string path = (opts.log_directory.empty() ? std::string() : opts.log_directory + "/") + opts.profile_filename;
+        f = std::fopen(path.c_str(), "w");
+      }
+      if (f) {
+        detail::PrintTimingTree(f, prof);
+        if (f != stdout) std::fclose(f);
+      }
+    }
     if (h) altro_destroy(h);
   }
   Core() = default;
@@ -812,6 +990,50 @@ class iLQR {
     PrepareSolve();
     detail::Check(c_->h, altro_solve_ilqr(c_->h), "altro_solve_ilqr");
     Pull(true, true);
+    AfterSolve();
+  }
+  // What SolverOptions::verbose asks for, after the fact: the rows the reference's logger prints while it iterates
+  // (solver_stats.cpp:80-116: iters, cost, viol, dJ | grad | alpha | reg, z | pen by level) of the instance GetStats()
+  // shows.  Below kInner only the last row (the state at the end of the solve), from kInner on every recorded iteration.
+  void PrintLog(FILE* f = stdout) const {
+    const SolverStats& S = c_->stats;
+    const int lvl = static_cast<int>(c_->opts.verbose);
+    if (lvl <= 0 || S.cost.empty()) return;
+    const size_t rows = S.cost.size();
+    auto header = [&]() {
+      std::fprintf(f, "%6s %12s %11s %10s", "iters", "cost", "viol", "dJ");
+      if (lvl >= 2) std::fprintf(f, " %10s", "grad");
+      if (lvl >= 3) std::fprintf(f, " %6s", "alpha");
+      if (lvl >= 4) std::fprintf(f, " %8s %7s", "reg", "z");
+      if (lvl >= 5) std::fprintf(f, " %8s", "pen");
+      std::fprintf(f, "\n");
+    };
+    const int freq = std::max(c_->opts.header_frequency, 1);
+    int printed = 0;
+    for (size_t i = lvl >= 3 ? 0 : rows - 1; i < rows; ++i, ++printed) {
+      if (printed % freq == 0) header();
+      std::fprintf(f, "%6zu %12.4g %11.3e %10.2e", i, S.cost[i], S.violations[i], S.cost_decrease[i]);
+      if (lvl >= 2) std::fprintf(f, " %10.2e", S.gradient[i]);
+      if (lvl >= 3) std::fprintf(f, " %6.2f", S.alpha[i]);
+      if (lvl >= 4) std::fprintf(f, " %8.1e %7.3f", S.regularization[i], S.improvement_ratio[i]);
+      if (lvl >= 5) std::fprintf(f, " %8.1e", S.max_penalty[i]);
+      std::fprintf(f, "\n");
+    }
+  }
+  // bookkeeping behind every whole solve: the log (verbose) and the profile sums (profiler_enable)
+  void AfterSolve() {
+    if (c_->opts.verbose != LogLevel::kSilent) PrintLog();
+    if (c_->opts.profiler_enable) {
+      altro_timing t;
+      if (altro_get_timing(c_->h, &t) == ALTRO_OK) {
+        altro_timing& a = c_->prof;
+        a.total_ms += t.total_ms; a.init_ms += t.init_ms; a.expansions_ms += t.expansions_ms;
+        a.backward_pass_ms += t.backward_pass_ms; a.forward_pass_ms += t.forward_pass_ms; a.fused_ms += t.fused_ms;
+        a.sweeps += t.sweeps; a.fused_sweeps += t.fused_sweeps; a.launches += t.launches;
+        a.sweep_launches += t.sweep_launches; a.instance_iterations += t.instance_iterations;
+        c_->prof_solves++;
+      }
+    }
   }
   void SolveSetup() {  // ilqr.hpp:629-645
     Push();
@@ -948,6 +1170,7 @@ class AugmentedLagrangianiLQR {
   }
   AugmentedLagrangianiLQR(const AugmentedLagrangianiLQR&) = delete;
   AugmentedLagrangianiLQR& operator=(const AugmentedLagrangianiLQR&) = delete;
+  AugmentedLagrangianiLQR(AugmentedLagrangianiLQR&&) noexcept = default;  // returned by value by MakeALSolver (unicycle.hpp:111-121)
 
   void InitializeFromProblem(const problem::Problem& prob, int dtype = ALTRO_F64, int device_id = 0) {  // al_solver.hpp:239-251
     ilqr_solver_.InitializeFromProblem(BuildAugLagProblem<n, m>(prob), dtype, device_id);
@@ -975,6 +1198,7 @@ class AugmentedLagrangianiLQR {
     detail::Check(Handle(), altro_solve_al(Handle()), "altro_solve_al");
     ilqr_solver_.Pull(true, true);
     status_ = ilqr_solver_.StatusAL();
+    ilqr_solver_.AfterSolve();
   }
   void UpdateDuals() { detail::Check(Handle(), altro_update_duals(Handle()), "altro_update_duals"); }
   void UpdatePenalties() { detail::Check(Handle(), altro_update_penalties(Handle()), "altro_update_penalties"); }
@@ -1048,6 +1272,7 @@ class AugmentedLagrangianiLQR {
     detail::Check(Handle(), altro_wait(Handle()), "altro_wait");
     ilqr_solver_.Pull(true, true);
     status_ = ilqr_solver_.StatusAL();
+    ilqr_solver_.AfterSolve();
   }
   altro_timing GetTiming() {
     altro_timing t;
@@ -1061,36 +1286,8 @@ class AugmentedLagrangianiLQR {
   // instances.  forward_pass includes the reference's cost / rollout / stats / dual_update /
   // penalty_update / convergence_check work, which the forward kernel performs.
   void PrintTimings(FILE* f = stdout) {
-    altro_timing t = GetTiming();
-    const double total = t.total_ms * 1e3;
-    // A large batch runs its batched sweeps as several chains on streams of their own: their launches overlap, and the
-    // summed launch durations of the three sweep kernels can exceed the wall time.  The tree shows wall-time shares:
-    // the three sections share what the solve took outside "init" and the persistent launch.
-    const double sweep_sum = t.expansions_ms + t.backward_pass_ms + t.forward_pass_ms;
-    const double sweep_wall = std::min(sweep_sum, std::max(0.0, t.total_ms - t.init_ms - t.fused_ms));
-    const double scale = sweep_sum > 0 ? sweep_wall / sweep_sum : 1.0;
-    t.expansions_ms *= scale;
-    t.backward_pass_ms *= scale;
-    t.forward_pass_ms *= scale;
-    const double ilqr = (t.expansions_ms + t.backward_pass_ms + t.forward_pass_ms + t.fused_ms) * 1e3;
-    auto row = [&](int depth, const char* name, double us, double parent) {
-      char label[64];
-      std::snprintf(label, sizeof(label), "%*s%s", 2 * depth, "", name);
-      std::fprintf(f, "%-28s %9.0f %8.0f %8.0f\n", label, us, total > 0 ? 100.0 * us / total : 0.0,
-                   parent > 0 ? 100.0 * us / parent : 0.0);
-    };
-    std::fprintf(f, "Description                  Time (us)   %%Total  %%Parent\n");
-    std::fprintf(f, "--------------------------------------------------------\n");
-    row(0, "al", total, total);
-    row(1, "ilqr", ilqr, total);
-    row(3, "backward_pass", t.backward_pass_ms * 1e3, ilqr);
-    row(3, "expansions", t.expansions_ms * 1e3, ilqr);
-    row(3, "forward_pass", t.forward_pass_ms * 1e3, ilqr);
-    row(3, "sweep_fused", t.fused_ms * 1e3, ilqr);
-    row(1, "init", t.init_ms * 1e3, total);
-    std::fprintf(f, "sweeps %d (tail iterations in the fused launch: %d), kernel launches %d (batched sweeps: %d), "
-                 "instance-iterations %lld\n",
-                 t.sweeps, t.fused_sweeps, t.launches, t.sweep_launches, t.instance_iterations);
+    detail::PrintTimingTree(f, GetTiming());
+    ilqr_solver_.CorePtr()->prof_printed = true;  // (the destructor prints the sums only if nobody asked before: timer.cpp:10-14)
   }
 
  private:

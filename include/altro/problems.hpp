@@ -85,51 +85,63 @@ class UnicycleProblem {
       ub = {3, +3};
       // the obstacles are registered whatever add_constraints says, and before the bounds: first in the
       // inequality list (unicycle.cpp:55-59); a plain iLQR ignores them (ilqr.hpp:117-119)
-      examples::CircleConstraint obs;
-      obs.SetBatchObstacles(circles, 9);
-      for (int k = 1; k < N; ++k) prob.SetConstraint(obs, k);
+      examples::CircleConstraint obstacles;
+      obstacles.SetBatchObstacles(circles, 9);
+      for (int k = 1; k < N; ++k) {
+        std::shared_ptr<constraints::Constraint<constraints::Inequality>> obs =
+            std::make_shared<examples::CircleConstraint>(obstacles);
+        prob.SetConstraint(obs, k);
+      }
     }
     const std::vector<double> uref = {0, 0};
-    for (int k = 0; k < N; ++k) prob.SetCostFunction(examples::QuadraticCost::LQRCost(Q, R, xf, uref), k);
-    prob.SetCostFunction(examples::QuadraticCost::LQRCost(Qf, Diag(2, 0.0), xf, uref, true), N);
-    const problem::DiscretizedModel<examples::Unicycle> model{examples::Unicycle()};
-    for (int k = 0; k < N; ++k) prob.SetDynamics(model, k);
+    for (int k = 0; k < N; ++k)
+      prob.SetCostFunction(std::make_shared<examples::QuadraticCost>(examples::QuadraticCost::LQRCost(Q, R, xf, uref)), k);
+    prob.SetCostFunction(
+        std::make_shared<examples::QuadraticCost>(examples::QuadraticCost::LQRCost(Qf, Diag(2, 0.0), xf, uref, true)), N);
+    using ModelType = problem::DiscretizedModel<examples::Unicycle>;
+    const ModelType model{examples::Unicycle()};
+    for (int k = 0; k < N; ++k) prob.SetDynamics(std::make_shared<ModelType>(model), k);
     if (add_constraints) {
-      for (int k = 0; k < N; ++k) prob.SetConstraint(examples::ControlBound(lb, ub), k);
-      prob.SetConstraint(examples::GoalConstraint(xf, 3), N);
+      for (int k = 0; k < N; ++k) prob.SetConstraint(std::make_shared<examples::ControlBound>(lb, ub), k);
+      prob.SetConstraint(std::make_shared<examples::GoalConstraint>(xf, 3), N);
     }
     prob.SetInitialState(x0);
     return prob;
   }
 
-  std::shared_ptr<Trajectory<3, 2>> InitialTrajectory() const {  // unicycle.hpp:84-92
-    auto Z = std::make_shared<Trajectory<3, 2>>(N, batch);
+  // unicycle.hpp:84-92: by value, like the reference (`std::make_shared<Trajectory<n, m>>(prob_def.InitialTrajectory())`,
+  // `*traj_ptr = prob_def.InitialTrajectory<n, m>()`); one trajectory object holds the whole batch
+  template <int n_size = NStates, int m_size = NControls>
+  Trajectory<n_size, m_size> InitialTrajectory() const {
+    Trajectory<n_size, m_size> Z(N, batch);
     for (int b = 0; b < batch; ++b)
       for (int k = 0; k < N; ++k) {
-        Z->Control(k, b)[0] = u0[0];
-        Z->Control(k, b)[1] = u0[1];
+        Z.Control(k, b)[0] = u0[0];
+        Z.Control(k, b)[1] = u0[1];
       }
-    Z->SetUniformStep(GetTimeStep());
+    Z.SetUniformStep(GetTimeStep());
     return Z;
   }
 
   // unicycle.hpp:94-109: an iLQR solver on the plain costs, or (alcost) on the AL cost with rho = 1, lambda = 0;
   // the trajectory is installed and rolled out
-  ilqr::iLQR<3, 2> MakeSolver(bool alcost = false) {
+  template <int n_size = NStates, int m_size = NControls>
+  ilqr::iLQR<n_size, m_size> MakeSolver(bool alcost = false) {
     problem::Problem prob = MakeProblem();
-    if (alcost) prob = augmented_lagrangian::BuildAugLagProblem<3, 2>(prob);
-    ilqr::iLQR<3, 2> solver(prob);
-    solver.SetTrajectory(InitialTrajectory());
+    if (alcost) prob = augmented_lagrangian::BuildAugLagProblem<n_size, m_size>(prob);
+    ilqr::iLQR<n_size, m_size> solver(prob);
+    solver.SetTrajectory(std::make_shared<Trajectory<n_size, m_size>>(InitialTrajectory<n_size, m_size>()));
     solver.Rollout();
     return solver;
   }
-  // unicycle.hpp:111-121
-  std::unique_ptr<augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>> MakeALSolver() {
+  // unicycle.hpp:111-121 (by value, as there)
+  template <int n_size = NStates, int m_size = NControls>
+  augmented_lagrangian::AugmentedLagrangianiLQR<n_size, m_size> MakeALSolver() {
     problem::Problem prob = MakeProblem(true);
-    auto solver = std::make_unique<augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>>(prob);
-    solver->SetTrajectory(InitialTrajectory());
-    solver->GetiLQRSolver().Rollout();
-    return solver;
+    augmented_lagrangian::AugmentedLagrangianiLQR<n_size, m_size> solver_al(prob);
+    solver_al.SetTrajectory(std::make_shared<Trajectory<n_size, m_size>>(InitialTrajectory<n_size, m_size>()));
+    solver_al.GetiLQRSolver().Rollout();
+    return solver_al;
   }
 
   // Seeded synthetic batch of BASELINE configs[2] (instance 0 = the reference problem): per-instance goals
@@ -175,39 +187,77 @@ class UnicycleProblem {
   float tf_ = 3.0f;
 };
 
-// examples/problems/triple_integrator.hpp:22-105 (dof = 2; uref = 0, quirk Q9)
+// examples/problems/triple_integrator.hpp:22-105 (uref = 0, quirk Q9).  A template over the degrees of freedom like the
+// reference's; the device library carries the dof = 2 engine (n = 6, m = 2: BASELINE configs[1]), another dof is refused
+// by altro_create when the solver is built.
+template <int dof = 2>
 class TripleIntegratorProblem {
  public:
-  static constexpr int NStates = 6;
-  static constexpr int NControls = 2;
+  static constexpr int NStates = 3 * dof;
+  static constexpr int NControls = dof;
   int N = 10;
   int batch = 1;
   float h = 0.1f;
-  std::vector<double> xf = {1, 2, 0, 0, 0, 0};   // [6] or [batch][6]
-  std::vector<double> x0 = {-1, -2, 0, 0, 0, 0};  // [6] or [batch][6]
-  problem::Problem MakeProblem(bool add_constraints = false) {
+  std::vector<double> xf = std::vector<double>(NStates, 0.0);  // [NStates] or [batch][NStates]
+  std::vector<double> x0 = std::vector<double>(NStates, 0.0);  // [NStates] or [batch][NStates]
+  std::vector<double> ubnd = std::vector<double>(dof);
+
+  TripleIntegratorProblem() {  // triple_integrator.hpp:37-43
+    for (int i = 0; i < dof; ++i) {
+      xf[i] = i + 1;
+      x0[i] = -(i + 1);
+      ubnd[i] = 100 * (i + 1);
+    }
+  }
+
+  template <class Integrator = problem::RungeKutta4<NStates, NControls>>
+  problem::Problem MakeProblem(const bool add_constraints = false) {
     problem::Problem prob(N);
     prob.SetBatch(batch);
-    const std::vector<double> uref = {0, 0};
-    for (int k = 0; k < N; ++k)
-      prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(6, 1.0), Diag(2, 1e-3), xf, uref), k);
-    prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(6, 1e5), Diag(2, 0.0), xf, uref, true), N);
-    const problem::DiscretizedModel<examples::TripleIntegrator> model{examples::TripleIntegrator(2)};
-    for (int k = 0; k < N; ++k) prob.SetDynamics(model, k);
+    using CostFunType = examples::QuadraticCost;
+    using ModelType = examples::TripleIntegrator;
+    const std::vector<double> uref(NControls, 0.0);
+    const bool is_term = true;
+    std::shared_ptr<CostFunType> qterm = std::make_shared<CostFunType>(
+        CostFunType::LQRCost(Diag(NStates, 1e5), Diag(NControls, 0.0), xf, uref, is_term));
+    for (int k = 0; k < N; ++k) {
+      std::shared_ptr<CostFunType> qcost =
+          std::make_shared<CostFunType>(CostFunType::LQRCost(Diag(NStates, 1.0), Diag(NControls, 1e-3), xf, uref));
+      prob.SetCostFunction(qcost, k);
+    }
+    prob.SetCostFunction(qterm, N);
+
+    using DModelType = problem::DiscretizedModel<ModelType, Integrator>;
+    ModelType model_continuous(dof);
+    DModelType model = DModelType(model_continuous);
+    for (int k = 0; k < N; ++k) prob.SetDynamics(std::make_shared<DModelType>(model), k);
+
     prob.SetInitialState(x0);
+
     if (add_constraints) {
-      for (int k = 0; k < N; ++k) prob.SetConstraint(examples::ControlBound({-100, -200}, {100, 200}), k);
-      prob.SetConstraint(examples::GoalConstraint(xf, 6), N);
+      std::vector<double> lb, ub;
+      for (int i = 0; i < dof; ++i) {
+        lb.emplace_back(-ubnd[i]);
+        ub.emplace_back(+ubnd[i]);
+      }
+      for (int k = 0; k < N; ++k) {
+        constraints::ConstraintPtr<constraints::Inequality> bnd = std::make_shared<examples::ControlBound>(lb, ub);
+        prob.SetConstraint(bnd, k);
+      }
+      constraints::ConstraintPtr<constraints::Equality> goal = std::make_shared<examples::GoalConstraint>(xf, NStates);
+      prob.SetConstraint(goal, N);
     }
     return prob;
   }
-  std::shared_ptr<Trajectory<6, 2>> InitialTrajectory() const {
-    auto Z = std::make_shared<Trajectory<6, 2>>(N, batch);
-    Z->SetUniformStep(h);
+  template <int n_size = NStates, int m_size = NControls>
+  Trajectory<n_size, m_size> InitialTrajectory() const {
+    Trajectory<n_size, m_size> Z(N, batch);
+    Z.SetUniformStep(h);
     return Z;
   }
   // BASELINE configs[1]: 51 knots, xf[0:2] ~ U([0.5, 2]^2), x0 = -xf, instance 0 = the reference problem
   void MakeBatch(int B, unsigned long long seed = kSeedBase + 2) {
+    static_assert(dof == 2, "the seeded batch of BASELINE configs[1] is the dof = 2 problem");
     N = 50;
     batch = B;
     SeededUniform U(seed);
@@ -240,16 +290,17 @@ class Quadrotor12Problem {
     for (int k = 0; k < N; ++k)
       prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(12, 1e-2 * h), Diag(4, 1e-2 * h), xf, uref), k);
     prob.SetCostFunction(examples::QuadraticCost::LQRCost(Diag(12, 100.0), Diag(4, 0.0), xf, uref, true), N);
-    const problem::DiscretizedModel<examples::Quadrotor12> model{examples::Quadrotor12()};
-    for (int k = 0; k < N; ++k) prob.SetDynamics(model, k);
+    using ModelType = problem::DiscretizedModel<examples::Quadrotor12>;
+    const ModelType model{examples::Quadrotor12()};
+    for (int k = 0; k < N; ++k) prob.SetDynamics(std::make_shared<ModelType>(model), k);
     for (int k = 0; k < N; ++k) prob.SetConstraint(examples::ControlBound({-5, -3, -3, -3}, {5, 3, 3, 3}), k);
     prob.SetConstraint(examples::GoalConstraint(xf, 12), N);
     prob.SetInitialState(std::vector<double>(12, 0.0));
     return prob;
   }
-  std::shared_ptr<Trajectory<12, 4>> InitialTrajectory() const {
-    auto Z = std::make_shared<Trajectory<12, 4>>(N, batch);
-    Z->SetUniformStep(h);
+  Trajectory<12, 4> InitialTrajectory() const {
+    Trajectory<12, 4> Z(N, batch);
+    Z.SetUniformStep(h);
     return Z;
   }
   void MakeBatch(int B, unsigned long long seed = kSeedBase + 5) {

@@ -1,0 +1,4 @@
+// Forwarding header: keeps the reference's include path `examples/basic_constraints.hpp` valid for callers that switch to the
+// MI355X solver; everything lives in the one facade header.
+#pragma once
+#include "../altro/altro.hpp"

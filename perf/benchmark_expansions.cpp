@@ -33,7 +33,7 @@ int main(int argc, char* argv[]) {
       ilqr::iLQR<3, 2> solver(prob);
       solver.SetRecordCostToGo(false);
       solver.SetRecordHistory(false);
-      solver.SetTrajectory(def.InitialTrajectory());
+      solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
       solver.Rollout();
       solver.SolveSetup();
       const double us = TimeExpansions(solver, nruns);

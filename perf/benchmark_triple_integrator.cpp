@@ -12,16 +12,16 @@
 using namespace altro;
 
 static void SolveTripleIntegrator(bool add_constraints, int nruns) {  // benchmark_triple_integrator.cpp:20-43
-  problems::TripleIntegratorProblem prob_def;
+  problems::TripleIntegratorProblem<> prob_def;
   problem::Problem prob = prob_def.MakeProblem(add_constraints);
   augmented_lagrangian::AugmentedLagrangianiLQR<6, 2> solver(prob);
   solver.GetiLQRSolver().SetRecordCostToGo(false);
-  auto traj_ptr = prob_def.InitialTrajectory();
+  auto traj_ptr = std::make_shared<Trajectory<6, 2>>(prob_def.InitialTrajectory());
   solver.SetTrajectory(traj_ptr);
   solver.GetOptions().profiler_enable = true;
   double best = 1e30;
   for (int r = 0; r < nruns; ++r) {
-    *traj_ptr = *prob_def.InitialTrajectory();
+    *traj_ptr = prob_def.InitialTrajectory();
     const auto start = std::chrono::high_resolution_clock::now();
     solver.Solve();
     const auto stop = std::chrono::high_resolution_clock::now();
@@ -34,15 +34,15 @@ static void SolveTripleIntegrator(bool add_constraints, int nruns) {  // benchma
 }
 
 static void SolveBatch(int B, int nruns) {  // BASELINE configs[1]
-  problems::TripleIntegratorProblem def;
+  problems::TripleIntegratorProblem<> def;
   def.MakeBatch(B);
   ilqr::iLQR<6, 2> solver(def.MakeProblem(false));
   solver.SetRecordCostToGo(false);
   solver.SetRecordHistory(false);
-  auto traj = def.InitialTrajectory();
+  auto traj = std::make_shared<Trajectory<6, 2>>(def.InitialTrajectory());
   solver.SetTrajectory(traj);
   for (int r = 0; r < nruns; ++r) {
-    *traj = *def.InitialTrajectory();
+    *traj = def.InitialTrajectory();
     solver.SetTrajectory(traj);
     solver.ResetStats();  // iLQR::Solve accumulates iterations_total across calls (quirk Q11)
     const auto start = std::chrono::high_resolution_clock::now();

@@ -21,12 +21,12 @@ static double SolveUnicycleLoop(int nruns) {  // perf/benchmark_unicycle.cpp:46-
   problem::Problem prob = def.MakeProblem(true);
   augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> solver(prob);
   solver.GetiLQRSolver().SetRecordCostToGo(false);  // timing run: lets the persistent tail kernel take the solve
-  auto traj = def.InitialTrajectory();
+  auto traj = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
   solver.SetTrajectory(traj);
   double best = 1e30;
   for (int iter = 0; iter < nruns; ++iter) {
     solver.SetPenalty(10.0);  // a no-op, as in the reference: Init() resets to initial_penalty (quirk Q8)
-    *traj = *def.InitialTrajectory();
+    *traj = def.InitialTrajectory();
     const auto t0 = std::chrono::high_resolution_clock::now();
     solver.Solve();
     const auto t1 = std::chrono::high_resolution_clock::now();
@@ -44,11 +44,11 @@ static void SolveBatch(int B, int nruns) {
   def.MakeTurn90Batch(B);
   problem::Problem prob = def.MakeProblem(true);
   augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> solver(prob);
-  auto traj = def.InitialTrajectory();
+  auto traj = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
   solver.SetTrajectory(traj);
   solver.GetOptions().profiler_enable = true;
   for (int iter = 0; iter < nruns; ++iter) {
-    *traj = *def.InitialTrajectory();
+    *traj = def.InitialTrajectory();
     solver.Solve();
     const altro_timing t = solver.GetTiming();
     int solved = 0;
@@ -79,7 +79,7 @@ static int SolveSharded(int gpus, int batch_per_gpu, int nruns) {
     problem::Problem prob = def.MakeProblem(true);
     solvers.push_back(std::make_unique<augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>>(prob, ALTRO_F32, devices[part]));
     solvers.back()->GetiLQRSolver().SetRecordCostToGo(false);
-    trajs.push_back(def.InitialTrajectory());
+    trajs.push_back(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
     solvers.back()->SetTrajectory(trajs.back());
     solvers.back()->NumConstraints();  // (creates the device state -- and the solver's streams -- before RCCL's)
   }
@@ -87,7 +87,7 @@ static int SolveSharded(int gpus, int batch_per_gpu, int nruns) {
   for (int part = 0; part < gpus; ++part) group.Attach(part, *solvers[part]);
   int failures = 0;
   for (int run = 0; run < nruns; ++run) {
-    for (int part = 0; part < gpus; ++part) *trajs[part] = *defs[part].InitialTrajectory();
+    for (int part = 0; part < gpus; ++part) *trajs[part] = defs[part].InitialTrajectory();
     const auto t0 = std::chrono::high_resolution_clock::now();
     group.Solve();
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();

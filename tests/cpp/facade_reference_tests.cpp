@@ -140,7 +140,7 @@ static void AugLagTest() {
     EXPECT(threw);
     alsolver.InitializeFromProblem(prob);
     EXPECT(alsolver.NumConstraints() == 4 * N + 3 && alsolver.NumConstraints(0) == 4 && alsolver.NumConstraints(N) == 3);
-    auto Z = def.InitialTrajectory();
+    auto Z = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
     alsolver.SetTrajectory(Z);
     alsolver.GetOptions().constraint_tolerance = 1e-6;
     alsolver.Solve();
@@ -158,11 +158,11 @@ static void AugLagTest() {
     problem::Problem prob = def.MakeProblem();
     augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> alsolver(N);
     alsolver.InitializeFromProblem(prob);
-    auto Z = def.InitialTrajectory();
+    auto Z = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
     alsolver.SetTrajectory(Z);
     alsolver.GetOptions().constraint_tolerance = 1e-6;
     alsolver.Solve();
-    *Z = *def.InitialTrajectory();
+    *Z = def.InitialTrajectory();
     alsolver.Solve();
     EXPECT(alsolver.GetStats().iterations_total == 14);
     EXPECT(alsolver.GetStats().iterations_outer == 5);
@@ -174,7 +174,7 @@ static void AugLagTest() {
     problem::Problem prob = def.MakeProblem();
     augmented_lagrangian::AugmentedLagrangianiLQR<3, 2> alsolver(N);
     alsolver.InitializeFromProblem(prob);
-    alsolver.SetTrajectory(def.InitialTrajectory());
+    alsolver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
     alsolver.Solve();
     std::vector<constraints::ConstraintInfo> coninfo = alsolver.GetConstraintInfo();
     EXPECT((int)coninfo.size() == N + 1);
@@ -190,14 +190,14 @@ static void AugLagTest() {
   CASE("AugLagTest.TwoSolves (:249-287): second inner solve after a dual and penalty update takes one iteration");
   {
     auto alsolver = def.MakeALSolver();
-    alsolver->GetiLQRSolver().Solve();
-    EXPECT(alsolver->GetiLQRSolver().GetStats().iterations_inner == 10);
-    EXPECT(std::abs(alsolver->GetMaxViolation() - 0.00017691645708972636) / 0.00017691645708972636 < 1e-6);
-    alsolver->UpdateDuals();
-    alsolver->UpdatePenalties();
-    alsolver->GetiLQRSolver().Solve();
-    EXPECT(alsolver->GetiLQRSolver().GetStats().iterations_inner == 1);
-    EXPECT(std::abs(alsolver->MaxViolation() - 6.26e-5) / 6.26e-5 < 0.1);
+    alsolver.GetiLQRSolver().Solve();
+    EXPECT(alsolver.GetiLQRSolver().GetStats().iterations_inner == 10);
+    EXPECT(std::abs(alsolver.GetMaxViolation() - 0.00017691645708972636) / 0.00017691645708972636 < 1e-6);
+    alsolver.UpdateDuals();
+    alsolver.UpdatePenalties();
+    alsolver.GetiLQRSolver().Solve();
+    EXPECT(alsolver.GetiLQRSolver().GetStats().iterations_inner == 1);
+    EXPECT(std::abs(alsolver.MaxViolation() - 6.26e-5) / 6.26e-5 < 0.1);
   }
 }
 
@@ -212,24 +212,24 @@ static void ExampleTests() {
     ilqr::iLQR<3, 2> al = def.MakeSolver(true);
     EXPECT(std::abs(al.Cost() - 141.9639680271223) < 1e-6);
     auto solver = def.MakeALSolver();
-    solver->SetPenalty(10.0);
-    EXPECT(std::abs(solver->GetiLQRSolver().Cost() - 221.6032851439234) < 1e-6);
-    solver->Solve();
-    EXPECT(solver->GetStatus() == SolverStatus::kSolved);
-    EXPECT(solver->MaxViolation() < 1e-4);
-    EXPECT(solver->GetStats().cost_decrease.back() < 1e-4);
-    EXPECT(solver->GetStats().gradient.back() < 1e-2);
-    EXPECT(solver->GetStats().iterations_total == 50 && solver->GetStats().iterations_outer == 5);
+    solver.SetPenalty(10.0);
+    EXPECT(std::abs(solver.GetiLQRSolver().Cost() - 221.6032851439234) < 1e-6);
+    solver.Solve();
+    EXPECT(solver.GetStatus() == SolverStatus::kSolved);
+    EXPECT(solver.MaxViolation() < 1e-4);
+    EXPECT(solver.GetStats().cost_decrease.back() < 1e-4);
+    EXPECT(solver.GetStats().gradient.back() < 1e-2);
+    EXPECT(solver.GetStats().iterations_total == 50 && solver.GetStats().iterations_outer == 5);
   }
   CASE("ExampleTripleIntegrator (example_triple_integrator_test.cpp:16-70)");
   {
-    problems::TripleIntegratorProblem def;
+    problems::TripleIntegratorProblem<> def;
     augmented_lagrangian::AugmentedLagrangianiLQR<6, 2> uncon(def.MakeProblem(false));
-    uncon.SetTrajectory(def.InitialTrajectory());
+    uncon.SetTrajectory(std::make_shared<Trajectory<6, 2>>(def.InitialTrajectory()));
     uncon.Solve();
     EXPECT(uncon.GetStats().iterations_total == 2 && uncon.GetStatus() == SolverStatus::kSolved);
     augmented_lagrangian::AugmentedLagrangianiLQR<6, 2> con(def.MakeProblem(true));
-    auto Z = def.InitialTrajectory();
+    auto Z = std::make_shared<Trajectory<6, 2>>(def.InitialTrajectory());
     con.SetTrajectory(Z);
     con.Solve();
     EXPECT(con.GetStatus() == SolverStatus::kSolved);
@@ -250,7 +250,7 @@ static void ExampleTests() {
       threw = true;
     }
     EXPECT(threw);
-    solver.SetTrajectory(def.InitialTrajectory());
+    solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
     solver.Solve();
     EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.GetStats().iterations_total == 11);
   }
@@ -367,9 +367,9 @@ static void KnotTimeTests() {
     problems::UnicycleProblem def;
     auto pa = def.MakeALSolver();
     auto pb = def.MakeALSolver();
-    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>&a = *pa, &b = *pb;
-    auto Za = def.InitialTrajectory();
-    auto Zb = def.InitialTrajectory();
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>&a = pa, &b = pb;
+    auto Za = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
+    auto Zb = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
     EXPECT(Za->IsUniformStep());
     const int N = Zb->NumSegments();
     for (int k = 0; k < N; ++k) Zb->SetStep(k, Za->GetStep(k) * (k == 0 ? 1.0f : 1.0f));
@@ -387,7 +387,7 @@ static void KnotTimeTests() {
       for (int i = 0; i < 3; ++i) worst = std::max(worst, std::abs(Za->State(k)[i] - Zb->State(k)[i]));
     EXPECT(worst < 1e-9);
     // a genuinely non-uniform grid (finer at the start) still solves, to a different trajectory
-    auto Zc = def.InitialTrajectory();
+    auto Zc = std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory());
     float t = 0.0f;
     for (int k = 0; k < N; ++k) {
       const float h = Za->GetStep(0) * (0.5f + static_cast<float>(k) / static_cast<float>(N - 1));
@@ -397,7 +397,7 @@ static void KnotTimeTests() {
     }
     Zc->SetTime(N, t);
     auto pc = def.MakeALSolver();
-    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& c = *pc;
+    augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& c = pc;
     c.SetTrajectory(Zc);
     c.Solve();
     EXPECT(c.GetStatus() == SolverStatus::kSolved && c.MaxViolation() < 1e-4);
@@ -558,7 +558,7 @@ static void RecordingPolicyTests() {
   CASE("Solve() of a small batch takes the persistent kernel; the step-level BackwardPass() records the cost-to-go");
   problems::UnicycleProblem def;
   auto ps = def.MakeALSolver();
-  augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& solver = *ps;
+  augmented_lagrangian::AugmentedLagrangianiLQR<3, 2>& solver = ps;
   solver.GetOptions().profiler_enable = true;
   solver.Solve();
   EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.GetStats().iterations_total == 11);
@@ -572,22 +572,22 @@ static void RecordingPolicyTests() {
   }
   EXPECT(threw);
   // ... but the read told the solver that its user wants P, p: every later Solve() keeps them, as the reference does
-  solver.SetTrajectory(def.InitialTrajectory());
+  solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();
   EXPECT(solver.GetStats().iterations_total == 11 && solver.GetTiming().fused_sweeps == 0);
   EXPECT(solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient().size() == 3);
   solver.GetiLQRSolver().SetRecordCostToGo(false);  // explicit: never
-  solver.SetTrajectory(def.InitialTrajectory());
+  solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();
   EXPECT(solver.GetTiming().fused_sweeps > 0);
   solver.GetiLQRSolver().SetRecordCostToGo(true);
-  solver.SetTrajectory(def.InitialTrajectory());
+  solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();
   EXPECT(solver.GetStats().iterations_total == 11 && solver.GetTiming().fused_sweeps == 0);
   EXPECT(solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient().size() == 3);
   CASE("The history follows max_iterations_total (no silent truncation at 300 rows)");
   solver.GetOptions().max_iterations_total = 450;
-  solver.SetTrajectory(def.InitialTrajectory());
+  solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();
   EXPECT(solver.GetiLQRSolver().HistoryRowsNeeded() == 452 && solver.GetStats().iterations_total == 11);
   EXPECT(solver.GetStats().cost.size() == 12);
