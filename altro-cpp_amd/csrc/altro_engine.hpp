@@ -114,7 +114,17 @@ class Engine final : public EngineBase {
 
   // ---- problem upload -------------------------------------------------------------------------
   altro_status Upload(const ProblemSpec& spec, std::string* err) override {
-    altro_status st = UploadImpl(spec);
+    altro_status st;
+    if (uploaded_) {
+      err_ = "problem definition changed after the device state was created; create a new handle";
+      st = ALTRO_NOT_READY;
+    } else {
+      st = UploadImpl(spec);
+      // EVERY failed upload -- a rejected argument, a failed allocation, a HIP error half-way -- leaves the engine as it
+      // was before it: buffers, chain streams and the chain booking of the partial upload go, so that the retry neither
+      // leaks them nor meets its own ChainClaim
+      if (st != ALTRO_OK) DropUpload();
+    }
     if (st != ALTRO_OK && err) *err = err_;
     return st;
   }
@@ -606,6 +616,15 @@ class Engine final : public EngineBase {
       hipLaunchKernelGGL((k_forward<T, M>), grid, dim3(kBlock), 0, cur_, A, d_pd_, d, mode, all, fwd_per_wave_);
     }
   }
+  static void CpuRelax() {  // one spin-wait hint, whatever the host CPU
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#else
+    std::this_thread::yield();
+#endif
+  }
   bool StepOk() {
     if (pd_.hstep > 0.0f || A_.hk) return true;
     err_ = "the integration step is not set (altro_set_uniform_step / Trajectory::SetUniformStep)";
@@ -651,7 +670,26 @@ class Engine final : public EngineBase {
       chain_ev_[c] = nullptr;
     }
     chains_ = 1;
+    // (the history buffers and the recording switches belong to the handle, not to the upload)
+    double* const hist = A_.hist;
+    int* const hist_len = A_.hist_len;
+    const int hist_cap = A_.hist_cap, record_ctg = A_.record_ctg;
     std::memset(&A_, 0, sizeof(A_));
+    A_.hist = hist;
+    A_.hist_len = hist_len;
+    A_.hist_cap = hist_cap;
+    A_.record_ctg = record_ctg;
+    d_tmp_ = nullptr;
+    d_list_[0] = d_list_[1] = nullptr;
+    d_iota_ = d_merged_ = nullptr;
+    d_spec_go_ = nullptr;
+    d_spec_io_ = nullptr;
+    d_spec_kd_ = nullptr;
+    X_init_ = U_init_ = nullptr;
+    d_phi_ = nullptr;
+    d_pd_ = nullptr;
+    d_scalarT_ = nullptr;
+    d_scalarI_ = nullptr;
   }
   void Release() {
     if (hipSetDevice(desc_.device_id) != hipSuccess) return;
@@ -753,9 +791,16 @@ class Engine final : public EngineBase {
   // Build the device problem description from the recorded setter calls.
   altro_status UploadImpl(const ProblemSpec& s) {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
-    if (uploaded_) {
-      err_ = "problem definition changed after the device state was created; create a new handle";
-      return ALTRO_NOT_READY;
+    // per-knot models (Problem::SetDynamics(model, k), problem.hpp:155-166): indices into the source's ALTRO_USER_MODELS,
+    // checked before anything is allocated
+    for (size_t k = 0; k < s.knot_model.size() && (int)k < desc_.N; ++k) {
+      const int w = s.knot_model[k];
+      if (w < 0 || w >= kModelCount) {
+        err_ = "altro_set_knot_models: knot " + std::to_string(k) + " asks for model " + std::to_string(w) + ", this handle's model " +
+               (kModelCount > 1 ? "source lists " + std::to_string(kModelCount) + " models (ALTRO_USER_MODELS)"
+                                : std::string("is a single model (a user source with #define ALTRO_USER_MODELS A, B, ... holds several)"));
+        return ALTRO_INVALID_ARG;
+      }
     }
     B_ = desc_.batch;
     N_ = desc_.N;
@@ -1357,18 +1402,8 @@ class Engine final : public EngineBase {
     A_.xcd_remap = 1;  // (ALTRO_HIP_XCD_REMAP=0: workgroup i takes slot block i, round 3)
     if (const char* e = std::getenv("ALTRO_HIP_XCD_REMAP")) A_.xcd_remap = atoi(e) != 0;
     if (!s.knot_model.empty()) {
-      // per-knot models (Problem::SetDynamics(model, k), problem.hpp:155-166): indices into the source's ALTRO_USER_MODELS
       bool any = false;
-      for (int k = 0; k < N_; ++k) {
-        const int w = s.knot_model[k];
-        if (w < 0 || w >= kModelCount) {
-          err_ = "altro_set_knot_models: knot " + std::to_string(k) + " asks for model " + std::to_string(w) + ", this handle's model " +
-                 (kModelCount > 1 ? "source lists " + std::to_string(kModelCount) + " models (ALTRO_USER_MODELS)"
-                                  : std::string("is a single model (a user source with #define ALTRO_USER_MODELS A, B, ... holds several)"));
-          return ALTRO_INVALID_ARG;
-        }
-        any = any || w != 0;
-      }
+      for (int k = 0; k < N_; ++k) any = any || s.knot_model[k] != 0;
       if (any) {
         int* dkm = nullptr;
         ALTRO_ALLOC(dkm, (size_t)N_ + 1);
@@ -1386,9 +1421,8 @@ class Engine final : public EngineBase {
     if (st == ALTRO_OK) st = SetInitialStateImpl(s);
     if (st == ALTRO_OK) st = SetKnotTimesImpl(s);
     if (st == ALTRO_OK) st = SetTrajectoryImpl(s);
-    // (a failed upload leaves the engine as it was before it: the C-ABI keeps the handle "not uploaded" and the next
-    //  call uploads again instead of meeting "problem definition changed")
-    if (st != ALTRO_OK) DropUpload();
+    // (a failed upload leaves the engine as it was before it -- Upload() drops whatever a failed UploadImpl built: the
+    //  C-ABI keeps the handle "not uploaded" and the next call uploads again instead of meeting "problem definition changed")
     return st;
 #undef ALTRO_ALLOC
   }
@@ -1605,7 +1639,7 @@ class Engine final : public EngineBase {
         timing_.host_naps += 1;
         check_streams = (++naps & 0xf) == 0;
       } else {
-        __builtin_ia32_pause();
+        CpuRelax();
         check_streams = (++spins & 0x3ff) == 0 && !nap;
       }
       if (check_streams) {

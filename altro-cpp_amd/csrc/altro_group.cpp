@@ -334,8 +334,15 @@ altro_status altro_group_solve_al(altro_group g) {
       done[i] = 1;
       --left;
     }
-    // (a sleeping poll: the parts' worker threads and the device do the work; this thread only stamps completion times)
-    if (left > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    // (the parts' worker threads and the device do the work; this thread only stamps completion times.  The latency path --
+    //  a sub-millisecond solve of a few instances per device -- must not pay a 50 - 100 us timer sleep per solve: yield for
+    //  the first 300 us, sleep only once the solve has proven long)
+    if (left > 0) {
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 300.0)
+        std::this_thread::yield();
+      else
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
   }
   if (first != ALTRO_OK) return first;
   return altro_group_gather(g);

@@ -25,7 +25,7 @@ threads, instances built outside the timed region), ``host_boundary`` (the same 
 batch of 1 / 8 / 64 -- the MPC use case -- next to one host core).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--batch B] [--no-cpu-baseline]
-                        [--no-other-configs] [--no-latency] [--no-fast-forward]
+                        [--no-other-configs] [--no-latency] [--no-fast-forward] [--no-pipeline2] [--no-numa-bind]
         (N > 1: one rank per GPU -- under torch.distributed.run as the driver launches it, or started plainly: bench.py
          then launches its N ranks itself, `self_launch`.  `--launch-check`: the rank plumbing alone, no GPU, gloo.)
 """
@@ -291,18 +291,38 @@ def self_launch(ngpus, argv):
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks ourselves --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>
     bench.py <the same arguments>` -- one rank per GPU; rank 0 of that job prints the ONE JSON line on our stdout."""
-    import socket
     import subprocess
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # (--standalone: torchrun's c10d rendezvous picks its own free port -- no bind / close / reuse race between eight
+    #  benchmark jobs starting together; --local-addr: the container's hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(ngpus), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it)
     env["ALTRO_BENCH_SELF_LAUNCHED"] = "1"
     return subprocess.run(cmd, env=env).returncode
+
+
+def bind_to_gpu_numa_node(torch, local_rank):
+    """Multi-rank runs: keep this rank's host threads (the sweep loop's polling thread, the async worker, RCCL's proxy) on
+    the NUMA node its GPU hangs off -- the pinned, mapped counters the device publishes and the kernel launches then stay
+    on the socket next to the GPU.  Best effort: returns what was done for the bench line, or None."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "bound": False, "why": "the platform reports no NUMA node for the device"}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return {"pci": bdf, "numa_node": node, "bound": False, "why": "no CPU of the node in this process's affinity mask"}
+        os.sched_setaffinity(0, allowed)
+        return {"pci": bdf, "numa_node": node, "bound": True, "cpus": len(allowed)}
+    except Exception as e:  # (never fail a run for an affinity hint)
+        return {"bound": False, "why": str(e)[:120]}
 
 
 def launch_check(args, rank, local_rank, world):
@@ -384,8 +404,9 @@ def compute_side(key, config_index, avg_launch_us):
             # duration for its own flops (both from the same launches)
             us = float(tj["avg_launch_us"])
             tf = flop / (us * 1e-6) / 1e12
-            return {"bound": "valu_f64", "achieved": round(tf, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 5), "fp64_valu_flop_per_launch": round(flop),
+            # (named for what it is: a figure of the COMMITTED profile -- its flops over its own launch time -- not of this run)
+            return {"bound": "valu_f64", "profile_achieved": round(tf, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "profile_frac": round(tf / FP64_VALU_PEAK_TFLOPS, 5), "fp64_valu_flop_per_launch": round(flop),
                     "profile_avg_launch_us": round(us, 2), "live_avg_launch_us": round(avg_launch_us, 2),
                     "valu_busy_frac": tj.get("valu_busy_frac"), "source": os.path.relpath(f, ROOT)}
         except Exception:
@@ -528,6 +549,9 @@ def main():
     ap.add_argument("--share-devices", action="store_true",
                     help="device = local_rank %% visible devices (several ranks on one GPU; tests only, needs --dist-backend gloo)")
     ap.add_argument("--no-fast-forward", action="store_true", help="skip the secondary `fast_forward` key")
+    ap.add_argument("--no-pipeline2", action="store_true", help="skip the secondary `pipeline_2` key (two handles in flight)")
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="multi-rank runs bind each rank's host threads to the NUMA node of its GPU; this switches it off")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -558,6 +582,7 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible): --gpus N needs N "
                          f"GPUs on this node (tests: --dist-backend gloo --share-devices lets the ranks share one)")
     torch.cuda.set_device(local_rank)
+    numa = bind_to_gpu_numa_node(torch, local_rank) if (world > 1 and not args.no_numa_bind) else None
 
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
@@ -677,7 +702,12 @@ def main():
                       "env_world_size": int(os.environ.get("WORLD_SIZE", "1")),
                       "records_match_get_stats": bool(flag.item() == 1.0),
                       "gather_is_separate_buffer": bool(gathered.data_ptr() != packed.data_ptr()),
-                      "rank_ms_per_step": [round(1e3 * e / args.steps, 3) for e in rank_elapsed]}
+                      "rank_ms_per_step": [round(1e3 * e / args.steps, 3) for e in rank_elapsed],
+                      # (load imbalance is the only scaling loss of this path: a SCALE record diagnoses it at a glance)
+                      "rank_ms_min": round(1e3 * min(rank_elapsed) / args.steps, 3),
+                      "rank_ms_max": round(1e3 * max(rank_elapsed) / args.steps, 3),
+                      "rank_ms_mean": round(1e3 * sum(rank_elapsed) / len(rank_elapsed) / args.steps, 3),
+                      "numa": numa}
     status = res[:, 3].astype(int)
     iters = res[:, 2]
     solved = int((status == 0).sum())
@@ -788,6 +818,58 @@ def main():
                 sf.close()
             finally:
                 del os.environ["ALTRO_HIP_FAST_FORWARD_STALLS"]
+        # ---- SECONDARY, never `value`: TWO handles in flight (asynchronous solves on their own streams): the latency-bound
+        #      tail of one batch -- ~100 stragglers on as many CUs -- overlaps the throughput-bound sweeps of the next.
+        #      Every step is still one complete solve of the headline's batch; the records of BOTH handles are compared
+        #      with the headline's ----
+        pipeline_2 = None
+        if world == 1 and args.pipeline == 1 and cfg["mode"] == "al" and not args.no_pipeline2:
+            if others is None and latency is None and fast_forward is None:
+                solver.close()
+            pool = [new_solver(), new_solver()]
+            pend = [False, False]
+            same = [None, None]
+
+            def pstep(i, check=False):
+                s_ = pool[i]
+                if pend[i]:
+                    s_.wait()
+                    s_.pack_results_device(packed.data_ptr())
+                    if check:
+                        same[i] = bool(np.array_equal(packed.cpu().numpy(), res[:B]))
+                s_.reset_trajectory()
+                s_.solve_async()
+                pend[i] = True
+
+            def pdrain(check=False):
+                for i, s_ in enumerate(pool):
+                    if pend[i]:
+                        s_.wait()
+                        s_.pack_results_device(packed.data_ptr())
+                        if check:
+                            same[i] = bool(np.array_equal(packed.cpu().numpy(), res[:B]))
+                        pend[i] = False
+
+            for i in range(2 * max(1, args.warmup)):
+                pstep(i % 2)
+            pdrain()
+            torch.cuda.synchronize()
+            psteps = 2 * max(1, min(args.steps, 10) // 2)
+            p0 = time.perf_counter()
+            for i in range(psteps):
+                pstep(i % 2)
+            pdrain()
+            torch.cuda.synchronize()
+            pel = time.perf_counter() - p0
+            pstep(0), pstep(1)  # (untimed: one more solve per handle whose records are read back and compared)
+            pdrain(check=True)
+            pipeline_2 = {"ms_per_step": round(1e3 * pel / psteps, 3), "value": round(solved * psteps / pel, 1),
+                          "unit": "trajectories/s", "steps": psteps, "handles_in_flight": 2,
+                          "records_identical_to_headline": bool(same[0] and same[1]),
+                          "note": "NOT the headline: two solver handles in flight (altro_solve_al_async), each step one complete "
+                                  "solve of the headline's batch; the tail of one solve overlaps the sweeps of the next"}
+            for s_ in pool:
+                s_.close()
         # ---- the achievable HBM ceiling of this device beside the data-sheet peak ----
         try:
             copy_gbs = measure_hbm_copy_gbs(torch, dev)
@@ -827,6 +909,7 @@ def main():
             "other_configs": others,
             "latency": latency,
             "fast_forward": fast_forward,
+            "pipeline_2": pipeline_2,
             **({"dist_check": dist_check} if dist_check is not None else {}),
         }
         print(json.dumps(out), flush=True)

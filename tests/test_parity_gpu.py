@@ -6,21 +6,24 @@ Tolerances:
   sin/cos rounding, which the iterations amplify by a few orders of magnitude.
   ALTRO_F32 engine (fp32 records, fp64 state and arithmetic): tests/test_f32_gpu.py.
 """
+import inspect
 import os
 
 import numpy as np
 import pytest
+
+import _ledger
 
 pytestmark = pytest.mark.gpu
 
 RT, AT = 1e-7, 1e-9
 
 
-def close(a, b, rtol=RT, atol=AT):
-    a, b = np.asarray(a), np.asarray(b)
-    err = np.abs(a - b)
-    tol = atol + rtol * np.maximum(np.abs(a), np.abs(b))
-    assert (err <= tol).all(), f"max err {err.max():.3e} (rel {(err / (np.abs(b) + 1e-300)).max():.3e})"
+def close(a, b, rtol=RT, atol=AT, label=None):
+    """Elementwise bar; the measured maxima go to the ledger (tests/_ledger.py -> profiles/r05_parity_errors.json)."""
+    if label is None:
+        label = f"line {inspect.currentframe().f_back.f_lineno}"
+    _ledger.close(a, b, rtol, atol, label)
 
 
 def both(P, factory, oracle_make, hip_make, **kw):
@@ -67,6 +70,52 @@ def test_step_level_unicycle(P, oracle_make, hip_make):
         close(Ug, Uo, 1e-8, 1e-10)
         close(g.get_constraint_values(), o.get_constraint_values(), 1e-8, 1e-10)
     assert g.get_stats()["alpha"][0] == 0.0625 or it  # K11 on instance 0 checked below
+
+
+def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
+    """The n = 12 path at STEP level against the oracle: one expansions / backward / forward sweep of
+    batch_quadrotor12 in fp64 -- [A|B], lxx ... lu of k_expansions (RK4 Jacobian chain with its structural zeros), K, d and
+    P, p of k_backward_mfma16 (the fp64 16x16x4 MFMA Riccati step), the line search of k_forward2 -- each against an
+    absolute bar.  Two sweeps: the second runs on the trajectory the first one accepted (non-trivial gains and states)."""
+    N = 200
+    o, g = both(P, P.batch_quadrotor12, oracle_make, hip_make, batch=6, N=N, dtype=A.F64)
+    for s in (o, g):
+        s.set_record_ctg(True)
+        s.rollout()
+    close(g.cost(), o.cost(), 1e-12, 0.0, label="initial cost")
+    close(g.get_trajectory()[0], o.get_trajectory()[0], 1e-12, 1e-13, label="X rollout")
+    for it in range(2):
+        for s in (o, g):
+            s.update_expansions()
+        for k in (0, 1, 100, N - 1, N):
+            eo, eg = o.get_expansion(k), g.get_expansion(k)
+            for key in ("lxx", "lx") + (("A", "B", "lxu", "luu", "lu") if k < N else ()):
+                close(eg[key], eo[key], 1e-10, 1e-12, label=f"expansion {key} (sweep {it})")
+        close(g.get_knot_costs(), o.get_knot_costs(), 1e-11, 1e-13, label=f"knot costs (sweep {it})")
+        close(g.get_constraint_values(), o.get_constraint_values(), 1e-10, 1e-11, label=f"constraint values (sweep {it})")
+        for s in (o, g):
+            s.backward_pass()
+        assert (o.get_stats()["regularization"] == g.get_stats()["regularization"]).all()
+        Ko, do = o.get_gains()
+        Kg, dg = g.get_gains()
+        Po, po = o.get_ctg()
+        Pg, pg = g.get_ctg()
+        # norm-wise per knot block: an m x n gain block / n x n cost-to-go block has entries 1e-8 of its largest one
+        # (decoupled axes), for which an element-wise relative bar is meaningless; SURVEY 8(c): rel 1e-9
+        close_normwise(Kg.reshape(-1, 4, 12), Ko.reshape(-1, 4, 12), 1e-9, label=f"K per knot, normwise (sweep {it})")
+        close_normwise(dg.reshape(-1, 4), do.reshape(-1, 4), 1e-9, label=f"d per knot, normwise (sweep {it})")
+        close_normwise(Pg.reshape(-1, 12, 12), Po.reshape(-1, 12, 12), 1e-9, label=f"P per knot, normwise (sweep {it})")
+        close_normwise(pg.reshape(-1, 12), po.reshape(-1, 12), 1e-9, label=f"p per knot, normwise (sweep {it})")
+        for s in (o, g):
+            s.forward_pass()
+        so, sg = o.get_stats(), g.get_stats()
+        assert (so["alpha"] == sg["alpha"]).all(), (so["alpha"], sg["alpha"])
+        close(sg["cost"], so["cost"], 1e-9, 0.0, label=f"cost after the line search (sweep {it})")
+        close(sg["improvement_ratio"], so["improvement_ratio"], 1e-7, 0.0, label=f"z (sweep {it})")
+        Xo, Uo = o.get_trajectory()
+        Xg, Ug = g.get_trajectory()
+        close(Xg, Xo, 1e-9, 1e-11, label=f"X after the line search (sweep {it})")
+        close(Ug, Uo, 1e-9, 1e-11, label=f"U after the line search (sweep {it})")
 
 
 def test_reference_constants_on_gpu(P, hip_make):
@@ -130,13 +179,9 @@ def test_reference_constants_on_gpu(P, hip_make):
     assert s.max_violation()[0] < 1e-4
 
 
-def close_normwise(a, b, rtol):
+def close_normwise(a, b, rtol, label="normwise"):
     """max-norm error relative to the max-norm of the reference block (per instance)."""
-    a, b = np.asarray(a), np.asarray(b)
-    ax = tuple(range(1, a.ndim))
-    err = np.abs(a - b).max(axis=ax)
-    ref = np.abs(b).max(axis=ax)
-    assert (err <= rtol * np.maximum(ref, 1e-12)).all(), f"max normwise rel err {(err / np.maximum(ref, 1e-12)).max():.3e}"
+    _ledger.close_normwise(a, b, rtol, label)
 
 
 def test_history_matches_oracle(P, oracle_make, hip_make):
@@ -168,18 +213,18 @@ def _compare_full(o, g, solved_only_tight=True, xtol=(RT, AT), gtol=1e-6):
     ok = so["status"] == 0 if solved_only_tight else np.ones(len(so), bool)
     Xo, Uo = o.get_trajectory()
     Xg, Ug = g.get_trajectory()
-    close(Xg[ok], Xo[ok], *xtol)
-    close(Ug[ok], Uo[ok], *xtol)
+    close(Xg[ok], Xo[ok], *xtol, label="X")
+    close(Ug[ok], Uo[ok], *xtol, label="U")
     Ko, do = o.get_gains()
     Kg, dg = g.get_gains()
-    close_normwise(Kg[ok], Ko[ok], gtol)
-    close(dg[ok], do[ok], max(gtol, 1e-5), max(1e-7, 0.1 * gtol))  # d -> 0 at convergence: absolute floor
+    close_normwise(Kg[ok], Ko[ok], gtol, label="K normwise")
+    close(dg[ok], do[ok], max(gtol, 1e-5), max(1e-7, 0.1 * gtol), label="d")  # d -> 0 at convergence: absolute floor
     if o.num_constraints() > 0:
         # a dual is lambda - rho*c with rho up to 1e4..1e8: 1e-12 in c shows up as rho*1e-12
-        close(g.get_duals()[ok], o.get_duals()[ok], 1e-5, 1e-7)
-        close(g.get_penalties(), o.get_penalties(), 0, 0)
+        close(g.get_duals()[ok], o.get_duals()[ok], 1e-5, 1e-7, label="duals")
+        close(g.get_penalties(), o.get_penalties(), 0, 0, label="penalties")
     for f in ("cost", "violation", "max_penalty", "alpha", "regularization"):
-        close(sg[f][ok], so[f][ok], 1e-7, 1e-10)
+        close(sg[f][ok], so[f][ok], 1e-7, 1e-10, label="stat " + f)
     return so, sg
 
 
@@ -259,6 +304,8 @@ def _config5_against_oracle(P, A, oracle_make, hip_make, oracle_lib, batch):
     print("config 5 fp64: GPU-vs-oracle error", {k: f"{v:.2e}" for k, v in err.items()},
           "oracle's own 1-ulp sensitivity", {k: f"{v:.2e}" for k, v in spread.items()})
     for k in err:  # the GPU differs from the oracle by no more than the oracle differs from itself
+        _ledger.record(f"config5 {k} (GPU vs oracle; bar = 4 x the oracle's own 1-ulp sensitivity)", err[k], err[k],
+                       err[k] / (4.0 * spread[k] + 1e-12), note=f"oracle 1-ulp spread {spread[k]:.3e}")
         assert err[k] <= 4.0 * spread[k] + 1e-12, (k, err[k], spread[k])
     assert np.allclose(sg["cost"], so["cost"], rtol=1e-7)
 
@@ -332,12 +379,15 @@ def test_config3_full_batch_against_oracle(P, A, oracle_make, hip_make, oracle_l
     # solved instances: exact schedule.  The 99 stragglers ride a line search down to alpha = 2^-19 for ~100
     # iterations; today all 4096 instances match (max |dX| 6e-13) -- two may flip before this fails
     assert same[solved].all(), np.flatnonzero(~same & solved)[:10]
+    # explicit counter of tolerated schedule flips (stragglers only; printed with their instance ids, kept in the ledger)
+    _ledger.count("schedule flips among the unsolved stragglers (4096 instances)", (~same).sum(), 2, np.flatnonzero(~same))
     assert (~same).sum() <= 2, (~same).sum()
     Xo, Uo = o.get_trajectory()
     Xg, Ug = g.get_trajectory()
-    assert np.allclose(Xg[solved], Xo[solved], rtol=1e-7, atol=1e-9)
-    assert np.allclose(Ug[solved], Uo[solved], rtol=1e-6, atol=1e-8)
-    assert np.allclose(sg["cost"][solved], so["cost"][solved], rtol=1e-10)
+    close(Xg[solved], Xo[solved], 1e-7, 1e-9, label="X solved instances")
+    close(Ug[solved], Uo[solved], 1e-6, 1e-8, label="U solved instances")
+    close(Xg[~solved & same], Xo[~solved & same], 1e-6, 1e-8, label="X stragglers (same schedule)")
+    close(sg["cost"][solved], so["cost"][solved], 1e-10, 0.0, label="cost solved instances")
 
 
 @pytest.mark.parametrize("no_fused", [False, True])
