@@ -326,6 +326,17 @@ ALTRO_DEV void fdlibm_sincos_kernels(double r, double* s, double* c) {
   *c = w + (((1.0 - w) - hz) + z * (z * pc));
 }
 
+// The rare path of sincos_ (|x| >= 1e5: a line-search trial that blew up): ocml's sincos with its Payne-Hanek argument
+// reduction, ~1 200 instructions and ~160 live registers per inlined copy (the rollout wave alone inlines six).  Round 5
+// measured the out-of-line alternative at compile level (-DALTRO_SINCOS_BIG_NOINLINE, profiles/r05_spill_map.txt): the
+// persistent kernel's vgpr_spill_count falls from 210 - 218 to 4 - 8 -- the spilled values live in these cold copies, not
+// on the knot-to-knot chains -- but a call inside the kernel costs 40 B of scratch per lane and moves ~15 more SGPR
+// spill reloads (v_readlane) per knot INTO the MFMA recursion.  Inline stays the default.
+#ifdef ALTRO_SINCOS_BIG_NOINLINE
+__device__ __attribute__((noinline)) inline void sincos_big(double x, double* s, double* c) { sincos(x, s, c); }
+#else
+ALTRO_DEV void sincos_big(double x, double* s, double* c) { sincos(x, s, c); }
+#endif
 template <>
 ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
   // Arguments of 1e5 and beyond (a line-search trial that blew up) take ocml's path with its full argument
@@ -345,7 +356,7 @@ ALTRO_DEV void sincos_<double>(double x, double* s, double* c) {
   double so = (q & 2) ? -s0 : s0;
   double co = ((q + 1) & 2) ? -c0 : c0;
   if (__builtin_expect(__ballot(big) != 0ull, 0)) {
-    if (big) sincos(x, &so, &co);
+    if (big) sincos_big(x, &so, &co);
   }
   *s = so;
   *c = co;
