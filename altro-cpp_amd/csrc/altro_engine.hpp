@@ -680,6 +680,8 @@ class Engine final : public EngineBase {
     A_.hist_cap = hist_cap;
     A_.record_ctg = record_ctg;
     d_tmp_ = nullptr;
+    d_twin_box_ = nullptr;
+    twin_cap_ = 0;
     d_list_[0] = d_list_[1] = nullptr;
     d_iota_ = d_merged_ = nullptr;
     d_spec_go_ = nullptr;
@@ -805,6 +807,20 @@ class Engine final : public EngineBase {
     B_ = desc_.batch;
     N_ = desc_.N;
     Bp_ = ((B_ + kBlock - 1) / kBlock) * kBlock;
+    // Twin workgroups of the persistent kernel (TwinCtl, altro_kernels.hpp) clone an instance into a SHADOW COLUMN of the
+    // per-instance arrays: every array is allocated twin_cap_ instances wider (the stride of all of them is Bp_), one column
+    // per slot of a persistent launch.  ALTRO_HIP_TWIN=0: no columns, no twins.
+    twin_cap_ = 0;
+    if constexpr (kMfmaBackward) {
+      const char* e = std::getenv("ALTRO_HIP_TWIN");
+      if (!(e && atoi(e) == 0) && !fast_forward_ && !no_fused_) {
+        const int want = std::min(Bp_, ((persist_at_ + 8 + kBlock - 1) / kBlock) * kBlock);
+        // (the MFMA backward pass addresses the expansion records with 32-bit byte offsets: only widen while that holds)
+        const size_t bytes = ((size_t)kBwdFrontPad + (size_t)N_ + 2) * RR::EP * (size_t)(Bp_ + want) * sizeof(RS);
+        if (bytes < (size_t)0xffffffffu) twin_cap_ = want;
+      }
+    }
+    Bp_ += twin_cap_;
     std::memset(&pd_, 0, sizeof(pd_));
     pd_.n = n;
     pd_.m = m;
@@ -1158,6 +1174,7 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
     ALTRO_ALLOC(d_tmp_, bp);
+    if (twin_cap_ > 0) ALTRO_ALLOC(d_twin_box_, (size_t)twin_cap_ * kTwWords);
     ALTRO_ALLOC(d_list_[0], bp);
     ALTRO_ALLOC(d_list_[1], bp);
     {
@@ -1713,9 +1730,17 @@ class Engine final : public EngineBase {
           circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
         // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
         int* const out = d_counter_ + max_sweeps + 2;
-        const dim3 g(ninst), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
         SpecRemote<T> rs{};
         const int spec_mode_ = this->spec_mode_ == kSpecAuto ? (circles ? (int)kSpecWave : (int)kSpecFree) : this->spec_mode_;
+        // twin workgroups (TwinCtl): one behind every primary, dispatched after all of them (same launch, higher block
+        // indices); not with a recorded history (its rows are appended in iteration order) nor in helper mode
+        TwinCtl tw{};
+        if (twin_cap_ > 0 && !A.hist && spec_mode_ != kSpecHelper && !d.fast_forward_stalls) {
+          hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * kTwWords * sizeof(unsigned long long), stream_);
+          tw = TwinCtl{d_twin_box_, ninst, twin_cap_, Bp_ - twin_cap_};
+        }
+        const dim3 g(ninst + (tw.base > 0 ? std::min(ninst, twin_cap_) : 0)), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
+        timing_.twin_workgroups = tw.base > 0 ? (int)g.x - ninst : 0;  // twin workgroups of this launch
         if (spec_mode_ == kSpecHelper) {
           // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
           rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
@@ -1723,11 +1748,11 @@ class Engine final : public EngineBase {
           hipEventRecord(spec_ev_, stream_);
           hipStreamWaitEvent(HelperStream(), spec_ev_, 0);
           const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
-          hipLaunchKernelGGL((k_spec_helper<T, M>), g, dim3(kBlock), hl, HelperStream(), A, d, rs);
+          hipLaunchKernelGGL((k_spec_helper<T, M>), dim3(ninst), dim3(kBlock), hl, HelperStream(), A, d, rs);
           spec_helper_running_ = true;
         }
 #define ALTRO_FUSED(CC, S, BLK) \
-  hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs)
+  hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw)
         if (circles) {
           if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
           else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
@@ -1811,6 +1836,8 @@ class Engine final : public EngineBase {
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};
   double* d_tmp_ = nullptr;
+  int twin_cap_ = 0;                          // shadow columns behind the batch (twin workgroups of the persistent kernel)
+  unsigned long long* d_twin_box_ = nullptr;  // their mailboxes, [twin_cap_][kTwWords]
   int* d_list_[2] = {nullptr, nullptr};
   bool mfma_offsets_ok_ = false;
   // ALTRO_HIP_BACKWARD = valu | coop selects a fallback backward kernel (tests); ALTRO_HIP_VALU_BACKWARD: legacy

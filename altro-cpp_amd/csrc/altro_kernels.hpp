@@ -660,7 +660,7 @@ constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bu
 template <class T, class M, bool CTG, bool FUSED, bool SPEC = false>
 ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int all, int lane, int slot_base,
                                   double* sKD, T* sKDf, int fused_junk, double* fh, double spec_rho = 0.0,
-                                  double spec_drho = 0.0, int* nbar = nullptr) {
+                                  double spec_drho = 0.0, int* nbar = nullptr, int b_fixed = -1) {
   static_assert(!SPEC || FUSED, "the speculative pass is a variant of the fused one");
   // 4 x 4 tiles with the vectors riding as column n: n <= 3 states, m <= 2 controls (round 4: was n = 3, m = 2 only -- the
   // tile offsets below are generic; what m = 1 changes is the 2 x 2 inverse, see qc)
@@ -671,7 +671,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   using RR = Rec<RS, n, m>;
   static_assert(RR::KP == R::KP, "the gain chunk in LDS is laid out like the stored record");
   const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
-  const int b0 = (FUSED && blk != 0) ? -1 : instance_of_slot(A, slot_base + blk, all);
+  const int b0 = (FUSED && blk != 0) ? -1 : ((FUSED && b_fixed >= 0) ? b_fixed : instance_of_slot(A, slot_base + blk, all));
   const bool inst_on = b0 >= 0;
   if (__ballot(inst_on) == 0ull) return;
   const int b = inst_on ? b0 : 0;
@@ -1707,6 +1707,10 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     } else {
       const double gsum = accepted ? g_sel : gsum_rej;
       inner_done = conv_stats_and_done_pre(A, o, b, gsum, viol, pre, cost_cur, last_status) ? 1 : 0;
+      if (ff) {  // (persistent kernel: the counters this iteration leaves -- what a twin workgroup's hand-over compares)
+        ff[6] = (double)(pre.it_inner + 1);
+        ff[7] = (double)(pre.it_total + 1);
+      }
     }
   }
   if (mode == kFwdStepOnly) return;
@@ -1774,7 +1778,10 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
         }
         if (t == 0) {
           begin_inner_solve(A, o, b);
-          if (ff) ff[5] = 1.0;  // (persistent kernel: LDS mirror of need_init_cost)
+          if (ff) {
+            ff[5] = 1.0;  // (persistent kernel: LDS mirror of need_init_cost)
+            ff[6] = 0.0;  // ... and of it_inner
+          }
         }
       }
       active = cont != 0;
@@ -2758,7 +2765,7 @@ enum KdMode { kKdNone = 0, kKdFull = 1, kKdFeedforward = 2 };
 template <class T, class M>
 ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, const FwdLds<T>& L, unsigned char* smem_raw,
                               T* sPool, int per_wave, int all, int tt, int nthreads, int kd_mode,
-                              bool with_traj = true, int bid = -1) {
+                              bool with_traj = true, int bid = -1, int b_fixed = -1) {
   if (bid < 0) bid = blockIdx.x;
   const bool with_kd = kd_mode != kKdNone;
   constexpr int LS = kLineSearchLanes;
@@ -2788,7 +2795,8 @@ ALTRO_DEV void forward2_stage(const DevArrays<T>& A, const ProblemDesc* pd, cons
       int bgs[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        bgs[g] = g < per_wave ? instance_of_slot(A, bid * per_wave + g, all) : -1;
+        // (b_fixed: the persistent kernel names its instance itself -- a twin workgroup works on a shadow column)
+        bgs[g] = g < per_wave ? (b_fixed >= 0 ? b_fixed : instance_of_slot(A, bid * per_wave + g, all)) : -1;
         if (bgs[g] < 0) continue;
         const int b = bgs[g];  // RECP / SOA address this instance
         auto ldrec = [&](const T* src, int per, int cnt, int EP, int vi) -> V {
@@ -2895,7 +2903,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                              const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr,
                              const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
                              double* fhw = nullptr, const int* eahead_words = nullptr, int eahead_waves = 0,
-                             int eahead_tag = 0) {
+                             int eahead_tag = 0, int b_fixed = -1) {
   static_assert(!SOFT || FUSED, "software synchronisation is a mode of the persistent kernel");
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -2906,7 +2914,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const int t = lane - grp * LS;
   // (batched kernel: the workgroups that share cache lines of the instance-minor arrays run on one XCD, see xcd_block)
   const int bid = FUSED ? (int)blockIdx.x : xcd_block((int)blockIdx.x, (int)gridDim.x, A.xcd_remap);
-  const int b0 = (grp < per_wave) ? instance_of_slot(A, bid * per_wave + grp, all) : -1;
+  const int b0 = (grp < per_wave) ? (b_fixed >= 0 ? b_fixed : instance_of_slot(A, bid * per_wave + grp, all)) : -1;
   const int N = A.N;
   const bool valid = b0 >= 0;
   if (__ballot(valid) == 0ull) return;  // every wave takes the same decision
@@ -3239,7 +3247,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       // (not armed: the fourth wave just keeps the barrier count)
       if (spec->armed)
         backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, spec->sKD2, spec->junk2, spec->fh2,
-                                                    rho_in, drho_in, SOFT ? nullptr : &nbar);
+                                                    rho_in, drho_in, SOFT ? nullptr : &nbar, b_fixed);
       // (the pass placed its barriers itself; whatever is left of the N / 2 + 1 of the knot loop and A, S, V.  With
       //  software synchronisation the forward waves take no hardware barrier: the recursion ran at its own pace)
       if (spec->armed) ALTRO_STAMP_ADD(8, st_w3);
@@ -3469,10 +3477,75 @@ struct SpecRemote {
 };
 constexpr int kSpecPolls = 400;  // polls of the result flag before the recursion is run locally (~0.1 us each)
 
+// -------------------------------------------------------------------------------------------------
+// TWIN WORKGROUPS (round 5): the second half of a straggler's rejection streak, computed beside the first half.
+//
+// What the tail of a batched solve is made of (profiles/r04_experiments.txt #5, scripts/probe_stragglers.py): ~2 % of
+// the instances reject every trial of every line search for exactly max_iterations_inner iterations.  A rejected
+// iteration changes nothing but the regularisation -- by a rule known in advance (ilqr.hpp:550, :770-786) -- and the
+// iteration counters, so the state ENTERING iteration j + K of such a streak is known at iteration j, K steps of the
+// scalar rule away, PROVIDED every iteration in between is rejected as well.  The reference walks those iterations one
+// after the other on one core; here one straggler owns one CU for ~100 x 39 us while more than half of the CUs idle.
+//
+// So the launch carries, behind its `base` primary workgroups, one TWIN workgroup per slot.  A twin gets a CU when the
+// quick instances have left; it reads the snapshot its primary publishes at the end of every iteration of a streak
+// (counters, regularisation), CLAIMS the iterations from `start` on -- about half of what is left --, clones the
+// instance into a shadow column of the per-instance arrays (index col0 + slot: every array of DevArrays is allocated
+// that much wider), sets the entering state of iteration `start` there (counters advanced, regularisation stepped
+// through the increase / decrease rule, cost_prev = cost_cur) and runs the SAME code as every workgroup of this kernel
+// on that column: every iteration of the instance is still computed, with the inputs the sequential order would have
+// given it -- by two workgroups side by side instead of one.  The primary, arriving at `start`, compares what it holds
+// with what the twin assumed (bitwise: regularisation, counters, an unbroken streak since the snapshot): equal -> it hands
+// the instance over and leaves, and the twin, when its clone is finished, copies the column back over the instance's
+// own; different (an accepted step, an end of the inner solve, a Cholesky retry that moved the regularisation) -> it
+// refuses, goes on alone, and the twin drops its work.  Either way the result is the sequential one, bit for bit
+// (tests/test_fused_gpu.py::test_twin_workgroups_are_bit_identical); ALTRO_HIP_TWIN=0 launches no twins.
+//
+// Mailbox (global memory, one per slot, 64-bit words, relaxed agent-scope atomics = coherent across the XCDs' L2s; what
+// travels through ordinary memory -- the clone's source, the column copied back -- is ordered by ONE agent-scope release
+// of the primary per streak / hand-over and one acquire of the twin).  Every wait is bounded; a twin that gives up
+// revokes its claim with a compare-and-swap against the primary's hand-over, so an instance always has exactly one owner.
+// -------------------------------------------------------------------------------------------------
+struct TwinCtl {
+  unsigned long long* box;  // [cap][kTwWords], zeroed by the host before the launch
+  int base;                 // first twin block of the launch (0: no twins)
+  int cap;                  // slots that own a mailbox and a shadow column
+  int col0;                 // first shadow column
+};
+enum TwinWord {
+  kTwSeq = 0,        // version of the newest snapshot (0: none yet)
+  kTwSnap = 1,       // two snapshot buffers of 4 words: (it_inner << 32 | it_total), rho, drho, primary's loop count
+  kTwClaim = 9,      // (start_it_inner << 32 | start_it_total), written last by the twin
+  kTwClaimRho = 10,  // regularisation the twin assumes to enter iteration `start`
+  kTwClaimDrho = 11,
+  kTwClaimSnap = 12, // it_total of the snapshot the claim was derived from
+  kTwHand = 13,      // 0 open, kTwOk / kTwRefused (primary), kTwRevoked (twin): set once, by compare-and-swap
+  kTwHandLoops = 14, // the primary's loop count at the hand-over
+  kTwWords = 16
+};
+constexpr unsigned long long kTwOk = 1, kTwRefused = 2, kTwRevoked = 3;
+constexpr int kTwinMinRemaining = 12;   // iterations left in a streak below which a twin is not worth its start-up
+constexpr int kTwinLag = 3;             // iterations the primary advances while the twin clones and stages
+constexpr int kTwinIdlePolls = 200;     // polls (~3 us each) a twin waits for a streak before it gives its CU back
+constexpr int kTwinHandPolls = 1 << 16; // polls a finished twin waits for the primary's verdict (the primary answers at `start`)
+ALTRO_DEV unsigned long long tw_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ALTRO_DEV void tw_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a thread's earlier mailbox stores have left the CU before its later ones are issued
+ALTRO_DEV void tw_order() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+ALTRO_DEV bool tw_cas(unsigned long long* p, unsigned long long expect, unsigned long long v) {
+  return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ALTRO_DEV unsigned long long tw_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+ALTRO_DEV double tw_dbl(unsigned long long x) { return __longlong_as_double((long long)x); }
+
 template <class T, class M, bool CIRC, int SPEC>
 __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
     DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
-    int* sweeps_out, SpecRemote<T> rs) {
+    int* sweeps_out, SpecRemote<T> rs, TwinCtl tw) {
   constexpr int kThreads = (spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock;
   constexpr bool kWave4 = spec_has_wave4(SPEC), kSoft = SPEC == kSpecFree;
   using R = Rec<T, M::n, M::m>;
@@ -3481,8 +3554,14 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   const ProblemDesc* pd = &pd_arg;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (blockIdx.x == 0 && tid == 0) publish_count(A);
-  const int b = instance_of_slot(A, blockIdx.x, 0);
-  if (b < 0) return;  // uniform over the workgroup
+  // (twin workgroups, see TwinCtl: blocks [base, ...) of the launch serve the same slots as blocks [0, base))
+  const bool is_twin = tw.base > 0 && (int)blockIdx.x >= tw.base;
+  const int slot = is_twin ? (int)blockIdx.x - tw.base : (int)blockIdx.x;
+  const int b_real = instance_of_slot(A, slot, 0);
+  if (b_real < 0) return;  // uniform over the workgroup
+  unsigned long long* const box = (tw.base > 0 && slot < tw.cap && persistent) ? tw.box + (size_t)slot * kTwWords : nullptr;
+  if (is_twin && !box) return;
+  int b = b_real;  // (a twin switches to its shadow column once it has claimed its share of the iterations)
   const int N = A.N;
   const unsigned Bp = A.Bp;
   // LDS: the forward block of one instance, then {pool, hand-off slots, flags} exactly as k_forward2
@@ -3535,6 +3614,125 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   if (tid < 32) g_stamp_acc[tid] = 0;
   int spec_iters = 0;
 #endif
+  // ---- twin workgroups (TwinCtl): the primary's bookkeeping, the twin's claim and clone ----
+  int tw_streak = 0;               // primary: consecutive rejected iterations during which the inner solve went on
+  int tw_break_total = -1;         // primary: it_total left by the last iteration that was NOT one of those
+  unsigned long long tw_ver = 0;   // primary, thread 0: version of the newest snapshot
+  bool tw_closed = false;          // primary, thread 0: the mailbox is out of use
+  unsigned long long tw_claim = 0, tw_claim_rho = 0, tw_claim_drho = 0;  // primary, thread 0: the twin's claim, once seen
+  int tw_claim_snap = 0;
+  int tw_loops0 = 0;               // twin: iterations the primary ran before the hand-over
+  // report of this workgroup to the host (longest chain of iterations, units processed): both ways out of the kernel
+  auto report = [&](int chain_loops, int units) __attribute__((always_inline)) {
+    if (sweeps_out && tid == 0) {
+      atomicMax(sweeps_out, chain_loops);  // longest chain of iterations of this launch
+      atomicAdd(sweeps_out + 1, units);    // (instance, iteration) units processed by this launch
+      const int chain = A.chain_size ? (b_real / A.chain_size < kMaxSweepChains - 1 ? b_real / A.chain_size : kMaxSweepChains - 1) : 0;
+      atomicMax(sweeps_out + 2, A.chain_base[chain] + chain_loops);  // ... counted from the first sweep of the solve
+      if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word
+    }
+  };
+  if (is_twin) {
+    if (tid == 0) {
+      double go = 0.0;
+      unsigned long long cnt = 0, rb = 0, db = 0;
+      for (int tries = 0; tries < kTwinIdlePolls; ++tries) {
+        if (tw_load(box + kTwHand) != 0) break;  // the primary has finished: nothing to share
+        const unsigned long long ver = tw_load(box + kTwSeq);
+        if (ver != 0) {
+          const unsigned long long* buf = box + kTwSnap + 4 * (ver & 1);
+          cnt = tw_load(buf);
+          rb = tw_load(buf + 1);
+          db = tw_load(buf + 2);
+          const unsigned long long ver2 = tw_load(box + kTwSeq);
+          if (ver2 == ver || ver2 == ver + 1) {  // (buffer ver & 1 is only rewritten by version ver + 2)
+            go = 1.0;
+            break;
+          }
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(32);
+      }
+      if (go != 0.0) {
+        const int it_in = (int)(cnt >> 32), it_tot = (int)(cnt & 0xffffffffull);
+        // iterations until a cap ends the streak at the latest (ilqr.hpp:600-611)
+        const int r1 = o.max_iterations_inner - it_in, r2 = o.max_iterations_total - it_tot;
+        const int R = r1 < r2 ? r1 : r2;
+        if (R < kTwinMinRemaining) {
+          go = 0.0;
+        } else {
+          const int ahead = (R + kTwinLag) / 2 + 1;  // iterations the primary keeps, counted from the snapshot
+          // the regularisation entering iteration `start`: every iteration in between runs its backward pass
+          // (DecreaseRegularization, ilqr.hpp:440) and rejects its line search (IncreaseRegularization, :550)
+          double rho = tw_dbl(rb), drho = tw_dbl(db);
+          for (int j = 0; j < ahead; ++j) {
+            decrease_reg(o, &rho, &drho);
+            increase_reg(o, &rho, &drho);
+          }
+          tw_store(box + kTwClaimRho, tw_bits(rho));
+          tw_store(box + kTwClaimDrho, tw_bits(drho));
+          tw_store(box + kTwClaimSnap, (unsigned long long)(unsigned)it_tot);
+          tw_order();
+          tw_store(box + kTwClaim, ((unsigned long long)(unsigned)(it_in + ahead) << 32) | (unsigned long long)(unsigned)(it_tot + ahead));
+          ff[8] = (double)(it_in + ahead);
+          ff[9] = (double)(it_tot + ahead);
+          ff[10] = rho;
+          ff[11] = drho;
+          // (what the primary's workgroup stored before it published -- the trajectory of its last accepted step, the
+          //  multipliers -- may sit in another XCD's L2: its release is matched by this acquire)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
+      ff[12] = go;
+    }
+    __syncthreads();
+    if (ff[12] == 0.0) return;
+    // ---- clone the instance into the shadow column ----
+    const int bT = tw.col0 + slot;
+    {
+      using R_ = Rec<T, M::n, M::m>;
+      for (int i = tid; i < (N + 1) * R_::nP; i += kThreads) {
+        const int k = i / R_::nP, e = i - k * R_::nP;
+        A.X[((size_t)(unsigned)k * Bp + (unsigned)bT) * R_::nP + e] = A.X[((size_t)(unsigned)k * Bp + (unsigned)b_real) * R_::nP + e];
+      }
+      for (int i = tid; i < N * R_::mP; i += kThreads) {
+        const int k = i / R_::mP, e = i - k * R_::mP;
+        A.U[((size_t)(unsigned)k * Bp + (unsigned)bT) * R_::mP + e] = A.U[((size_t)(unsigned)k * Bp + (unsigned)b_real) * R_::mP + e];
+      }
+      if (tid < R_::nP) A.x0[(size_t)bT * R_::nP + tid] = A.x0[(size_t)b_real * R_::nP + tid];
+      auto column = [&](T* arr, int rows) __attribute__((always_inline)) {
+        for (int r = tid; r < rows; r += kThreads) arr[(unsigned)r * Bp + (unsigned)bT] = arr[(unsigned)r * Bp + (unsigned)b_real];
+      };
+      column(A.costs, N + 1);
+      column(A.lam, pd->total_rows);
+      column(A.pen, pd->total_rows);
+      column(A.cval, pd->total_rows);
+      column(const_cast<T*>(A.ipool), pd->nslots);
+      if (tid == 0) {
+        // per-instance solver state: as the primary left it ...
+        const double c0 = A.dV0[b_real], c1 = A.dV1[b_real], c2 = A.J0[b_real], c3 = A.initial_cost[b_real], c4 = A.cost_cur[b_real],
+                     c5 = A.dJ[b_real], c6 = A.grad[b_real], c7 = A.viol[b_real], c8 = A.penmax[b_real], c9 = A.alpha[b_real],
+                     c10 = A.z[b_real], c11 = A.reg_log[b_real];
+        const int i0 = A.status[b_real], i1 = A.status_al[b_real], i2 = A.it_outer[b_real], i3 = A.phase[b_real],
+                  i4 = A.need_init_cost[b_real];
+        A.dV0[bT] = c0; A.dV1[bT] = c1; A.J0[bT] = c2; A.initial_cost[bT] = c3; A.cost_cur[bT] = c4;
+        A.dJ[bT] = c5; A.grad[bT] = c6; A.viol[bT] = c7; A.penmax[bT] = c8; A.alpha[bT] = c9; A.z[bT] = c10; A.reg_log[bT] = c11;
+        A.status[bT] = i0; A.status_al[bT] = i1; A.it_outer[bT] = i2; A.phase[bT] = i3; A.need_init_cost[bT] = i4;
+        // ... but for what the rejected iterations up to `start` will have changed: counters, regularisation, and the
+        // previous cost, which every iteration of a streak sets to the (unchanged) current one (solver_stats.cpp:54-66)
+        A.cost_prev[bT] = c4;
+        A.it_inner[bT] = (int)ff[8];
+        A.it_total[bT] = (int)ff[9];
+        A.rho_reg[bT] = ff[10];
+        A.drho[bT] = ff[11];
+      }
+    }
+    b = bT;
+    __syncthreads();
+    if (tid == 0) ff[12] = tw_load(box + kTwHand) == 0 ? 1.0 : 0.0;  // (refused already -- the primary broke its streak or finished)
+    __syncthreads();
+    if (ff[12] == 0.0) return;
+  }
   if (wave == 2 && lane == 0) {  // LDS mirrors of initial_cost / need_init_cost (read by this same lane: forward2_body)
     ff[4] = A.initial_cost[b];
     ff[5] = A.need_init_cost[b] ? 1.0 : 0.0;
@@ -3544,7 +3742,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     // ---- S: X, U, lambda, rho, parameters -> LDS (all threads).  Only once: phases 2 and 3 of the
     //      forward pass keep the LDS copies current from then on ----
     if (loops == 0) {
-      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kThreads, kKdNone);
+      forward2_stage<T, M>(A, pd, L, smem_raw, sPool, 1, 0, tid, kThreads, kKdNone, true, -1, b);
       __syncthreads();
     }
     // (the two per-instance scalars the running-cost wave needs after E: requested now, their memory latency -- two
@@ -3599,7 +3797,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
       if (wave == 0) ALTRO_STAMP_ADD(16, st_cp);
     } else if (wave == 0) {
       // ---- B ----
-      backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh);
+      backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh, 0.0, 0.0, nullptr, b);
       // (its own LDS writes of fh[4], fh[5]: program order)
       if (SPEC == kSpecHelper && lane == 0 && armed) request();
     }
@@ -3613,7 +3811,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     forward2_body<T, M, true, kSrcLds, CIRC, kSoft>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
                                                     kWave4 ? &spec : nullptr, alpha_tab,
                                                     FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh,
-                                                    sync_words + kSyEAhead0, persistent ? (kWave4 ? 3 : 2) : 0, loops + 1);
+                                                    sync_words + kSyEAhead0, persistent ? (kWave4 ? 3 : 2) : 0, loops + 1, b);
     ++loops;
     if (wave == 0 && st_adopted) ALTRO_STAMP_ADD(11, st_f);
     const long long st_x = ALTRO_STAMP_T0();
@@ -3704,11 +3902,146 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
+    // ---- twin workgroups (TwinCtl).  Primary: publish the state this iteration leaves while a streak is on, answer a
+    //      claim when the iteration it names is reached.  Twin: a look at the verdict now and then. ----
+    if (box) {
+      if (!is_twin) {
+        const bool rc = ff[0] != 0.0 && ff[3] == 0.0;  // every trial rejected, and the inner solve goes on
+        tw_streak = rc ? tw_streak + 1 : 0;
+        if (!rc) tw_break_total = (int)ff[7];
+        if (tid == 0) {
+          double act = 0.0;
+          if (!tw_closed && (tw_streak >= 2 || tw_ver != 0)) {
+            const int it_in = (int)ff[6], it_tot = (int)ff[7];  // the counters entering the next iteration
+            if (tw_claim == 0) {
+              if (rc && tw_streak >= 2) {
+                ++tw_ver;
+                unsigned long long* buf = box + kTwSnap + 4 * (tw_ver & 1);
+                tw_store(buf, ((unsigned long long)(unsigned)it_in << 32) | (unsigned long long)(unsigned)it_tot);
+                tw_store(buf + 1, tw_bits(ff[1]));
+                tw_store(buf + 2, tw_bits(ff[2]));
+                tw_store(buf + 3, (unsigned long long)(unsigned)loops);
+                // once per streak: whatever the last accepted step and the first rejected iteration stored (trajectory,
+                // multipliers, cost_prev = cost_cur) leaves this XCD's L2 before a twin is told that it may read it
+                if (tw_streak == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                tw_order();
+                tw_store(box + kTwSeq, tw_ver);
+              }
+              // (a streak that broke: the snapshot on display describes a state that no longer exists -- a late twin would
+              //  claim on it and be refused; hide it until the next streak publishes)
+              if (!rc && tw_ver != 0) tw_store(box + kTwSeq, 0ull);
+              tw_claim = tw_load(box + kTwClaim);
+              if (tw_claim != 0) {  // (its other words were stored before it; from now on nothing is published or polled)
+                tw_claim_rho = tw_load(box + kTwClaimRho);
+                tw_claim_drho = tw_load(box + kTwClaimDrho);
+                tw_claim_snap = (int)tw_load(box + kTwClaimSnap);
+              }
+            }
+            if (tw_claim != 0) {
+              const int s_in = (int)(tw_claim >> 32), s_tot = (int)(tw_claim & 0xffffffffull);
+              bool refuse = !rc || it_in > s_in;
+              if (!refuse && it_in == s_in) {
+                // the twin's assumptions about the state entering this iteration, bit for bit -- and no iteration since
+                // its snapshot that was anything but a rejected one
+                const bool same = it_tot == s_tot && tw_bits(ff[1]) == tw_claim_rho && tw_bits(ff[2]) == tw_claim_drho &&
+                                  tw_break_total < tw_claim_snap;
+                if (same) act = 2.0; else refuse = true;
+              }
+              if (refuse) {
+                tw_cas(box + kTwHand, 0ull, kTwRefused);
+                tw_closed = true;
+              }
+            }
+          }
+          ff[13] = act;
+        }
+      } else if (tid == 0) {
+        ff[13] = ((loops & 7) == 0 && tw_load(box + kTwHand) >= kTwRefused) ? 1.0 : 0.0;
+      }
+    }
     // (waves of a workgroup share the CU's vector L1, which stores write through and keep coherent,
     // so what this iteration wrote -- trajectory, multipliers, records -- is what the next one reads)
     // everyone has read the flag before phase 3 of the next iteration rewrites it; without a speculated backward pass
     // the next iteration reads this one's scalars from global memory: drain the stores
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
+    if (box) {
+      const double act = ff[13];
+      if (act == 1.0) return;  // twin: the primary refused (or finished) -- nothing of the clone is visible outside its column
+      if (act == 2.0) {
+        // HAND-OVER.  Everything this workgroup has stored leaves its L2 before the twin -- which will copy its column
+        // over the instance's -- is told so: the two workgroups may sit on different XCDs, whose L2s write back on their own.
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          tw_store(box + kTwHandLoops, (unsigned long long)(unsigned)loops);
+          tw_order();
+          ff[13] = tw_cas(box + kTwHand, 0ull, kTwOk) ? 3.0 : 0.0;  // (lost against a twin that gave up: go on alone)
+          tw_closed = true;
+        }
+        __syncthreads();
+        if (ff[13] == 3.0) {
+          report(loops + skipped, loops);
+          return;  // the twin owns the instance: its copy-back is the instance's state
+        }
+      }
+    }
+  }
+  // ---- a twin commits: the primary's verdict, then the shadow column over the instance's own ----
+  if (is_twin) {
+    if (tid == 0) {
+      unsigned long long h = 0;
+      for (int tries = 0; tries < kTwinHandPolls && (h = tw_load(box + kTwHand)) == 0; ++tries) __builtin_amdgcn_s_sleep(32);
+      if (h == 0) h = tw_cas(box + kTwHand, 0ull, kTwRevoked) ? kTwRevoked : tw_load(box + kTwHand);
+      if (h == kTwOk) {
+        ff[14] = (double)(unsigned)tw_load(box + kTwHandLoops);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      ff[13] = h == kTwOk ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (ff[13] == 0.0) return;
+    tw_loops0 = (int)ff[14];
+    {
+      using R_ = Rec<T, M::n, M::m>;
+      using RS_ = rec_scalar_t<T, M>;
+      using RR_ = Rec<RS_, M::n, M::m>;
+      const int bT = b;
+      for (int i = tid; i < (N + 1) * R_::nP; i += kThreads) {
+        const int k = i / R_::nP, e = i - k * R_::nP;
+        A.X[((size_t)(unsigned)k * Bp + (unsigned)b_real) * R_::nP + e] = A.X[((size_t)(unsigned)k * Bp + (unsigned)bT) * R_::nP + e];
+      }
+      for (int i = tid; i < N * R_::mP; i += kThreads) {
+        const int k = i / R_::mP, e = i - k * R_::mP;
+        A.U[((size_t)(unsigned)k * Bp + (unsigned)b_real) * R_::mP + e] = A.U[((size_t)(unsigned)k * Bp + (unsigned)bT) * R_::mP + e];
+      }
+      RS_* const E = (RS_*)A.EXP;
+      for (int i = tid; i < (N + 1) * RR_::EP; i += kThreads) {
+        const int k = i / RR_::EP, e = i - k * RR_::EP;
+        E[((size_t)(unsigned)k * Bp + (unsigned)b_real) * RR_::EP + e] = E[((size_t)(unsigned)k * Bp + (unsigned)bT) * RR_::EP + e];
+      }
+      auto column = [&](T* arr, int rows) __attribute__((always_inline)) {
+        for (int r = tid; r < rows; r += kThreads) arr[(unsigned)r * Bp + (unsigned)b_real] = arr[(unsigned)r * Bp + (unsigned)bT];
+      };
+      column(A.costs, N + 1);
+      column(A.lam, pd->total_rows);
+      column(A.pen, pd->total_rows);
+      column(A.cval, pd->total_rows);
+      if (tid == 0) {
+        const double c0 = A.rho_reg[bT], c1 = A.drho[bT], c2 = A.dV0[bT], c3 = A.dV1[bT], c4 = A.J0[bT], c5 = A.initial_cost[bT],
+                     c6 = A.cost_cur[bT], c7 = A.cost_prev[bT], c8 = A.dJ[bT], c9 = A.grad[bT], c10 = A.viol[bT], c11 = A.penmax[bT],
+                     c12 = A.alpha[bT], c13 = A.z[bT], c14 = A.reg_log[bT];
+        const int i0 = A.status[bT], i1 = A.status_al[bT], i2 = A.it_inner[bT], i3 = A.it_outer[bT], i4 = A.it_total[bT],
+                  i5 = A.phase[bT], i6 = A.need_init_cost[bT];
+        A.rho_reg[b_real] = c0; A.drho[b_real] = c1; A.dV0[b_real] = c2; A.dV1[b_real] = c3; A.J0[b_real] = c4;
+        A.initial_cost[b_real] = c5; A.cost_cur[b_real] = c6; A.cost_prev[b_real] = c7; A.dJ[b_real] = c8; A.grad[b_real] = c9;
+        A.viol[b_real] = c10; A.penmax[b_real] = c11; A.alpha[b_real] = c12; A.z[b_real] = c13; A.reg_log[b_real] = c14;
+        A.status[b_real] = i0; A.status_al[b_real] = i1; A.it_inner[b_real] = i2; A.it_outer[b_real] = i3; A.it_total[b_real] = i4;
+        A.phase[b_real] = i5; A.need_init_cost[b_real] = i6;
+      }
+    }
+    b = b_real;  // (the gains below go to the instance's own records)
+  } else if (box && tid == 0 && !tw_closed) {
+    tw_cas(box + kTwHand, 0ull, kTwRefused);  // the instance is finished: a twin still waiting for a streak may leave
   }
 #ifdef ALTRO_STAMPS
   __syncthreads();
@@ -3734,13 +4067,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     if (e < (Rec<RS, M::n, M::m>::KP)) RECP((RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[e] = (RS)sKDf[i];
   }
   if (SPEC == kSpecHelper && tid == 0) __hip_atomic_store(rs.go + b, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (sweeps_out && tid == 0) {
-    atomicMax(sweeps_out, loops + skipped);  // longest chain of iterations of this launch
-    atomicAdd(sweeps_out + 1, loops);          // (instance, iteration) units processed by this launch
-    const int chain = A.chain_size ? (b / A.chain_size < kMaxSweepChains - 1 ? b / A.chain_size : kMaxSweepChains - 1) : 0;
-    atomicMax(sweeps_out + 2, A.chain_base[chain] + loops + skipped);  // ... counted from the first sweep of the solve
-    if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word
-  }
+  report(tw_loops0 + loops + skipped, loops);
 }
 
 // The speculative backward passes of k_sweep_fused<.., kSpecHelper>: one wavefront per straggler, on whatever CU has

@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_header(A):
     assert [f for f, _ in A.Timing._fields_] == ["total_ms", "init_ms", "expansions_ms", "backward_pass_ms", "forward_pass_ms",
                                                 "fused_ms", "sweeps", "fused_sweeps", "launches", "sweep_launches",
                                                 "instance_iterations",
-                                                "fused_instance_iterations", "host_naps", "reserved"]
+                                                "fused_instance_iterations", "host_naps", "twin_workgroups"]
 
 
 def test_default_options_are_the_reference_defaults(A):

@@ -177,3 +177,69 @@ def test_candidate_layouts_are_bit_identical(tmp_path):
         got = run(tag, env)
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (tag, k)
+
+
+_SCRIPT_TWIN = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+cases = (("turn90_512", lambda: P.batch_turn90(make, batch=512, seed=P.SEED_BASE + 3)),        # persistent kernel from the first sweep, ~12 stragglers
+         ("turn90_2304", lambda: P.batch_turn90(make, batch=2304, seed=P.SEED_BASE + 3)),      # chains of sweeps, hand-over, ~55 stragglers
+         ("obstacles_192", lambda: P.batch_three_obstacles(make, batch=192, dtype=A.F64)),   # lock-step speculation (circle constraints)
+         ("obstacles_r32", lambda: P.batch_three_obstacles(make, batch=192, dtype=A.F32)))   # fp32 records
+for name, fac in cases:
+    s = fac()
+    for rep in range(2):   # (the second solve reuses mailboxes and shadow columns)
+        s.reset_trajectory()
+        s.solve()
+    X, U = s.get_trajectory()
+    st = s.get_stats()
+    tm = s.get_timing()
+    out[name + "_X"] = X; out[name + "_U"] = U
+    K, d = s.get_gains()
+    out[name + "_K"] = K; out[name + "_d"] = d
+    out[name + "_lam"] = s.get_duals(); out[name + "_pen"] = s.get_penalties(); out[name + "_c"] = s.get_constraint_values()
+    for f in st.dtype.names:
+        out[name + "_st_" + f] = st[f]
+    for k in (0, 50, 100):
+        e = s.get_expansion(k)
+        for key, v in e.items():
+            out[name + "_exp%%d_%%s" %% (k, key)] = v
+    out[name + "_costs"] = s.get_knot_costs()
+    out[name + "_twins"] = np.array([tm["twin_workgroups"]]); out[name + "_ms"] = np.array([tm["total_ms"]])
+    out[name + "_iters"] = np.array([tm["instance_iterations"], tm["fused_instance_iterations"], tm["sweeps"]])
+    s.close()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_twin_workgroups_are_bit_identical(tmp_path):
+    """Twin workgroups of the persistent kernel (TwinCtl, altro_kernels.hpp): the second half of a straggler's rejection
+    streak is computed by a second workgroup on a shadow column, beside the first half, and copied back after the
+    primary has confirmed the state the twin assumed.  Every iteration is still executed with the inputs the sequential
+    order gives it, so NOTHING may differ from a launch without twins (ALTRO_HIP_TWIN=0): trajectories, gains,
+    multipliers, penalties, stored constraint values, expansion records, knot costs, every statistic -- on the batch that
+    starts in the persistent kernel, behind the chains of sweeps, with circle constraints (lock-step speculation) and
+    with fp32 records."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env_extra in (("twin", {}), ("solo", {"ALTRO_HIP_TWIN": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_TWIN % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
+        res[tag] = np.load(out)
+    a, b = res["twin"], res["solo"]
+    for name in ("turn90_512", "turn90_2304", "obstacles_192", "obstacles_r32"):
+        assert a[name + "_twins"][0] > 0 and b[name + "_twins"][0] == 0, name
+        print(name, "ms with / without twins", a[name + "_ms"][0], b[name + "_ms"][0], "iterations", a[name + "_iters"], b[name + "_iters"])
+    for k in a.files:
+        if k.endswith(("_twins", "_ms", "_iters")):
+            continue
+        assert np.array_equal(a[k], b[k]), (k, np.abs(np.asarray(a[k], float) - np.asarray(b[k], float)).max())
+    # the twins really took their share: a batch with stragglers finishes sooner, and every iteration was executed
+    assert a["turn90_2304_ms"][0] < 0.8 * b["turn90_2304_ms"][0], (a["turn90_2304_ms"], b["turn90_2304_ms"])
+    assert a["turn90_2304_iters"][0] == b["turn90_2304_iters"][0]       # sum of iterations_total
+    assert a["turn90_2304_iters"][1] >= b["turn90_2304_iters"][1]       # units executed by the persistent launch (refused twins add theirs)

@@ -102,7 +102,7 @@ def test_step_level_calls_with_per_knot_steps(A, P, oracle_make, hip_make):
         assert np.abs(eg["B"]).max() > 0
     Ko, do = o.get_gains()
     Kg, dg = g.get_gains()
-    assert np.allclose(Kg, Ko, rtol=1e-7, atol=1e-9) and np.allclose(dg, do, rtol=1e-7, atol=1e-9)
+    assert np.allclose(Kg, Ko, rtol=1e-9, atol=1e-11) and np.allclose(dg, do, rtol=1e-9, atol=1e-11)  # (measured 1.1e-14)
     assert np.array_equal(o.get_stats()["alpha"], g.get_stats()["alpha"])
     assert np.allclose(g.get_trajectory()[0], o.get_trajectory()[0], rtol=1e-9, atol=1e-11)
 

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _same(o, g, traj_tol=1e-7, only_solved=False):
+def _same(o, g, traj_tol=1e-9, only_solved=False):  # (bars pinned to profiles/r05_parity_errors.json: measured X 2.3e-12, U 8.2e-11 abs)
     so, sg = o.get_stats(), g.get_stats()
     for f in ("status", "status_ilqr", "iterations_total", "iterations_outer", "iterations_inner"):
         assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
@@ -91,7 +91,7 @@ def test_cholesky_restart_path(P, A, oracle_make, hip_make):
     assert np.allclose(sg["regularization"], so["regularization"], rtol=1e-12)
     Xo, _ = o.get_trajectory()
     Xg, _ = g.get_trajectory()
-    assert np.allclose(Xg, Xo, rtol=1e-6, atol=1e-8)
+    assert np.allclose(Xg, Xo, rtol=1e-9, atol=1e-11)  # (measured 1e-15)
 
 
 def test_state_limit_and_rejected_line_search(P, oracle_make, hip_make):
@@ -102,7 +102,7 @@ def test_state_limit_and_rejected_line_search(P, oracle_make, hip_make):
     for s in (o, g):
         s.set_options(state_max=2.5, control_max=50.0, max_iterations_inner=8, max_iterations_outer=2)
         s.solve()
-    so = _same(o, g, traj_tol=1e-7)
+    so = _same(o, g, traj_tol=1e-9)
     assert set(np.unique(so["status"])) <= {0, 2, 3, 5, 6, 7}
     o2 = P.batch_turn90(oracle_make, batch=4)
     g2 = P.batch_turn90(hip_make, batch=4)
@@ -164,8 +164,8 @@ def test_randomised_problems_and_options(P, A, oracle_make, hip_make, seed):
     ok = so["status"] == 0
     Xo, Uo = o.get_trajectory()
     Xg, Ug = g.get_trajectory()
-    assert np.allclose(Xg[ok], Xo[ok], rtol=1e-6, atol=1e-7)
-    assert np.allclose(Ug[ok], Uo[ok], rtol=1e-6, atol=1e-7)
+    assert np.allclose(Xg[ok], Xo[ok], rtol=1e-9, atol=1e-11)  # (measured: X 5e-14, U 4.3e-13 abs)
+    assert np.allclose(Ug[ok], Uo[ok], rtol=1e-9, atol=1e-11)
 
 
 def test_async_solve_matches_blocking(P, A, hip_make):

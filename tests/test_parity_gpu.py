@@ -114,8 +114,9 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
         close(sg["improvement_ratio"], so["improvement_ratio"], 1e-7, 0.0, label=f"z (sweep {it})")
         Xo, Uo = o.get_trajectory()
         Xg, Ug = g.get_trajectory()
-        close(Xg, Xo, 1e-9, 1e-11, label=f"X after the line search (sweep {it})")
-        close(Ug, Uo, 1e-9, 1e-11, label=f"U after the line search (sweep {it})")
+        # (measured in sweep 0: X 1.2e-11, U 3.3e-11 abs -- entries of 1e-4 next to entries of 1)
+        close(Xg, Xo, 1e-9, 2e-10, label=f"X after the line search (sweep {it})")
+        close(Ug, Uo, 1e-9, 2e-10, label=f"U after the line search (sweep {it})")
 
 
 def test_reference_constants_on_gpu(P, hip_make):
@@ -204,7 +205,18 @@ def test_history_matches_oracle(P, oracle_make, hip_make):
     assert g.get_history(0, "alpha")[0] == 0.0625  # K11
 
 
-def _compare_full(o, g, solved_only_tight=True, xtol=(RT, AT), gtol=1e-6):
+# Bars of the full-solve comparisons, pinned to what is MEASURED (profiles/r05_parity_errors.json; GPU and oracle are both
+# deterministic, so the measured maxima reproduce to the bit) and to SURVEY 8(c) (fp64: rel 1e-9, abs 1e-12 scale):
+#   X      measured abs <= 3.9e-12 over every config           bar rel 1e-9 + abs 2e-11
+#   U      measured abs <= 6.3e-11 (|u| = 100: rel 8e-13)       bar rel 1e-9 + abs 5e-10
+#   K      measured norm-wise rel <= 3.4e-10                    bar norm-wise 5e-9
+#   d      measured abs <= 1.0e-10 (d -> 0 at convergence)      bar rel 1e-9 + abs 1e-9
+#   duals  lambda - rho c: an error of 1e-12 in c shows up as rho 1e-12; measured 8.8e-8 abs at max penalty 1e5
+#                                                               bar rel 1e-9 + abs 1e-11 x the instance's max penalty
+XTOL, UTOL, KTOL, DTOL = (1e-9, 2e-11), (1e-9, 5e-10), 5e-9, (1e-9, 1e-9)
+
+
+def _compare_full(o, g, solved_only_tight=True, xtol=XTOL, utol=UTOL, gtol=KTOL):
     so, sg = o.get_stats(), g.get_stats()
     assert (so["status"] == sg["status"]).all(), (so["status"], sg["status"])
     assert (so["iterations_total"] == sg["iterations_total"]).all(), np.flatnonzero(so["iterations_total"] != sg["iterations_total"])
@@ -214,17 +226,21 @@ def _compare_full(o, g, solved_only_tight=True, xtol=(RT, AT), gtol=1e-6):
     Xo, Uo = o.get_trajectory()
     Xg, Ug = g.get_trajectory()
     close(Xg[ok], Xo[ok], *xtol, label="X")
-    close(Ug[ok], Uo[ok], *xtol, label="U")
+    close(Ug[ok], Uo[ok], *utol, label="U")
     Ko, do = o.get_gains()
     Kg, dg = g.get_gains()
     close_normwise(Kg[ok], Ko[ok], gtol, label="K normwise")
-    close(dg[ok], do[ok], max(gtol, 1e-5), max(1e-7, 0.1 * gtol), label="d")  # d -> 0 at convergence: absolute floor
+    close(dg[ok], do[ok], *DTOL, label="d")  # d -> 0 at convergence: absolute floor
     if o.num_constraints() > 0:
-        # a dual is lambda - rho*c with rho up to 1e4..1e8: 1e-12 in c shows up as rho*1e-12
-        close(g.get_duals()[ok], o.get_duals()[ok], 1e-5, 1e-7, label="duals")
+        # a dual is lambda - rho*c with rho up to 1e4..1e8: 1e-12 in c shows up as rho*1e-12 -> the bar scales with the penalty
+        lo, lg = o.get_duals()[ok], g.get_duals()[ok]
+        pen = np.maximum(so["max_penalty"][ok], 1.0)[:, None]
+        close(lg / pen, lo / pen, 1e-9, 1e-10, label="duals / max penalty")  # (measured 8.8e-8 abs at max penalty >= 1e4)
         close(g.get_penalties(), o.get_penalties(), 0, 0, label="penalties")
-    for f in ("cost", "violation", "max_penalty", "alpha", "regularization"):
-        close(sg[f][ok], so[f][ok], 1e-7, 1e-10, label="stat " + f)
+    for f in ("max_penalty", "alpha", "regularization"):
+        close(sg[f][ok], so[f][ok], 0, 0, label="stat " + f)  # exact
+    close(sg["cost"][ok], so["cost"][ok], 1e-10, 0.0, label="stat cost")            # measured rel 5.9e-12
+    close(sg["violation"][ok], so["violation"][ok], 1e-7, 1e-12, label="stat violation")  # measured abs 1.8e-14 (rel 5e-9 of 3e-6)
     return so, sg
 
 
@@ -384,9 +400,9 @@ def test_config3_full_batch_against_oracle(P, A, oracle_make, hip_make, oracle_l
     assert (~same).sum() <= 2, (~same).sum()
     Xo, Uo = o.get_trajectory()
     Xg, Ug = g.get_trajectory()
-    close(Xg[solved], Xo[solved], 1e-7, 1e-9, label="X solved instances")
-    close(Ug[solved], Uo[solved], 1e-6, 1e-8, label="U solved instances")
-    close(Xg[~solved & same], Xo[~solved & same], 1e-6, 1e-8, label="X stragglers (same schedule)")
+    close(Xg[solved], Xo[solved], *XTOL, label="X solved instances")          # measured 1.7e-12
+    close(Ug[solved], Uo[solved], *UTOL, label="U solved instances")          # measured 2.5e-12
+    close(Xg[~solved & same], Xo[~solved & same], *XTOL, label="X stragglers (same schedule)")  # measured 2.6e-13
     close(sg["cost"][solved], so["cost"][solved], 1e-10, 0.0, label="cost solved instances")
 
 
@@ -409,12 +425,12 @@ def test_horizon_lengths_and_ragged_batches(P, A, oracle_make, hip_make, no_fuse
             assert (so["status"] == sg["status"]).all() and (so["iterations_outer"] == sg["iterations_outer"]).all()
             assert (np.abs(so["iterations_total"] - sg["iterations_total"]) <= 2).all()
         else:
-            _compare_full(o, g, xtol=(1e-6, 1e-8), gtol=1e-5)
+            _compare_full(o, g)  # (round 5: the default bars -- measured X 3.2e-13, U 5e-13, K 3.4e-10 on these horizons)
         assert g.get_timing()["fused_sweeps"] == 0 if no_fused else g.get_timing()["fused_sweeps"] > 0
     for N, batch in ((5, 5), (51, 5), (50, 1)):
         o, g = both(P, P.batch_three_obstacles, oracle_make, hip_make, batch=batch, N=N, dtype=A.F64)
         o.solve(); g.solve()
-        _compare_full(o, g, xtol=(1e-6, 1e-8), gtol=1e-5)
+        _compare_full(o, g)
 
 
 def test_setters_are_ordered_against_the_solver_stream(P, A, hip_make):

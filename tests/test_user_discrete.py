@@ -150,7 +150,7 @@ def test_knot_model_indices_are_validated(A):
 
 
 # ---- GPU: the HIP path against the oracle ------------------------------------------------------------------------------
-def _parity(o, g, xtol=1e-7, min_solved=0.9):
+def _parity(o, g, xtol=1e-10, min_solved=0.9):  # (measured X 7e-13, U 7e-12 abs over all three models and both engines)
     so, sg = o.get_stats(), g.get_stats()
     for f in ("status", "iterations_total", "iterations_outer"):
         assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
@@ -195,7 +195,7 @@ def test_model_per_knot_matches_the_oracle(A, P, hip_make, steps_oracle, dtype_n
         g = P.cartpole_steps(hip_make, kind, km, batch=B, goal=goals, dtype=getattr(A, dtype_name))
         o = P.cartpole_steps(steps_oracle, kind, km, batch=B, goal=goals, dtype=A.F64 if dtype_name == "F64" else 2)
         g.solve(); o.solve()
-        so = _parity(o, g, 1e-7 if dtype_name == "F64" else 1e-5)
+        so = _parity(o, g)
         print("model per knot", dtype_name, km[:6], "...", "iterations", np.unique(so["iterations_total"]))
         g.close()
     # step level: every knot's [A | B] is its own model's

@@ -80,7 +80,7 @@ def test_cartpole_solves_and_matches_the_oracle(A, P, hip_make, cartpole_oracle,
     assert (so["status"] == 0).mean() > 0.9
     ok = so["status"] == 0
     (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
-    tol = 1e-7 if dtype_name == "F64" else 1e-5
+    tol = 1e-10  # (both engines against their own oracle -- fp64 / record-rounding: measured X 5e-14, U 5e-13, duals 1e-11 abs)
     assert np.allclose(Xg[ok], Xo[ok], rtol=tol, atol=tol), np.abs(Xg[ok] - Xo[ok]).max()
     assert np.allclose(Ug[ok], Uo[ok], rtol=10 * tol, atol=10 * tol), np.abs(Ug[ok] - Uo[ok]).max()
     assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-7)
@@ -178,11 +178,11 @@ def test_user_cost_and_constraint_match_the_oracle(A, P, hip_make, track_oracle,
     assert (so["status"] == 0).mean() > 0.9
     ok = so["status"] == 0
     (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
-    tol = 1e-7 if dtype_name == "F64" else 1e-5
+    tol = 1e-10  # (both engines against their own oracle -- fp64 / record-rounding: measured X 5e-14, U 5e-13, duals 1e-11 abs)
     assert np.allclose(Xg[ok], Xo[ok], rtol=tol, atol=tol), np.abs(Xg[ok] - Xo[ok]).max()
     assert np.allclose(Ug[ok], Uo[ok], rtol=10 * tol, atol=10 * tol), np.abs(Ug[ok] - Uo[ok]).max()
     assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-7)
-    assert np.allclose(g.get_duals()[ok], o.get_duals()[ok], rtol=1e3 * tol, atol=1e3 * tol)
+    assert np.allclose(g.get_duals()[ok], o.get_duals()[ok], rtol=1e2 * tol, atol=1e2 * tol)
     # the sway limit holds (to the constraint tolerance) and is active for the long moves
     sway = np.abs(0.5 * np.sin(Xg[:, :, 1])).max(axis=1)
     assert (sway[ok] < 0.04 + 1e-3).all() and (sway[ok][-5:] > 0.04 - 1e-3).all(), sway

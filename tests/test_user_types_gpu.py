@@ -128,10 +128,10 @@ def test_mixed_types_match_the_oracle(A, P, hip_make, multi_oracle, dtype_name):
         assert (so[f] == sg[f]).all(), (f, so[f], sg[f])
     assert (so["status"] == 0).all()
     (Xo, Uo), (Xg, Ug) = o.get_trajectory(), g.get_trajectory()
-    tol = 1e-7 if dtype_name == "F64" else 1e-5
+    tol = 1e-10  # (both engines against their own oracle -- fp64 / record-rounding: measured X 5e-14, U 5e-13, duals 1e-11 abs)
     assert np.allclose(Xg, Xo, rtol=tol, atol=tol), np.abs(Xg - Xo).max()
     assert np.allclose(Ug, Uo, rtol=10 * tol, atol=10 * tol), np.abs(Ug - Uo).max()
     assert np.allclose(sg["cost"], so["cost"], rtol=1e-7)
-    assert np.allclose(g.get_duals(), o.get_duals(), rtol=1e3 * tol, atol=1e3 * tol)
+    assert np.allclose(g.get_duals(), o.get_duals(), rtol=1e2 * tol, atol=1e2 * tol)
     speed = np.abs(Xg[:, :, 2]).max(axis=1)
     assert (np.abs(speed[-4:] - 0.6) < 1e-3).all(), speed
