@@ -75,7 +75,8 @@ class Timing(C.Structure):
                 ("backward_pass_ms", C.c_double), ("forward_pass_ms", C.c_double), ("fused_ms", C.c_double),
                 ("sweeps", C.c_int), ("fused_sweeps", C.c_int), ("launches", C.c_int), ("sweep_launches", C.c_int),
                 ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong),
-                ("host_naps", C.c_int), ("twin_workgroups", C.c_int)]
+                ("host_naps", C.c_int), ("twin_workgroups", C.c_int),
+                ("twin_claims", C.c_int), ("twin_handovers", C.c_int)]
 
 
 class AltroError(RuntimeError):

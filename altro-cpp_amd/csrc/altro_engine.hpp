@@ -1174,7 +1174,7 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.pen, (size_t)rows * bp);
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
     ALTRO_ALLOC(d_tmp_, bp);
-    if (twin_cap_ > 0) ALTRO_ALLOC(d_twin_box_, (size_t)twin_cap_ * kTwWords);
+    if (twin_cap_ > 0) ALTRO_ALLOC(d_twin_box_, (size_t)twin_cap_ * (kTwWords + 1));  // mailboxes, then the state words
     ALTRO_ALLOC(d_list_[0], bp);
     ALTRO_ALLOC(d_list_[1], bp);
     {
@@ -1736,8 +1736,8 @@ class Engine final : public EngineBase {
         // indices); not with a recorded history (its rows are appended in iteration order) nor in helper mode
         TwinCtl tw{};
         if (twin_cap_ > 0 && !A.hist && spec_mode_ != kSpecHelper && !d.fast_forward_stalls) {
-          hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * kTwWords * sizeof(unsigned long long), stream_);
-          tw = TwinCtl{d_twin_box_, ninst, twin_cap_, Bp_ - twin_cap_};
+          hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * (kTwWords + 1) * sizeof(unsigned long long), stream_);
+          tw = TwinCtl{d_twin_box_, d_twin_box_ + (size_t)twin_cap_ * kTwWords, ninst, twin_cap_, Bp_ - twin_cap_, twin_lag_, std::getenv("ALTRO_HIP_TWIN_DEBUG") ? 1 : 0};
         }
         const dim3 g(ninst + (tw.base > 0 ? std::min(ninst, twin_cap_) : 0)), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
         timing_.twin_workgroups = tw.base > 0 ? (int)g.x - ninst : 0;  // twin workgroups of this launch
@@ -1787,8 +1787,53 @@ class Engine final : public EngineBase {
     int sweeps = 0;  // longest chain of iterations, the look-ahead sweep of a chain that ran dry included
     for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
-      int extra[4] = {0, 0, 0, 0};
+      int extra[6] = {0, 0, 0, 0, 0, 0};
       ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      timing_.twin_handovers = extra[4];
+      timing_.twin_claims = extra[5];
+      if (twin_cap_ > 0 && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {  // the mailboxes after the launch, slot by slot
+        std::vector<unsigned long long> box((size_t)twin_cap_ * kTwWords);
+        ALTRO_HIP_CHECK(CopySync(box.data(), d_twin_box_, box.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        int hist[4] = {0, 0, 0, 0}, why[8] = {0};
+        unsigned long long t0 = ~0ull;
+        for (int s = 0; s < twin_cap_; ++s)
+          if (box[(size_t)s * kTwWords + kTwStamp + kTsPStart]) t0 = std::min(t0, box[(size_t)s * kTwWords + kTwStamp + kTsPStart]);
+        int shown = 0;
+        for (int s = 0; s < twin_cap_; ++s) {
+          const unsigned long long* w = &box[(size_t)s * kTwWords];
+          hist[w[kTwHand] & 3]++;
+          if ((w[kTwHand] & 3) == kTwOk && (shown++ % 8) == 0) {  // timelines of every eighth hand-over, us from the first workgroup's start
+            const unsigned long long* ts = w + kTwStamp;
+            auto us = [&](int i) { return ts[i] ? (double)(long long)(ts[i] - t0) * 0.01 : -1.0; };
+            fprintf(stderr, "  slot %3d  P: start %.0f snap %.0f (loop %llu) claim %.0f hand %.0f (loops %llu) | T: start %.0f go %.0f cloned %.0f first %.0f done %.0f (loops %llu) "
+                    "verdict %.0f commit %.0f | claim start it %d\n", s, us(kTsPStart), us(kTsPSnap), ts[kTsPLoopsAtSnap], us(kTsPClaim), us(kTsPHand),
+                    w[kTwHandLoops], us(kTsTStart), us(kTsTGo), us(kTsTCloned), us(kTsTFirst), us(kTsTDone), ts[kTsTLoops], us(kTsTVerdict), us(kTsTCommit),
+                    (int)(w[kTwClaim] >> 32));
+          }
+          if (w[kTwClaim] != 0 && (w[kTwHand] & 3) == kTwRefused) {
+            why[w[kTwWhy] & 7]++;
+            if (why[w[kTwWhy] & 7] <= 3)
+              fprintf(stderr, "  twin slot %d refused: why %d at it_inner %d (claim start %d, snapshot total %d), snapshots %llu\n", s, (int)(w[kTwWhy] & 7),
+                      (int)((w[kTwWhy] >> 8) & 0xffff), (int)((w[kTwWhy] >> 24) & 0xffff), (int)w[kTwClaimSnap], w[kTwSeq]);
+          }
+        }
+        {
+          double last_commit = 0, last_pend = 0, last_tstart = 0;
+          int s_commit = -1, s_pend = -1;
+          for (int s = 0; s < twin_cap_; ++s) {
+            const unsigned long long* ts = &box[(size_t)s * kTwWords + kTwStamp];
+            auto us = [&](int i) { return ts[i] ? (double)(long long)(ts[i] - t0) * 0.01 : -1.0; };
+            if (us(kTsTCommit) > last_commit) { last_commit = us(kTsTCommit); s_commit = s; }
+            if (us(kTsPEnd) > last_pend) { last_pend = us(kTsPEnd); s_pend = s; }
+            last_tstart = std::max(last_tstart, us(kTsTStart));
+          }
+          fprintf(stderr, "twin timeline: last commit %.0f us (slot %d), last primary that finished by itself %.0f us (slot %d), last twin start %.0f us\n",
+                  last_commit, s_commit, last_pend, s_pend, last_tstart);
+        }
+        fprintf(stderr, "twin mailboxes: launched %d claims %d handovers %d | hand word: open %d ok %d refused %d revoked %d | refusals of claims: "
+                "streak broke %d, passed %d, counters %d, rho %d, drho %d, break since snapshot %d\n", timing_.twin_workgroups,
+                timing_.twin_claims, timing_.twin_handovers, hist[0], hist[1], hist[2], hist[3], why[1], why[2], why[3], why[4], why[5], why[6]);
+      }
       if (extra[3] != 0) {
         err_ = "k_sweep_fused: a forward wave gave up waiting for its sequence word (software synchronisation)";
         return ALTRO_HIP_ERROR;
@@ -1837,6 +1882,7 @@ class Engine final : public EngineBase {
   DevArrays<T> A_{};
   double* d_tmp_ = nullptr;
   int twin_cap_ = 0;                          // shadow columns behind the batch (twin workgroups of the persistent kernel)
+  int twin_lag_ = std::getenv("ALTRO_HIP_TWIN_LAG") ? atoi(std::getenv("ALTRO_HIP_TWIN_LAG")) : kTwinLag;
   unsigned long long* d_twin_box_ = nullptr;  // their mailboxes, [twin_cap_][kTwWords]
   int* d_list_[2] = {nullptr, nullptr};
   bool mfma_offsets_ok_ = false;

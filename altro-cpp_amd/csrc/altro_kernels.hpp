@@ -3508,10 +3508,15 @@ constexpr int kSpecPolls = 400;  // polls of the result flag before the recursio
 // -------------------------------------------------------------------------------------------------
 struct TwinCtl {
   unsigned long long* box;  // [cap][kTwWords], zeroed by the host before the launch
+  unsigned long long* state;  // [cap] one word per slot for the pool's scan: kTwsSnap | kTwsClosed | kTwsLocked
   int base;                 // first twin block of the launch (0: no twins)
   int cap;                  // slots that own a mailbox and a shadow column
   int col0;                 // first shadow column
+  int lag;                  // iterations the primary is expected to advance while a twin clones and stages (kTwinLag)
+  int debug;                // stamp the mailbox (ALTRO_HIP_TWIN_DEBUG)
 };
+enum TwinStamp { kTsPStart = 0, kTsPSnap = 1, kTsPClaim = 2, kTsPHand = 3, kTsPLoopsAtSnap = 4, kTsTStart = 5, kTsTGo = 6, kTsTCloned = 7,
+                 kTsTFirst = 8, kTsTDone = 9, kTsTVerdict = 10, kTsTCommit = 11, kTsTLoops = 12, kTsPEnd = 13 };
 enum TwinWord {
   kTwSeq = 0,        // version of the newest snapshot (0: none yet)
   kTwSnap = 1,       // two snapshot buffers of 4 words: (it_inner << 32 | it_total), rho, drho, primary's loop count
@@ -3521,12 +3526,23 @@ enum TwinWord {
   kTwClaimSnap = 12, // it_total of the snapshot the claim was derived from
   kTwHand = 13,      // 0 open, kTwOk / kTwRefused (primary), kTwRevoked (twin): set once, by compare-and-swap
   kTwHandLoops = 14, // the primary's loop count at the hand-over
-  kTwWords = 16
+  kTwWhy = 15,       // diagnostics (ALTRO_HIP_TWIN_DEBUG): why a claim was refused / what the twin did last
+  kTwStamp = 16,     // diagnostics: 100 MHz wall-clock stamps of the two workgroups (TwinStamp), written when tw.debug is set
+  kTwWords = 32
 };
 constexpr unsigned long long kTwOk = 1, kTwRefused = 2, kTwRevoked = 3;
+// state word of a slot (contiguous array: a wavefront of the pool looks at 64 slots with one coalesced load):
+//   kTwsSnap    the primary has a snapshot of a running streak on display (cleared when the streak breaks)
+//   kTwsClosed  the primary has finished, refused or handed over: nothing more to come from this slot
+//   kTwsLocked  a twin has taken the slot (compare-and-swap kTwsSnap -> kTwsSnap | kTwsLocked), or has found it not worth it
+constexpr unsigned long long kTwsSnap = 1, kTwsClosed = 2, kTwsLocked = 4;
 constexpr int kTwinMinRemaining = 12;   // iterations left in a streak below which a twin is not worth its start-up
 constexpr int kTwinLag = 3;             // iterations the primary advances while the twin clones and stages
-constexpr int kTwinIdlePolls = 200;     // polls (~3 us each) a twin waits for a streak before it gives its CU back
+// polls (~3 us each) a twin waits for its primary to publish a streak.  The primary closes the mailbox when it finishes, so the
+// wait ends with the primary at the latest; the bound only guards against a primary that never runs.  (Round 5, first version:
+// 200 polls = 0.6 ms.  88 of ~100 stragglers of config 2 got their twin -- and the launch was as long as before: it ends with
+// its slowest instance, and the twelve whose twin had given up before their streak began still walked all 100 iterations alone.)
+constexpr int kTwinIdlePolls = 1 << 15;
 constexpr int kTwinHandPolls = 1 << 16; // polls a finished twin waits for the primary's verdict (the primary answers at `start`)
 ALTRO_DEV unsigned long long tw_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3554,13 +3570,15 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   const ProblemDesc* pd = &pd_arg;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (blockIdx.x == 0 && tid == 0) publish_count(A);
-  // (twin workgroups, see TwinCtl: blocks [base, ...) of the launch serve the same slots as blocks [0, base))
+  // (twin workgroups, see TwinCtl: blocks [base, ...) of the launch are a POOL -- each serves whichever slot of the launch
+  //  publishes a streak first -- and block base + t owns shadow column col0 + t)
   const bool is_twin = tw.base > 0 && (int)blockIdx.x >= tw.base;
-  const int slot = is_twin ? (int)blockIdx.x - tw.base : (int)blockIdx.x;
-  const int b_real = instance_of_slot(A, slot, 0);
-  if (b_real < 0) return;  // uniform over the workgroup
-  unsigned long long* const box = (tw.base > 0 && slot < tw.cap && persistent) ? tw.box + (size_t)slot * kTwWords : nullptr;
-  if (is_twin && !box) return;
+  const int tslot = is_twin ? (int)blockIdx.x - tw.base : -1;
+  int slot = is_twin ? -1 : (int)blockIdx.x;
+  int b_real = is_twin ? -1 : instance_of_slot(A, slot, 0);
+  if (!is_twin && b_real < 0) return;  // uniform over the workgroup
+  if (is_twin && (tslot >= tw.cap || !persistent)) return;
+  unsigned long long* box = (!is_twin && tw.base > 0 && slot < tw.cap && persistent) ? tw.box + (size_t)slot * kTwWords : nullptr;
   int b = b_real;  // (a twin switches to its shadow column once it has claimed its share of the iterations)
   const int N = A.N;
   const unsigned Bp = A.Bp;
@@ -3619,9 +3637,15 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   int tw_break_total = -1;         // primary: it_total left by the last iteration that was NOT one of those
   unsigned long long tw_ver = 0;   // primary, thread 0: version of the newest snapshot
   bool tw_closed = false;          // primary, thread 0: the mailbox is out of use
+  bool tw_shown = false;           // primary, thread 0: the slot's state word says "snapshot on display"
   unsigned long long tw_claim = 0, tw_claim_rho = 0, tw_claim_drho = 0;  // primary, thread 0: the twin's claim, once seen
   int tw_claim_snap = 0;
   int tw_loops0 = 0;               // twin: iterations the primary ran before the hand-over
+  auto stamp = [&](int which, long long value = -1) __attribute__((always_inline)) {
+    if (box && tw.debug) tw_store(box + kTwStamp + which, (unsigned long long)(value >= 0 ? value : wall_clock64()));
+  };
+  const long long tstart_clock = tw.debug ? wall_clock64() : 0;
+  if (tid == 0 && !is_twin) stamp(kTsPStart);
   // report of this workgroup to the host (longest chain of iterations, units processed): both ways out of the kernel
   auto report = [&](int chain_loops, int units) __attribute__((always_inline)) {
     if (sweeps_out && tid == 0) {
@@ -3633,62 +3657,100 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     }
   };
   if (is_twin) {
-    if (tid == 0) {
-      double go = 0.0;
-      unsigned long long cnt = 0, rb = 0, db = 0;
-      for (int tries = 0; tries < kTwinIdlePolls; ++tries) {
-        if (tw_load(box + kTwHand) != 0) break;  // the primary has finished: nothing to share
-        const unsigned long long ver = tw_load(box + kTwSeq);
-        if (ver != 0) {
-          const unsigned long long* buf = box + kTwSnap + 4 * (ver & 1);
-          cnt = tw_load(buf);
-          rb = tw_load(buf + 1);
-          db = tw_load(buf + 2);
-          const unsigned long long ver2 = tw_load(box + kTwSeq);
-          if (ver2 == ver || ver2 == ver + 1) {  // (buffer ver & 1 is only rewritten by version ver + 2)
-            go = 1.0;
-            break;
+    // ---- find work: a slot whose primary has published a streak and that no other twin serves ----
+    if (wave == 0) {
+      const int cnt_slots = A.act_count ? *A.act_count : A.act_count_const;
+      const int nsl = cnt_slots < tw.cap ? cnt_slots : tw.cap;
+      int chosen = -1;
+      for (int tries = 0; tries < kTwinIdlePolls && chosen < 0; ++tries) {
+        int waiting = 0;  // primaries that may still offer something: alive (or not yet dispatched) and unclaimed
+        for (int s0 = 0; s0 < nsl && chosen < 0; s0 += kBlock) {
+          const int sc = s0 + lane;
+          bool open = false, cand = false;
+          if (sc < nsl) {
+            const unsigned long long st = tw_load(tw.state + sc);
+            open = (st & (kTwsClosed | kTwsLocked)) == 0;
+            cand = st == kTwsSnap;
           }
-          continue;
-        }
-        __builtin_amdgcn_s_sleep(32);
-      }
-      if (go != 0.0) {
-        const int it_in = (int)(cnt >> 32), it_tot = (int)(cnt & 0xffffffffull);
-        // iterations until a cap ends the streak at the latest (ilqr.hpp:600-611)
-        const int r1 = o.max_iterations_inner - it_in, r2 = o.max_iterations_total - it_tot;
-        const int R = r1 < r2 ? r1 : r2;
-        if (R < kTwinMinRemaining) {
-          go = 0.0;
-        } else {
-          const int ahead = (R + kTwinLag) / 2 + 1;  // iterations the primary keeps, counted from the snapshot
-          // the regularisation entering iteration `start`: every iteration in between runs its backward pass
-          // (DecreaseRegularization, ilqr.hpp:440) and rejects its line search (IncreaseRegularization, :550)
-          double rho = tw_dbl(rb), drho = tw_dbl(db);
-          for (int j = 0; j < ahead; ++j) {
-            decrease_reg(o, &rho, &drho);
-            increase_reg(o, &rho, &drho);
+          waiting += __popcll(__ballot(open));
+          unsigned long long m = __ballot(cand);
+          while (m != 0 && chosen < 0) {
+            const int s2 = s0 + (__ffsll((long long)m) - 1);
+            m &= m - 1;
+            unsigned long long* bx = tw.box + (size_t)s2 * kTwWords;
+            int got = 0;  // 0: lost the lock, 1: claimed, 2: locked but nothing to claim (kept locked), 3: snapshot gone (unlocked)
+            if (lane == 0 && tw_cas(tw.state + s2, kTwsSnap, kTwsSnap | kTwsLocked)) {
+              got = 3;
+              unsigned long long cnt = 0, rb = 0, db = 0;
+              bool have = false;
+              for (int r = 0; r < 8 && !have; ++r) {
+                const unsigned long long ver = tw_load(bx + kTwSeq);
+                if (ver == 0) break;  // the streak broke meanwhile
+                const unsigned long long* buf = bx + kTwSnap + 4 * (ver & 1);
+                cnt = tw_load(buf);
+                rb = tw_load(buf + 1);
+                db = tw_load(buf + 2);
+                const unsigned long long ver2 = tw_load(bx + kTwSeq);
+                have = ver2 == ver || ver2 == ver + 1;  // (buffer ver & 1 is only rewritten by version ver + 2)
+              }
+              if (have) {
+                const int it_in = (int)(cnt >> 32), it_tot = (int)(cnt & 0xffffffffull);
+                // iterations until a cap ends the streak at the latest (ilqr.hpp:600-611)
+                const int r1 = o.max_iterations_inner - it_in, r2 = o.max_iterations_total - it_tot;
+                const int R = r1 < r2 ? r1 : r2;
+                if (R < kTwinMinRemaining) {
+                  got = 2;  // not worth a twin's start-up: stays locked, nobody else tries
+                } else {
+                  const int ahead = (R + tw.lag) / 2 + 1;  // iterations the primary keeps, counted from the snapshot
+                  // the regularisation entering iteration `start`: every iteration in between runs its backward pass
+                  // (DecreaseRegularization, ilqr.hpp:440) and rejects its line search (IncreaseRegularization, :550)
+                  double rho = tw_dbl(rb), drho = tw_dbl(db);
+                  for (int jj = 0; jj < ahead; ++jj) {
+                    decrease_reg(o, &rho, &drho);
+                    increase_reg(o, &rho, &drho);
+                  }
+                  tw_store(bx + kTwClaimRho, tw_bits(rho));
+                  tw_store(bx + kTwClaimDrho, tw_bits(drho));
+                  tw_store(bx + kTwClaimSnap, (unsigned long long)(unsigned)it_tot);
+                  tw_order();
+                  tw_store(bx + kTwClaim, ((unsigned long long)(unsigned)(it_in + ahead) << 32) | (unsigned long long)(unsigned)(it_tot + ahead));
+                  ff[8] = (double)(it_in + ahead);
+                  ff[9] = (double)(it_tot + ahead);
+                  ff[10] = rho;
+                  ff[11] = drho;
+                  if (sweeps_out) atomicAdd(sweeps_out + 5, 1);  // claims of this launch
+                  got = 1;
+                }
+              }
+              if (got == 3) __hip_atomic_fetch_and(tw.state + s2, ~kTwsLocked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            got = __shfl(got, 0);
+            if (got == 1) chosen = s2;
           }
-          tw_store(box + kTwClaimRho, tw_bits(rho));
-          tw_store(box + kTwClaimDrho, tw_bits(drho));
-          tw_store(box + kTwClaimSnap, (unsigned long long)(unsigned)it_tot);
-          tw_order();
-          tw_store(box + kTwClaim, ((unsigned long long)(unsigned)(it_in + ahead) << 32) | (unsigned long long)(unsigned)(it_tot + ahead));
-          ff[8] = (double)(it_in + ahead);
-          ff[9] = (double)(it_tot + ahead);
-          ff[10] = rho;
-          ff[11] = drho;
-          // (what the primary's workgroup stored before it published -- the trajectory of its last accepted step, the
-          //  multipliers -- may sit in another XCD's L2: its release is matched by this acquire)
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (chosen < 0) {
+          if (waiting == 0) break;  // every primary has finished or has its twin
+          __builtin_amdgcn_s_sleep(64);
         }
       }
-      ff[12] = go;
+      if (lane == 0) {
+        ff[15] = (double)chosen;
+        // (what the primary's workgroup stored before it published -- the trajectory of its last accepted step, the
+        //  multipliers -- may sit in another XCD's L2: its release is matched by this acquire)
+        if (chosen >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
     }
     __syncthreads();
-    if (ff[12] == 0.0) return;
+    slot = (int)ff[15];
+    if (slot < 0) return;
+    box = tw.box + (size_t)slot * kTwWords;
+    b_real = instance_of_slot(A, slot, 0);
+    if (tid == 0) {
+      stamp(kTsTStart, tstart_clock);
+      stamp(kTsTGo);
+    }
     // ---- clone the instance into the shadow column ----
-    const int bT = tw.col0 + slot;
+    const int bT = tw.col0 + tslot;
     {
       using R_ = Rec<T, M::n, M::m>;
       for (int i = tid; i < (N + 1) * R_::nP; i += kThreads) {
@@ -3729,6 +3791,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     }
     b = bT;
     __syncthreads();
+    if (tid == 0) stamp(kTsTCloned);
     if (tid == 0) ff[12] = tw_load(box + kTwHand) == 0 ? 1.0 : 0.0;  // (refused already -- the primary broke its streak or finished)
     __syncthreads();
     if (ff[12] == 0.0) return;
@@ -3926,11 +3989,25 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
                 if (tw_streak == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 tw_order();
                 tw_store(box + kTwSeq, tw_ver);
+                if (!tw_shown) {
+                  tw_order();
+                  __hip_atomic_fetch_or(tw.state + slot, kTwsSnap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  tw_shown = true;
+                }
+                if (tw_ver == 1) {
+                  stamp(kTsPSnap);
+                  stamp(kTsPLoopsAtSnap, loops);
+                }
               }
               // (a streak that broke: the snapshot on display describes a state that no longer exists -- a late twin would
               //  claim on it and be refused; hide it until the next streak publishes)
-              if (!rc && tw_ver != 0) tw_store(box + kTwSeq, 0ull);
+              if (!rc && tw_shown) {
+                __hip_atomic_fetch_and(tw.state + slot, ~kTwsSnap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tw_store(box + kTwSeq, 0ull);
+                tw_shown = false;
+              }
               tw_claim = tw_load(box + kTwClaim);
+              if (tw_claim != 0) stamp(kTsPClaim);
               if (tw_claim != 0) {  // (its other words were stored before it; from now on nothing is published or polled)
                 tw_claim_rho = tw_load(box + kTwClaimRho);
                 tw_claim_drho = tw_load(box + kTwClaimDrho);
@@ -3940,15 +4017,19 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
             if (tw_claim != 0) {
               const int s_in = (int)(tw_claim >> 32), s_tot = (int)(tw_claim & 0xffffffffull);
               bool refuse = !rc || it_in > s_in;
+              int why = !rc ? 1 : (it_in > s_in ? 2 : 0);
               if (!refuse && it_in == s_in) {
                 // the twin's assumptions about the state entering this iteration, bit for bit -- and no iteration since
                 // its snapshot that was anything but a rejected one
                 const bool same = it_tot == s_tot && tw_bits(ff[1]) == tw_claim_rho && tw_bits(ff[2]) == tw_claim_drho &&
                                   tw_break_total < tw_claim_snap;
                 if (same) act = 2.0; else refuse = true;
+                why = it_tot != s_tot ? 3 : (tw_bits(ff[1]) != tw_claim_rho ? 4 : (tw_bits(ff[2]) != tw_claim_drho ? 5 : 6));
               }
               if (refuse) {
+                tw_store(box + kTwWhy, (unsigned long long)why | ((unsigned long long)(unsigned)it_in << 8) | ((unsigned long long)(unsigned)s_in << 24));
                 tw_cas(box + kTwHand, 0ull, kTwRefused);
+                __hip_atomic_fetch_or(tw.state + slot, kTwsClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tw_closed = true;
               }
             }
@@ -3956,6 +4037,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
           ff[13] = act;
         }
       } else if (tid == 0) {
+        if (loops == 1) stamp(kTsTFirst);
         ff[13] = ((loops & 7) == 0 && tw_load(box + kTwHand) >= kTwRefused) ? 1.0 : 0.0;
       }
     }
@@ -3976,7 +4058,9 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
           tw_store(box + kTwHandLoops, (unsigned long long)(unsigned)loops);
           tw_order();
           ff[13] = tw_cas(box + kTwHand, 0ull, kTwOk) ? 3.0 : 0.0;  // (lost against a twin that gave up: go on alone)
+          __hip_atomic_fetch_or(tw.state + slot, kTwsClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tw_closed = true;
+          stamp(kTsPHand);
         }
         __syncthreads();
         if (ff[13] == 3.0) {
@@ -3989,18 +4073,22 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   // ---- a twin commits: the primary's verdict, then the shadow column over the instance's own ----
   if (is_twin) {
     if (tid == 0) {
+      stamp(kTsTDone);
+      stamp(kTsTLoops, loops);
       unsigned long long h = 0;
       for (int tries = 0; tries < kTwinHandPolls && (h = tw_load(box + kTwHand)) == 0; ++tries) __builtin_amdgcn_s_sleep(32);
       if (h == 0) h = tw_cas(box + kTwHand, 0ull, kTwRevoked) ? kTwRevoked : tw_load(box + kTwHand);
       if (h == kTwOk) {
         ff[14] = (double)(unsigned)tw_load(box + kTwHandLoops);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        stamp(kTsTVerdict);
       }
       ff[13] = h == kTwOk ? 1.0 : 0.0;
     }
     __syncthreads();
     if (ff[13] == 0.0) return;
     tw_loops0 = (int)ff[14];
+    if (sweeps_out && tid == 0) atomicAdd(sweeps_out + 4, 1);  // hand-overs of this launch
     {
       using R_ = Rec<T, M::n, M::m>;
       using RS_ = rec_scalar_t<T, M>;
@@ -4040,8 +4128,11 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
       }
     }
     b = b_real;  // (the gains below go to the instance's own records)
+    if (tid == 0) stamp(kTsTCommit);
   } else if (box && tid == 0 && !tw_closed) {
     tw_cas(box + kTwHand, 0ull, kTwRefused);  // the instance is finished: a twin still waiting for a streak may leave
+    __hip_atomic_fetch_or(tw.state + slot, kTwsClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(kTsPEnd);
   }
 #ifdef ALTRO_STAMPS
   __syncthreads();

@@ -167,6 +167,8 @@ typedef struct altro_timing {
                            /* waited for a sweep counter (large batches; ALTRO_HIP_HOST_WAIT=spin: 0) */
   int twin_workgroups;     /* twin workgroups of the persistent launch: each may take over the second half  */
                            /* of one straggler's rejection streak (0: none launched, ALTRO_HIP_TWIN=0)        */
+  int twin_claims;         /* ... twins that found a streak and claimed its second half                      */
+  int twin_handovers;      /* ... claims the primary confirmed: instances finished by their twin              */
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

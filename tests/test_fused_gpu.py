@@ -208,7 +208,8 @@ for name, fac in cases:
     for k in (0, 50, 100):
         e = s.get_expansion(k)
         for key, v in e.items():
-            out[name + "_exp%%d_%%s" %% (k, key)] = v
+            if k < 100 or key in ("lxx", "lx"):   # (the terminal knot has no dynamics and no control blocks)
+                out[name + "_exp%%d_%%s" %% (k, key)] = v
     out[name + "_costs"] = s.get_knot_costs()
     out[name + "_twins"] = np.array([tm["twin_workgroups"]]); out[name + "_ms"] = np.array([tm["total_ms"]])
     out[name + "_iters"] = np.array([tm["instance_iterations"], tm["fused_instance_iterations"], tm["sweeps"]])
