@@ -159,7 +159,10 @@ def dominant_kernel_roofline(cfg, tm, config_index):
         "kernel_wall_ms": {k: round(v, 3) for k, v in wall_ms.items()},
         "sweep_launches": tm.get("sweep_launches", 0),
         "concurrent_chains": max(1, round(tm.get("sweep_launches", 0) / max(1, tm["sweeps"] - tm["fused_sweeps"]))),
-        "tail_iterations": tm["fused_sweeps"],
+        "tail_iterations": tm["fused_sweeps"],  # most iterations ONE workgroup of the persistent launch ran (a twin: its share)
+        # twin workgroups of the persistent launch: launched / claimed a streak's second half / confirmed
+        "twin_workgroups": tm.get("twin_workgroups", 0), "twin_claims": tm.get("twin_claims", 0),
+        "twin_handovers": tm.get("twin_handovers", 0),
         # the OTHER roof: how close the kernel's fp64 vector work comes to the fp64 VALU peak (PMC pass in profiles/)
         "compute": compute_side(key, config_index, 1e3 * avg_launch_ms),
     }
@@ -178,7 +181,9 @@ def dominant_kernel_roofline(cfg, tm, config_index):
             "limiter": "serial dependency chain: the persistent tail kernel carries one straggler instance per "
                        "workgroup through ~100 iterations x (N Riccati steps + N RK4 steps); chain_floor_us is "
                        "the dependent-instruction latency of one iteration (measured issue latencies, "
-                       "profiles/r01_microbench.txt), tail_iteration_us what one iteration takes",
+                       "profiles/r01_microbench.txt), tail_iteration_us = launch duration / the most iterations any one "
+                       "workgroup ran (with twin workgroups the ~100 rejected iterations of a straggler are shared by two "
+                       "workgroups: the figure then includes the twin's start-up and the hand-over)",
         })
     return roofline
 

@@ -158,7 +158,7 @@ typedef struct altro_timing {
   double fused_ms;         /* the persistent tail launch (k_sweep_fused): every remaining    */
                            /* iteration of the straggler instances, one workgroup each      */
   int sweeps;              /* batched iLQR sweeps = longest chain of iterations             */
-  int fused_sweeps;        /* how many of them ran inside the persistent launch             */
+  int fused_sweeps;        /* most iterations one workgroup of the persistent launch ran    */
   int launches;            /* number of kernel launches                                     */
   int sweep_launches;      /* batched sweeps launched (all chains of sweeps together)       */
   long long instance_iterations; /* sum over instances of iterations_total                  */
