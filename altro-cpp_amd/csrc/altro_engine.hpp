@@ -257,6 +257,7 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   altro_status UpdateExpansions(const altro_options&) override {
+    ctg_replayable_ = false;  // (the records a replayed backward pass would read are about to change)
     if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     hipLaunchKernelGGL((k_expansions<T, M>), GridBK(), dim3(kBlock), 0, stream_, A_, d_pd_, 1, (int*)nullptr, (int*)nullptr);
@@ -266,7 +267,43 @@ class Engine final : public EngineBase {
     cur_ = stream_;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     LaunchBackward(A_, ToDevOpts(o), 1, B_);
+    ctg_fresh_ = A_.record_ctg != 0;
+    ctg_replayable_ = false;
     return Sync();
+  }
+  // the backward pass of the last iteration of a whole solve, once more, with the cost-to-go records on (see GetCtg)
+  altro_status ReplayCtg() {
+    ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
+    altro_status st = Sync();
+    if (st != ALTRO_OK) return st;
+    double* tmpT = nullptr;
+    int* tmpI = nullptr;
+    const size_t nT = (size_t)kNumScalarT * Bp_ * sizeof(double), nI = (size_t)kNumScalarI * Bp_ * sizeof(int);
+    ALTRO_HIP_CHECK(hipMalloc((void**)&tmpT, nT));
+    if (hipMalloc((void**)&tmpI, nI) != hipSuccess) {
+      hipFree(tmpT);
+      err_ = "ReplayCtg: out of device memory";
+      return ALTRO_HIP_ERROR;
+    }
+    hipError_t e = hipMemcpyAsync(tmpT, d_scalarT_, nT, hipMemcpyDeviceToDevice, stream_);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmpI, d_scalarI_, nI, hipMemcpyDeviceToDevice, stream_);
+    // the regularisation the last backward pass used (stats_.Log("reg", rho_)) is what this one starts from
+    if (e == hipSuccess) e = hipMemcpyAsync(A_.rho_reg, A_.reg_log, (size_t)Bp_ * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    if (e == hipSuccess) {
+      DevArrays<T> A = A_;
+      A.record_ctg = 1;
+      cur_ = stream_;
+      LaunchBackward(A, last_opts_, 1, B_);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scalarT_, tmpT, nT, hipMemcpyDeviceToDevice, stream_);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scalarI_, tmpI, nI, hipMemcpyDeviceToDevice, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    hipFree(tmpT);
+    hipFree(tmpI);
+    ALTRO_HIP_CHECK(e);
+    ctg_fresh_ = true;
+    return ALTRO_OK;
   }
   altro_status ForwardPass(const altro_options& o) override {
     cur_ = stream_;
@@ -326,10 +363,21 @@ class Engine final : public EngineBase {
     A_.record_ctg = enable ? 1 : 0;
     return ALTRO_OK;
   }
+  // KnotPointFunctions::GetCostToGoHessian / Gradient (knot_point_function_type.hpp:243-268): P, p of the LAST backward
+  // pass.  The solve itself keeps them in registers unless altro_set_record_ctg asked for the records (the persistent kernel
+  // never stores them).  The reference's stay readable after Solve(); here a read behind a solve that did not record runs
+  // that backward pass ONCE MORE with the recording on -- the expansions of the last iteration are still in memory, the
+  // regularisation it used is logged (reg_log) -- and puts the solver state back (ReplayCtg): same kernels on the same
+  // inputs, the same P, p.
   altro_status GetCtg(double* P, double* p) override {
-    if (!A_.record_ctg) {
-      err_ = "cost-to-go is only recorded after altro_set_record_ctg(h, 1)";
-      return ALTRO_NOT_READY;
+    if (!ctg_fresh_) {
+      if (!ctg_replayable_) {
+        err_ = "no cost-to-go to read: it belongs to a backward pass -- altro_solve_*, or altro_backward_pass after "
+               "altro_set_record_ctg(h, 1) -- and the trajectory or the expansions have changed since the last one";
+        return ALTRO_NOT_READY;
+      }
+      const altro_status rs = ReplayCtg();
+      if (rs != ALTRO_OK) return rs;
     }
     if (P) {
       altro_status st = DownloadRec(A_.CTG, N_ + 1, R::CP, R::oP, n * n, P);
@@ -1479,6 +1527,9 @@ class Engine final : public EngineBase {
     d.fast_forward_stalls = fast_forward_ ? 1 : 0;
     const bool prof = o.profiler_enable != 0;
     last_mode_ilqr_ = (mode == kFwdILQR);
+    last_opts_ = d;
+    ctg_fresh_ = A_.record_ctg != 0;  // (recorded by the batched backward kernels of this solve, or readable through ReplayCtg)
+    ctg_replayable_ = true;
     std::memset(&timing_, 0, sizeof(timing_));
     size_t nev = 0;
     cur_ = stream_;
@@ -1877,6 +1928,9 @@ class Engine final : public EngineBase {
   int B_ = 0, Bp_ = 0, N_ = 0;
   bool uploaded_ = false;
   bool last_mode_ilqr_ = false;
+  DevOpts last_opts_{};          // options of the last whole solve (ReplayCtg)
+  bool ctg_fresh_ = false;       // the cost-to-go records are those of the last backward pass
+  bool ctg_replayable_ = false;  // ... or can be recomputed from what the last whole solve left in memory
   ProblemDesc pd_{};
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};

@@ -635,7 +635,10 @@ ALTRO_DEV void rows01(double x, double& from_row0, double& from_row1) {
   from_row1 = __hiloint2double((int)bb[1], (int)a[1]);
 }
 
-constexpr int kBwdAhead = 6;    // knots per prefetch block of the MFMA backward pass
+#ifndef ALTRO_BWD_AHEAD
+#define ALTRO_BWD_AHEAD 6
+#endif
+constexpr int kBwdAhead = ALTRO_BWD_AHEAD;  // knots per prefetch block of the MFMA backward pass (A/B builds: profiles/r05_experiments.txt)
 constexpr int kBwdFrontPad = 2 * kBwdAhead;  // records in front of knot 0 that the prefetch may touch
 constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bulk stores (4 instances: 32 KiB)
 

@@ -779,7 +779,6 @@ struct Core {
   std::vector<std::vector<examples::ConstraintDesc>> cons;  // per knot, solver order (empty without AL)
   // cache
   unsigned gains_epoch = ~0u, ctg_epoch = ~0u;
-  bool ctg_read = false;  // a KnotPointFunctions view has asked for the cost-to-go: whole solves record it from now on
   std::vector<double> K, d, P, p;
   // sums of the solves' device timings while SolverOptions::profiler_enable is set; written at destruction unless
   // PrintTimings() was called (the reference's Timer: timer.cpp:10-14, solver_stats.cpp:60-77)
@@ -873,14 +872,11 @@ class KnotPointFunctions {
   }
   void Ctg() const {
     if (c_->ctg_epoch == c_->epoch) return;
-    c_->ctg_read = true;  // (iLQR::PrepareSolve: every later Solve() keeps P, p -- as the reference does after its Solve())
     c_->P.resize((size_t)c_->B * (c_->N + 1) * n * n);
     c_->p.resize((size_t)c_->B * (c_->N + 1) * n);
-    if (altro_get_ctg(c_->h, c_->P.data(), c_->p.data()) != ALTRO_OK)
-      throw std::runtime_error(std::string("altro_get_ctg failed: ") + altro_last_error(c_->h) +
-                               " -- the last whole Solve() ran without recording the cost-to-go (default for small batches: the "
-                               "persistent kernel keeps P, p in registers).  Solves from now on record it; or call "
-                               "SetRecordCostToGo(true) before Solve(), or read it after a step-level BackwardPass().");
+    // (behind a Solve() that did not record them -- the default: the persistent kernel keeps P, p in registers -- the library
+    //  runs the last iteration's backward pass once more with the records on: altro_get_ctg, Engine::ReplayCtg)
+    detail::Check(c_->h, altro_get_ctg(c_->h, c_->P.data(), c_->p.data()), "altro_get_ctg");
     c_->ctg_epoch = c_->epoch;
   }
   static std::vector<double> Slice(const std::vector<double>& v, size_t off, size_t len) {
@@ -945,14 +941,13 @@ class iLQR {
   // rows the SolverStats vectors can reach under the current options (one per iteration + the initial row)
   int HistoryRowsNeeded() const { return std::max(kHistoryCapacity, c_->opts.max_iterations_total + 2); }
 
-  // KnotPointFunctions::GetCostToGoHessian / Gradient need the backward pass to store P, p of every knot (the solve
-  // itself only needs them in registers, and the persistent tail kernel -- the fast path of exactly the small batches a
-  // facade user solves -- only runs without the recording).  Default for batches of up to kHistoryBatchLimit instances:
-  // the STEP-LEVEL BackwardPass() records (that is where the reference's tests read the cost-to-go:
-  // test/ilqr/unicycle_ilqr_test.cpp:39-54), Solve() does not.  SetRecordCostToGo(true) records everywhere (a Solve()
-  // then takes the batched kernels only), SetRecordCostToGo(false) nowhere.  DIFFERENCE FROM THE REFERENCE, where P and p
-  // stay readable after every Solve(): here the first GetCostToGo*() behind a default Solve() throws (with this
-  // explanation); from that read on the solver knows its user wants them and every later Solve() records (Core::ctg_read).
+  // KnotPointFunctions::GetCostToGoHessian / Gradient need P, p of every knot in memory; a solve only needs them in
+  // registers, and the persistent tail kernel -- the fast path of exactly the small batches a facade user solves -- only
+  // runs without the recording.  Default for batches of up to kHistoryBatchLimit instances: the STEP-LEVEL BackwardPass()
+  // records (that is where the reference's tests read the cost-to-go: test/ilqr/unicycle_ilqr_test.cpp:39-54), Solve()
+  // does not -- and P, p are readable behind it all the same, as in the reference: the first read makes the library run the
+  // last iteration's backward pass once more with the records on (same kernels, same inputs, same values; round 5).
+  // SetRecordCostToGo(true) records during every solve (which then takes the batched kernels only), (false) never.
   void SetRecordCostToGo(bool on) {
     ctg_auto_ = false;
     ApplyRecordCtg(on);
@@ -965,7 +960,7 @@ class iLQR {
   // called in front of every whole solve (also by AugmentedLagrangianiLQR::Solve): recording policy and a history
   // buffer large enough for the iteration caps in force
   void PrepareSolve() {
-    if (ctg_auto_) ApplyRecordCtg(c_->ctg_read);
+    if (ctg_auto_) ApplyRecordCtg(false);
     if (c_->record_history && HistoryRowsNeeded() > c_->hist_cap) SetRecordHistory(true);
   }
 

@@ -10,7 +10,7 @@ rm -rf $P; mkdir -p $P
 # the size of the trace pass's.  ALTRO_HIP_CHAINS forces the count (and skips the check): what a fresh process picks
 # (4 for a batch >= 2048, else 1).
 case $C in 2|3) export ALTRO_HIP_CHAINS=4;; *) export ALTRO_HIP_CHAINS=1;; esac
-CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --no-fast-forward"
+CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --no-fast-forward --no-pipeline2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o bench -- $CMD > $P/trace_run.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -o bench -- $CMD > $P/fetch_run.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -o bench -- $CMD > $P/write_run.log 2>&1

@@ -564,18 +564,21 @@ static void RecordingPolicyTests() {
   EXPECT(solver.GetStatus() == SolverStatus::kSolved && solver.GetStats().iterations_total == 11);
   EXPECT(solver.GetTiming().fused_sweeps > 0);  // (round 2: the default recording kept the facade off this path)
   EXPECT(solver.GetStats().alpha.size() == 12 && solver.GetStats().alpha[0] == 0.0625);  // history: one call, all fields
-  bool threw = false;
-  try {
-    solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient();
-  } catch (const std::runtime_error&) {
-    threw = true;  // not recorded by a whole solve unless asked for
-  }
-  EXPECT(threw);
-  // ... but the read told the solver that its user wants P, p: every later Solve() keeps them, as the reference does
+  // P, p stay readable behind Solve(), as in the reference (knot_point_function_type.hpp:243-268): the persistent kernel kept
+  // them in registers, so the read makes the library run the last iteration's backward pass once more with the records on
+  const std::vector<double> p0 = solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient();
+  const std::vector<double> P50 = solver.GetiLQRSolver().GetKnotPointFunction(50).GetCostToGoHessian();
+  EXPECT(p0.size() == 3 && P50.size() == 9);
+  EXPECT(solver.GetStats().iterations_total == 11 && solver.GetStatus() == SolverStatus::kSolved);  // (the replay left the solver state alone)
+  // ... the same values a solve that records them all the way gives (then on the batched kernels), and the next default
+  // solve is back on the persistent kernel
+  solver.GetiLQRSolver().SetRecordCostToGo(true);
   solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();
   EXPECT(solver.GetStats().iterations_total == 11 && solver.GetTiming().fused_sweeps == 0);
-  EXPECT(solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient().size() == 3);
+  const std::vector<double> p0r = solver.GetiLQRSolver().GetKnotPointFunction(0).GetCostToGoGradient();
+  const std::vector<double> P50r = solver.GetiLQRSolver().GetKnotPointFunction(50).GetCostToGoHessian();
+  EXPECT(p0 == p0r && P50 == P50r);
   solver.GetiLQRSolver().SetRecordCostToGo(false);  // explicit: never
   solver.SetTrajectory(std::make_shared<Trajectory<3, 2>>(def.InitialTrajectory()));
   solver.Solve();

@@ -247,6 +247,48 @@ def _compare_full(o, g, solved_only_tight=True, xtol=XTOL, utol=UTOL, gtol=KTOL)
     return so, sg
 
 
+def test_cost_to_go_is_readable_after_a_default_solve(P, A, oracle_make, hip_make):
+    """KnotPointFunctions::GetCostToGoHessian / Gradient after Solve() (knot_point_function_type.hpp:243-268): the reference
+    keeps P, p of the last backward pass; the persistent kernel keeps them in registers, so altro_get_ctg behind a solve that
+    did not record them runs that backward pass once more with the records on (Engine::ReplayCtg) -- the oracle's values, the
+    bits of a solve that records all the way, and a solver state that the replay leaves alone."""
+    o, g = both(P, P.batch_turn90, oracle_make, hip_make, batch=96)
+    o.solve(); g.solve()
+    assert g.get_timing()["fused_sweeps"] > 0  # (the path that does not store them)
+    before = g.get_stats().copy()
+    lam0, K0 = g.get_duals(), g.get_gains()[0]
+    Pg, pg = g.get_ctg()
+    Po, po = o.get_ctg()
+    ok = o.get_stats()["status"] == 0
+    close_normwise(Pg[ok].reshape(-1, 3, 3), Po[ok].reshape(-1, 3, 3), 1e-8, label="P per knot after Solve, normwise")
+    close_normwise(pg[ok].reshape(-1, 3), po[ok].reshape(-1, 3), 1e-7, label="p per knot after Solve, normwise")
+    after = g.get_stats()
+    for f in before.dtype.names:
+        assert np.array_equal(before[f], after[f]), f
+    assert np.array_equal(lam0, g.get_duals()) and np.array_equal(K0, g.get_gains()[0])
+    g2 = P.batch_turn90(hip_make, batch=96)
+    g2.set_record_ctg(True)
+    g2.solve()
+    assert g2.get_timing()["fused_sweeps"] == 0
+    P2, p2 = g2.get_ctg()
+    assert np.array_equal(Pg, P2) and np.array_equal(pg, p2)
+    # a large batch: chains of sweeps, twin workgroups in the tail -- still the recorded solve's bits
+    g3 = P.batch_turn90(hip_make, batch=2304, seed=P.SEED_BASE + 3)
+    g3.solve()
+    P3, p3 = g3.get_ctg()
+    g4 = P.batch_turn90(hip_make, batch=2304, seed=P.SEED_BASE + 3)
+    g4.set_record_ctg(True)
+    g4.solve()
+    P4, p4 = g4.get_ctg()
+    assert np.array_equal(P3, P4) and np.array_equal(p3, p4)
+    # once the expansions have changed, the backward pass of the last iteration cannot be run again: nothing to read
+    g5 = P.batch_turn90(hip_make, batch=8)
+    g5.solve()
+    g5.update_expansions()
+    with pytest.raises(A.AltroError):
+        g5.get_ctg()
+
+
 def test_config1_three_obstacles_single(P, oracle_make, hip_make):
     o, g = both(P, P.unicycle_three_obstacles, oracle_make, hip_make)
     o.solve(); g.solve()
