@@ -1553,8 +1553,8 @@ class Engine final : public EngineBase {
     // stays one sweep ahead of the device, and sizes each grid with the newest count it knows --
     // counts only shrink, so it is an upper bound -- so tail sweeps launch a handful of workgroups.
     const int C = chains_;
-    const int cstride = 2 * (max_sweeps + 8);  // per chain: counts [0, max_sweeps + 2), results of the persistent kernel
-                                               // [max_sweeps + 2, + 3), cursors of the list rebuilds (dense sweeps) in the second half
+    const int cstride = 2 * (max_sweeps + 12);  // per chain: counts [0, max_sweeps + 2), results of the persistent kernel
+                                                // [max_sweeps + 2, + 10), cursors of the list rebuilds (dense sweeps) in the second half
     {
       altro_status rs = ReserveCounters(C * cstride + 16);
       if (rs != ALTRO_OK) return rs;
@@ -1635,7 +1635,7 @@ class Engine final : public EngineBase {
         // a good part of the chain is still iterating: lane = instance (coalesced rows and records), and the list is
         // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions)
         hipLaunchKernelGGL((k_expansions<T, M>), dim3((span + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 2,
-                           d_list_[i % 2] + ch.lo, ch.d_cnt + (max_sweeps + 8) + i);
+                           d_list_[i % 2] + ch.lo, ch.d_cnt + (max_sweeps + 12) + i);
       } else {
         hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 0, (int*)nullptr,
                            (int*)nullptr);
@@ -1838,10 +1838,11 @@ class Engine final : public EngineBase {
     int sweeps = 0;  // longest chain of iterations, the look-ahead sweep of a chain that ran dry included
     for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
-      int extra[6] = {0, 0, 0, 0, 0, 0};
+      int extra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
       timing_.twin_handovers = extra[4];
       timing_.twin_claims = extra[5];
+      timing_.fused_workgroup_iterations = extra[6];
       if (twin_cap_ > 0 && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {  // the mailboxes after the launch, slot by slot
         std::vector<unsigned long long> box((size_t)twin_cap_ * kTwWords);
         ALTRO_HIP_CHECK(CopySync(box.data(), d_twin_box_, box.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

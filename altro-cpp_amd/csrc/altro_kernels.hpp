@@ -3652,8 +3652,9 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   // report of this workgroup to the host (longest chain of iterations, units processed): both ways out of the kernel
   auto report = [&](int chain_loops, int units) __attribute__((always_inline)) {
     if (sweeps_out && tid == 0) {
-      atomicMax(sweeps_out, units + skipped);  // most iterations any ONE workgroup of this launch ran (a twin: its share)
+      atomicMax(sweeps_out, chain_loops);      // longest chain of iterations of one instance inside this launch
       atomicAdd(sweeps_out + 1, units);        // (instance, iteration) units processed by this launch
+      atomicMax(sweeps_out + 6, units + skipped);  // most iterations any ONE workgroup ran (a twin or its primary: their share)
       const int chain = A.chain_size ? (b_real / A.chain_size < kMaxSweepChains - 1 ? b_real / A.chain_size : kMaxSweepChains - 1) : 0;
       atomicMax(sweeps_out + 2, A.chain_base[chain] + chain_loops);  // ... counted from the first sweep of the solve
       if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word

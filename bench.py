@@ -159,7 +159,8 @@ def dominant_kernel_roofline(cfg, tm, config_index):
         "kernel_wall_ms": {k: round(v, 3) for k, v in wall_ms.items()},
         "sweep_launches": tm.get("sweep_launches", 0),
         "concurrent_chains": max(1, round(tm.get("sweep_launches", 0) / max(1, tm["sweeps"] - tm["fused_sweeps"]))),
-        "tail_iterations": tm["fused_sweeps"],  # most iterations ONE workgroup of the persistent launch ran (a twin: its share)
+        "tail_iterations": tm["fused_sweeps"],  # longest chain of iterations of one instance inside the persistent launch
+        "tail_workgroup_iterations": tm.get("fused_workgroup_iterations", 0) or tm["fused_sweeps"],  # ... of one WORKGROUP (a twin or its primary: their share)
         # twin workgroups of the persistent launch: launched / claimed a streak's second half / confirmed
         "twin_workgroups": tm.get("twin_workgroups", 0), "twin_claims": tm.get("twin_claims", 0),
         "twin_handovers": tm.get("twin_handovers", 0),
@@ -173,7 +174,7 @@ def dominant_kernel_roofline(cfg, tm, config_index):
         #  pass ready by then -- so the floor of such an iteration is the longer chain alone: chain_floor_overlap_us)
         floor_us = sum(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
         floor_overlap_us = max(CHAIN_CYCLES_PER_KNOT.values()) * N / (CLOCK_GHZ * 1e3)
-        iter_us = 1e3 * tm["fused_ms"] / tm["fused_sweeps"]
+        iter_us = 1e3 * tm["fused_ms"] / max(1, tm.get("fused_workgroup_iterations", 0) or tm["fused_sweeps"])
         roofline.update({
             "chain_floor_us": round(floor_us, 2), "chain_floor_overlap_us": round(floor_overlap_us, 2),
             "tail_iteration_us": round(iter_us, 2),

@@ -158,7 +158,7 @@ typedef struct altro_timing {
   double fused_ms;         /* the persistent tail launch (k_sweep_fused): every remaining    */
                            /* iteration of the straggler instances, one workgroup each      */
   int sweeps;              /* batched iLQR sweeps = longest chain of iterations             */
-  int fused_sweeps;        /* most iterations one workgroup of the persistent launch ran    */
+  int fused_sweeps;        /* how many of them ran inside the persistent launch             */
   int launches;            /* number of kernel launches                                     */
   int sweep_launches;      /* batched sweeps launched (all chains of sweeps together)       */
   long long instance_iterations; /* sum over instances of iterations_total                  */
@@ -169,6 +169,9 @@ typedef struct altro_timing {
                            /* of one straggler's rejection streak (0: none launched, ALTRO_HIP_TWIN=0)        */
   int twin_claims;         /* ... twins that found a streak and claimed its second half                      */
   int twin_handovers;      /* ... claims the primary confirmed: instances finished by their twin              */
+  int fused_workgroup_iterations; /* most iterations ONE workgroup of the persistent launch ran (a twin or its    */
+                           /* primary: their share of the instance's iterations)                               */
+  int reserved;
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

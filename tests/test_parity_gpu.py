@@ -98,7 +98,10 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
         for s in (o, g):
             s.backward_pass()
         assert (o.get_stats()["regularization"] == g.get_stats()["regularization"]).all()
-        nw = 1e-9 if it == 0 else 1e-7
+        # (measured, sweep 0: K 1.9e-11, d 6.5e-12, P 6.7e-11, p 2.9e-11 norm-wise.  Sweep 1 runs from non-trivial gains and
+        #  states -- handed to BOTH sides bit for bit, see the end of the loop -- so that its bars measure the kernels, not
+        #  the 1e10-fold sensitivity of this model to its inputs, which test_config5_* measures)
+        nw = 1e-9 if it == 0 else 1e-8
         Ko, do = o.get_gains()
         Kg, dg = g.get_gains()
         Po, po = o.get_ctg()
@@ -120,6 +123,10 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
         # (measured in sweep 0: X 1.2e-11, U 3.3e-11 abs -- entries of 1e-4 next to entries of 1)
         close(Xg, Xo, 1e-9, 2e-10 if it == 0 else 1e-8, label=f"X after the line search (sweep {it})")
         close(Ug, Uo, 1e-9, 2e-10 if it == 0 else 1e-8, label=f"U after the line search (sweep {it})")
+        # the next sweep starts from ONE trajectory on both sides (the GPU's): Qf / Q = 5e5 over 200 knots turns the 3e-11 of
+        # this line search into 1e-3 of the next sweep's gains -- in the oracle just as in the GPU (test_config5_*)
+        for s in (o, g):
+            s.set_trajectory(Xg, Ug)
 
 
 def test_reference_constants_on_gpu(P, hip_make):
