@@ -76,16 +76,27 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
     """The n = 12 path at STEP level against the oracle: one expansions / backward / forward sweep of
     batch_quadrotor12 in fp64 -- [A|B], lxx ... lu of k_expansions (RK4 Jacobian chain with its structural zeros), K, d and
     P, p of k_backward_mfma16 (the fp64 16x16x4 MFMA Riccati step), the line search of k_forward2 -- each against an
-    absolute bar.  Two sweeps: the second runs on the trajectory the first one accepted (non-trivial gains and states)."""
+    absolute bar.  Two sweeps: the second runs on the trajectory the first one accepted (non-trivial gains and states).
+
+    The second sweep's Riccati recursion is ill-conditioned (Qf / Q = 5e5 over 200 knots): the ORACLE's own K moves by
+    6e-4 norm-wise when its input trajectory is moved by one unit in the last place (measured on CPU; 1e-16 and 1e-12
+    relative perturbations give the same 1e-3: the amplification saturates).  So that sweep is judged against a second
+    oracle instance `o2` that gets the same trajectory with ~1-ulp noise: the GPU may differ from the oracle by no more
+    than 10 x what the oracle differs from itself (and never less than the 1e-8 bar); both figures go to the ledger."""
     N = 200
     o, g = both(P, P.batch_quadrotor12, oracle_make, hip_make, batch=6, N=N, dtype=A.F64)
-    for s in (o, g):
+    o2 = P.batch_quadrotor12(oracle_make, batch=6, N=N, dtype=A.F64)
+    for s in (o, g, o2):
         s.set_record_ctg(True)
         s.rollout()
     close(g.cost(), o.cost(), 1e-12, 0.0, label="initial cost")
     close(g.get_trajectory()[0], o.get_trajectory()[0], 1e-12, 1e-13, label="X rollout")
+    def spread(a, b):
+        ax = tuple(range(1, a.ndim))
+        return float((np.abs(a - b).max(axis=ax) / np.maximum(np.abs(b).max(axis=ax), 1e-12)).max())
+
     for it in range(2):
-        for s in (o, g):
+        for s in (o, g, o2):
             s.update_expansions()
         for k in (0, 1, 100, N - 1, N):
             eo, eg = o.get_expansion(k), g.get_expansion(k)
@@ -95,24 +106,34 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
         #  trajectories that differ by the 3e-11 of the first line search, which the bars of that sweep carry)
         close(g.get_knot_costs(), o.get_knot_costs(), 1e-11, 1e-13 if it == 0 else 2e-12, label=f"knot costs (sweep {it})")
         close(g.get_constraint_values(), o.get_constraint_values(), 1e-10, 1e-11 if it == 0 else 1e-9, label=f"constraint values (sweep {it})")
-        for s in (o, g):
+        for s in (o, g, o2):
             s.backward_pass()
         assert (o.get_stats()["regularization"] == g.get_stats()["regularization"]).all()
         # (measured, sweep 0: K 1.9e-11, d 6.5e-12, P 6.7e-11, p 2.9e-11 norm-wise.  Sweep 1 runs from non-trivial gains and
         #  states -- handed to BOTH sides bit for bit, see the end of the loop -- so that its bars measure the kernels, not
         #  the 1e10-fold sensitivity of this model to its inputs, which test_config5_* measures)
-        nw = 1e-9 if it == 0 else 1e-8
         Ko, do = o.get_gains()
         Kg, dg = g.get_gains()
         Po, po = o.get_ctg()
         Pg, pg = g.get_ctg()
+        nwK = nwd = nwP = nwp = 1e-9
+        if it == 1:
+            K2, d2 = o2.get_gains()
+            P2, p2 = o2.get_ctg()
+            own = [spread(K2.reshape(-1, 4, 12), Ko.reshape(-1, 4, 12)), spread(d2.reshape(-1, 4), do.reshape(-1, 4)),
+                   spread(P2.reshape(-1, 12, 12), Po.reshape(-1, 12, 12)), spread(p2.reshape(-1, 12), po.reshape(-1, 12))]
+            for name, v in zip("KdPp", own):
+                _ledger.record(f"ORACLE vs ORACLE + 1 ulp of input: {name} per knot, normwise (sweep 1)", v, v, 0.0, 0.0, 0.0)
+            nwK, nwd, nwP, nwp = (max(1e-8, 10.0 * v) for v in own)
         # norm-wise per knot block: an m x n gain block / n x n cost-to-go block has entries 1e-8 of its largest one
         # (decoupled axes), for which an element-wise relative bar is meaningless; SURVEY 8(c): rel 1e-9
-        close_normwise(Kg.reshape(-1, 4, 12), Ko.reshape(-1, 4, 12), nw, label=f"K per knot, normwise (sweep {it})")
-        close_normwise(dg.reshape(-1, 4), do.reshape(-1, 4), nw, label=f"d per knot, normwise (sweep {it})")
-        close_normwise(Pg.reshape(-1, 12, 12), Po.reshape(-1, 12, 12), nw, label=f"P per knot, normwise (sweep {it})")
-        close_normwise(pg.reshape(-1, 12), po.reshape(-1, 12), nw, label=f"p per knot, normwise (sweep {it})")
-        for s in (o, g):
+        close_normwise(Kg.reshape(-1, 4, 12), Ko.reshape(-1, 4, 12), nwK, label=f"K per knot, normwise (sweep {it})")
+        close_normwise(dg.reshape(-1, 4), do.reshape(-1, 4), nwd, label=f"d per knot, normwise (sweep {it})")
+        close_normwise(Pg.reshape(-1, 12, 12), Po.reshape(-1, 12, 12), nwP, label=f"P per knot, normwise (sweep {it})")
+        close_normwise(pg.reshape(-1, 12), po.reshape(-1, 12), nwp, label=f"p per knot, normwise (sweep {it})")
+        if it == 1:
+            break  # (the line search of a sweep whose gains are only defined to 1e-3 has nothing to compare)
+        for s in (o, g, o2):
             s.forward_pass()
         so, sg = o.get_stats(), g.get_stats()
         assert (so["alpha"] == sg["alpha"]).all(), (so["alpha"], sg["alpha"])
@@ -121,12 +142,14 @@ def test_step_level_quadrotor12(P, A, oracle_make, hip_make):
         Xo, Uo = o.get_trajectory()
         Xg, Ug = g.get_trajectory()
         # (measured in sweep 0: X 1.2e-11, U 3.3e-11 abs -- entries of 1e-4 next to entries of 1)
-        close(Xg, Xo, 1e-9, 2e-10 if it == 0 else 1e-8, label=f"X after the line search (sweep {it})")
-        close(Ug, Uo, 1e-9, 2e-10 if it == 0 else 1e-8, label=f"U after the line search (sweep {it})")
-        # the next sweep starts from ONE trajectory on both sides (the GPU's): Qf / Q = 5e5 over 200 knots turns the 3e-11 of
-        # this line search into 1e-3 of the next sweep's gains -- in the oracle just as in the GPU (test_config5_*)
+        close(Xg, Xo, 1e-9, 2e-10, label=f"X after the line search (sweep {it})")
+        close(Ug, Uo, 1e-9, 2e-10, label=f"U after the line search (sweep {it})")
+        # the next sweep starts from ONE trajectory on both sides (the GPU's); the second oracle gets it with noise of one
+        # unit in the last place
         for s in (o, g):
             s.set_trajectory(Xg, Ug)
+        rng = np.random.default_rng(5)
+        o2.set_trajectory(Xg * (1.0 + 1e-16 * rng.standard_normal(Xg.shape)), Ug * (1.0 + 1e-16 * rng.standard_normal(Ug.shape)))
 
 
 def test_reference_constants_on_gpu(P, hip_make):
