@@ -77,7 +77,7 @@ class Timing(C.Structure):
                 ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong),
                 ("host_naps", C.c_int), ("twin_workgroups", C.c_int),
                 ("twin_claims", C.c_int), ("twin_handovers", C.c_int),
-                ("fused_workgroup_iterations", C.c_int), ("reserved", C.c_int)]
+                ("fused_workgroup_iterations", C.c_int), ("segment_columns", C.c_int)]
 
 
 class AltroError(RuntimeError):

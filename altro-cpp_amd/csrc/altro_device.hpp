@@ -264,7 +264,31 @@ struct DevArrays {
   int xcd_remap;          // workgroup order of k_forward2 / k_backward_mfma: neighbouring instances on one XCD (xcd_block)
   int cand_front;         // k_forward2: leading line-search trials that own a candidate slot (CandLayout, altro_kernels.hpp)
   const int* knot_model;  // model of the source's ALTRO_USER_MODELS list that knot k uses (Problem::SetDynamics(model, k)); null: 0
+  // SEGMENTS OF A REJECTION STREAK in the batched sweeps (round 5; forward_phase3, altro_kernels.hpp).  An instance whose
+  // line search rejects every trial changes nothing but its regularisation (by a rule known in advance) and its counters, so
+  // the state entering iteration j + L of such a streak is known at iteration j.  The state machine then SPLITS what is left
+  // of the inner solve into seg_parts segments: the instance keeps the first, the others start in SHADOW COLUMNS -- clones of
+  // the instance with counters and regularisation advanced -- that join the active list as instances of their own, so that
+  // one sweep advances the streak by seg_parts iterations.  A column that reaches the end of its segment compares what it
+  // holds with what its successor assumed (bit for bit) and retires; a mismatch, or anything but a rejected iteration on the
+  // way, cancels the successors and the column goes on alone.  k_seg_fixup copies the last valid column of every chain back
+  // over the instance's own.  Every iteration is computed with the inputs the sequential order gives it: same bits.
+  // All arrays [Bp]; nullptr = feature off (ALTRO_HIP_SEGMENTS=0, small batches, a recorded history).
+  int *seg_end;     // it_inner at which this column's segment ends (INT_MAX: it owns the rest)
+  int *seg_next;    // shadow column of the next segment (-1: none)
+  int *seg_flag;    // kSegCancelled | kSegRetired
+  int *seg_streak;  // consecutive rejected iterations (inner solve going on) of this column
+  int *seg_tot0;    // it_total / regularisation this column ASSUMED when it started: what its predecessor must arrive with
+  double *seg_rho0, *seg_drho0;
+  int* seg_cursor;     // next free column of this launch's slice of shadow columns (device counter of the chain)
+  int seg_lo, seg_hi;  // that slice
+  int seg_parts;       // segments a streak is split into (1: this sweep does not split -- the host sized the next sweep's grids
+                       // for the count it knows, and only every kSegSplitEvery-th sweep may outgrow that)
 };
+constexpr int kSegSplitEvery = 4;
+constexpr int kSegCancelled = 1, kSegRetired = 2;
+constexpr int kSegNoEnd = 0x7fffffff;
+constexpr int kSegMinRemaining = 24;  // iterations left in an inner solve below which a streak is not split
 // step and time of knot k (k wave-uniform where it matters: scalar loads)
 template <class T>
 ALTRO_DEV T step_of(const DevArrays<T>& A, const ProblemDesc* pd, int k) {

@@ -730,6 +730,8 @@ class Engine final : public EngineBase {
     d_tmp_ = nullptr;
     d_twin_box_ = nullptr;
     twin_cap_ = 0;
+    d_seg_cursor_ = nullptr;
+    seg_total_ = 0;
     d_list_[0] = d_list_[1] = nullptr;
     d_iota_ = d_merged_ = nullptr;
     d_spec_go_ = nullptr;
@@ -862,13 +864,33 @@ class Engine final : public EngineBase {
     if constexpr (kMfmaBackward) {
       const char* e = std::getenv("ALTRO_HIP_TWIN");
       if (!(e && atoi(e) == 0) && !fast_forward_ && !no_fused_) {
-        const int want = std::min(Bp_, ((persist_at_ + 8 + kBlock - 1) / kBlock) * kBlock);
+        // (a solve that has split rejection streaks hands over at 3/2 of persist_at_, see Solve)
+        const int want = std::min(Bp_, ((persist_at_ * 3 / 2 + 8 + kBlock - 1) / kBlock) * kBlock);
         // (the MFMA backward pass addresses the expansion records with 32-bit byte offsets: only widen while that holds)
         const size_t bytes = ((size_t)kBwdFrontPad + (size_t)N_ + 2) * RR::EP * (size_t)(Bp_ + want) * sizeof(RS);
         if (bytes < (size_t)0xffffffffu) twin_cap_ = want;
       }
     }
-    Bp_ += twin_cap_;
+    // Segments of rejection streaks in the batched sweeps (DevArrays::seg_*): shadow columns [Bpad, Bpad + seg_total_),
+    // one slice per chain of sweeps, then the twin columns.  Only for batches that run batched sweeps at all; ALTRO_HIP_SEGMENTS=0 switches it off.
+    seg_total_ = 0;
+    seg_col0_ = Bp_;
+    if constexpr (kMfmaBackward) {
+      const char* e = std::getenv("ALTRO_HIP_SEGMENTS");
+      if (!(e && atoi(e) == 0) && !fast_forward_ && B_ > persist_at_) {
+        // (5/8 of the batch: most of the plateau of config 3 -- a quarter of its instances, three clones each -- fits, and
+        //  what the wider arrays cost a batch that never splits stays around 0.5 %: config 2 runs 0.3 % / 1 % / 2 % slower
+        //  with 2048 / 3520 / 4096 unused columns behind its 4672; config 3 is as fast with 2560 as with 4096;
+        //  profiles/r05_experiments.txt #3)
+        int want = (Bp_ * 5 / 8) / kBlock * kBlock;
+        if (const char* e2 = std::getenv("ALTRO_HIP_SEG_COLUMNS")) want = std::max(kBlock, atoi(e2) / kBlock * kBlock);
+        const size_t bytes = ((size_t)kBwdFrontPad + (size_t)N_ + 2) * RR::EP * (size_t)(Bp_ + want + twin_cap_) * sizeof(RS);
+        if (bytes < (size_t)0xffffffffu) seg_total_ = want;
+      }
+    }
+    seg_parts_ = 4;
+    if (const char* e = std::getenv("ALTRO_HIP_SEG_PARTS")) seg_parts_ = std::max(1, std::min(8, atoi(e)));
+    Bp_ += seg_total_ + twin_cap_;
     std::memset(&pd_, 0, sizeof(pd_));
     pd_.n = n;
     pd_.m = m;
@@ -1223,6 +1245,17 @@ class Engine final : public EngineBase {
     ALTRO_ALLOC(A_.cval, (size_t)rows * bp);
     ALTRO_ALLOC(d_tmp_, bp);
     if (twin_cap_ > 0) ALTRO_ALLOC(d_twin_box_, (size_t)twin_cap_ * (kTwWords + 1));  // mailboxes, then the state words
+    if (seg_total_ > 0) {
+      // (kept out of A_: only the launches of Solve that take part in the scheme see them, SegArrays)
+      ALTRO_ALLOC(seg_.end, bp);
+      ALTRO_ALLOC(seg_.next, bp);
+      ALTRO_ALLOC(seg_.flag, bp);
+      ALTRO_ALLOC(seg_.streak, bp);
+      ALTRO_ALLOC(seg_.tot0, bp);
+      ALTRO_ALLOC(seg_.rho0, bp);
+      ALTRO_ALLOC(seg_.drho0, bp);
+      ALTRO_ALLOC(d_seg_cursor_, kMaxChains);
+    }
     ALTRO_ALLOC(d_list_[0], bp);
     ALTRO_ALLOC(d_list_[1], bp);
     {
@@ -1516,6 +1549,8 @@ class Engine final : public EngineBase {
     int sweeps = 0;                  // sweeps enqueued
     int known = 0;                   // newest count the host knows (an upper bound of what the next sweep works on)
     bool waiting = false, done = false, tail = false;
+    bool last_split = false;         // the sweep enqueued last was allowed to split rejection streaks (its list may outgrow `known`)
+    bool split_seen = false;         // ... some sweep of this chain was: its slice of shadow columns may hold instances
     std::vector<size_t> ev;          // profiler events: chain start, then three per sweep
   };
 
@@ -1535,7 +1570,11 @@ class Engine final : public EngineBase {
     cur_ = stream_;
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
-    hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, A_, d, 1);
+    {
+      DevArrays<T> As = A_;
+      if (seg_total_ > 0) SegArrays(As);  // (resets the bookkeeping of the segments, DevArrays::seg_*)
+      hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, As, d, 1);
+    }
     hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
     timing_.launches += (mode == kFwdAL) ? 3 : 2;
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
@@ -1560,6 +1599,10 @@ class Engine final : public EngineBase {
       if (rs != ALTRO_OK) return rs;
     }
     ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+    // segments of rejection streaks: not with a recorded history (its rows are appended in iteration order)
+    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_;
+    const int seg_capc = seg_on ? (seg_total_ / C) / kBlock * kBlock : 0;  // shadow columns per chain
+    if (seg_on) ALTRO_HIP_CHECK(hipMemsetAsync(d_seg_cursor_, 0, kMaxChains * sizeof(int), stream_));
     Chain chain[kMaxChains];
     for (int c = 0; c < C; ++c) {
       Chain& ch = chain[c];
@@ -1599,26 +1642,74 @@ class Engine final : public EngineBase {
       ch.ev.push_back(nev++);
     };
     // lists of a chain: its own slice [lo, ...) of the two list buffers (a chain never holds more than hi - lo instances)
+    // (a chain's slice of the two list buffers: its instances and its shadow columns -- every column is listed at most once)
+    auto list_of = [&](int which, const Chain& ch) { return d_list_[which] + ch.lo + (int)(&ch - chain) * seg_capc; };
+    // (the kernels only see the arrays -- and pay for the bookkeeping of streaks, a few dependent words per instance and
+    //  sweep -- from sweep seg_from of a chain on: a batch whose sweeps are over by then, config 2, never does)
+    const int seg_from = std::getenv("ALTRO_HIP_SEG_FROM") ? atoi(std::getenv("ALTRO_HIP_SEG_FROM")) : 24;
+    auto seg_fields = [&](DevArrays<T>& A, const Chain& ch, int i) {
+      if (!seg_on || i < seg_from) {
+        A.seg_end = nullptr;
+        return;
+      }
+      const int c = (int)(&ch - chain);
+      SegArrays(A);
+      A.seg_cursor = d_seg_cursor_ + c;
+      A.seg_lo = seg_col0_ + c * seg_capc;
+      A.seg_hi = A.seg_lo + seg_capc;
+      A.seg_parts = seg_parts_;
+    };
+    // may sweep i of a chain split streaks?  Only every kSegSplitEvery-th does: the host sizes the grids of sweep i + 1 from
+    // the count sweep i - 1 left, and a sweep that splits is the only thing that can make a list longer than that
+    // ... and only while the batch has room: a streak split while most of the batch is still iterating only makes sweeps
+    // longer that the GPU already fills (the gain is in packing the plateau of the long inner solves into fewer sweeps)
+    const int seg_below = (int)((long long)B_ * seg_below_pct_ / 100);
+    // ... and not any more once the hand-over to the persistent kernel is near (3 x persist_at_ instances left): the
+    // launch takes whatever the lists hold by then, and a list that has just grown fourfold means rounds of workgroups
+    // instead of one (config 3: 32.2 - 32.6 ms with this bound, 33 - 35 ms with 1.5 x).  Once a chain has split, the
+    // hand-over itself moves to 1.5 x persist_at_: what is left when the segments retire are the long runners, whose
+    // iterations the persistent kernel runs at a fifth of a batched sweep's latency.
+    const int seg_above = std::getenv("ALTRO_HIP_SEG_ABOVE") ? atoi(std::getenv("ALTRO_HIP_SEG_ABOVE")) : 3 * persist_at_;
+    const int seg_persist_at = std::getenv("ALTRO_HIP_SEG_PERSIST_AT") ? atoi(std::getenv("ALTRO_HIP_SEG_PERSIST_AT")) : persist_at_ * 3 / 2;
+    const int seg_every = std::getenv("ALTRO_HIP_SEG_EVERY") ? std::max(1, atoi(std::getenv("ALTRO_HIP_SEG_EVERY"))) : kSegSplitEvery;
+    auto splits_in = [&](int i) {
+      return seg_on && i >= seg_from + 2 && (i % seg_every) == 0 && total_known() <= seg_below && total_known() > seg_above;
+    };
+    // upper bound of the instances a sweep may meet, given the newest count the host knows: a streak that splits adds
+    // seg_parts - 1 columns per instance between that count and the sweep being enqueued
+    auto bound_of = [&](const Chain& ch) {  // ... of the sweep about to be enqueued: what the one before it left
+      const int known = std::max(1, ch.known);
+      if (!ch.last_split) return known;
+      return (int)std::min<long long>((long long)(ch.hi - ch.lo) + seg_capc, (long long)known * seg_parts_);
+    };
+    auto any_split = [&]() {
+      bool any = false;
+      for (int c = 0; c < C; ++c) any = any || chain[c].split_seen;
+      return seg_on && any;
+    };
     auto enqueue_sweep = [&](Chain& ch, int i) -> altro_status {
       DevArrays<T> A = A_;
       A.chain_lo = ch.lo;
-      A.chain_hi = C > 1 ? ch.hi : 0;
+      A.chain_hi = (C > 1 || seg_on) ? ch.hi : 0;
+      seg_fields(A, ch, i);
       if (i == 0) {
         A.act_list = C > 1 ? d_iota_ + ch.lo : nullptr;
         A.act_count = nullptr;
         A.act_count_const = ch.hi - ch.lo;
         A.host_count = nullptr;
       } else {
-        A.act_list = d_list_[i % 2] + ch.lo;
+        A.act_list = list_of(i % 2, ch);
         A.act_count = ch.d_cnt + (i - 1);
         A.host_count = ch.h_cnt_dev + (i - 1);
       }
-      A.next_list = d_list_[(i + 1) % 2] + ch.lo;
+      A.next_list = list_of((i + 1) % 2, ch);
       A.next_count = ch.d_cnt + i;
-      const int ninst = std::max(1, ch.known);
+      const int ninst = i == 0 ? std::max(1, ch.known) : bound_of(ch);
+      const bool may_split = splits_in(i);
+      if (!may_split) A.seg_parts = 1;
       // (a batch that fits the CUs from the start -- the MPC case, one or a few dozen instances -- goes to the persistent
       //  kernel at once: its first sweep as three launches and a host round trip would only add latency)
-      if (fused_ok && (i > 0 || (C == 1 && !no_fused_first_)) && (tail_mode || total_known() <= persist_at_)) {
+      if (fused_ok && (i > 0 || (C == 1 && !no_fused_first_)) && (tail_mode || total_known() <= (any_split() ? seg_persist_at : persist_at_))) {
         // the tail: every instance left gets a workgroup that runs whole iterations (k_sweep_fused, launched below
         // for all chains together); this chain's list is the one sweep i would have worked on
         tail_mode = true;
@@ -1631,11 +1722,12 @@ class Engine final : public EngineBase {
       PoisonLds();
       // (small models only: their expansions are HBM-bound; the 12-state model's are compute-bound and pay for the idle
       //  lanes of a dense launch: config 4 +13 %)
-      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)ninst >= span) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
+      if (i > 0 && dense_expansions_ && !kKdgEligible && 4 * (long long)std::max(1, ch.known) >= span) {  // (thresholds 1/2 ... 1/16 measured: 1/4 ... 1/8 best)
         // a good part of the chain is still iterating: lane = instance (coalesced rows and records), and the list is
-        // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions)
-        hipLaunchKernelGGL((k_expansions<T, M>), dim3((span + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 2,
-                           d_list_[i % 2] + ch.lo, ch.d_cnt + (max_sweeps + 12) + i);
+        // rebuilt in runs of neighbouring instances for the two kernels that follow (see k_expansions); the launch also
+        // covers the chain's slice of shadow columns (instance_of_slot)
+        hipLaunchKernelGGL((k_expansions<T, M>), dim3((span + (ch.split_seen ? seg_capc : 0) + kBlock - 1) / kBlock, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 2,
+                           list_of(i % 2, ch), ch.d_cnt + (max_sweeps + 12) + i);
       } else {
         hipLaunchKernelGGL((k_expansions<T, M>), dim3(gridB.x, N_ + 1), dim3(kBlock), 0, ch.st, A, d_pd_, 0, (int*)nullptr,
                            (int*)nullptr);
@@ -1646,6 +1738,8 @@ class Engine final : public EngineBase {
       LaunchForward(A, d, mode, 0, ninst, total_known());
       rec(ch);
       cur_ = stream_;
+      ch.last_split = may_split;
+      ch.split_seen = ch.split_seen || may_split;
       timing_.launches += 3;
       timing_.sweep_launches += 1;
       return ALTRO_OK;
@@ -1743,16 +1837,17 @@ class Engine final : public EngineBase {
             ninst_l += B_;
             continue;
           }
-          lists.list[lists.n] = d_list_[ch.sweeps % 2] + ch.lo;
+          lists.list[lists.n] = list_of(ch.sweeps % 2, ch);
           lists.count[lists.n] = ch.d_cnt + (ch.sweeps - 1);
           lists.n++;
-          ninst_l += std::max(1, ch.known);
+          ninst_l += bound_of(ch);
           if (ch.st != stream_) {  // the engine's stream continues behind this chain's last sweep
             hipEventRecord(chain_ev_[c], ch.st);
             hipStreamWaitEvent(stream_, chain_ev_[c], 0);
           }
         }
-        const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), B_);
+        const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), (long long)B_ + (seg_on ? seg_total_ : 0));
+        if (any_split()) SegArrays(A);
         if (whole_batch) {
           A.act_list = nullptr;
           A.act_count = nullptr;
@@ -1835,6 +1930,19 @@ class Engine final : public EngineBase {
       spec_helper_running_ = false;
     }
     ALTRO_HIP_CHECK(hipGetLastError());
+    if (any_split()) {
+      // chains of segments: the last valid column of each over the instance's own (k_seg_fixup; a workgroup per instance,
+      // all but the split ones leave at once)
+      if constexpr (kMfmaBackward) {
+        DevArrays<T> As = A_;
+        SegArrays(As);
+        hipLaunchKernelGGL((k_seg_fixup<T, M>), dim3(B_), dim3(kBlock), 0, stream_, As, d_pd_);
+        timing_.launches += 1;
+        int cur[kMaxChains] = {0};
+        ALTRO_HIP_CHECK(CopySync(cur, d_seg_cursor_, sizeof(cur), hipMemcpyDeviceToHost));  // (synchronises the stream)
+        for (int c = 0; c < C; ++c) timing_.segment_columns += std::min(cur[c], seg_capc);
+      }
+    }
     int sweeps = 0;  // longest chain of iterations, the look-ahead sweep of a chain that ran dry included
     for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
@@ -1843,6 +1951,12 @@ class Engine final : public EngineBase {
       timing_.twin_handovers = extra[4];
       timing_.twin_claims = extra[5];
       timing_.fused_workgroup_iterations = extra[6];
+      if (seg_on && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {
+        int cur[kMaxChains] = {0};
+        ALTRO_HIP_CHECK(CopySync(cur, d_seg_cursor_, sizeof(cur), hipMemcpyDeviceToHost));
+        fprintf(stderr, "segments: shadow columns used per chain %d %d %d %d (of %d each), persistent launch over <= %d slots, longest own chain %d, longest workgroup %d\n",
+                cur[0], cur[1], cur[2], cur[3], seg_capc, (int)timing_.twin_workgroups, extra[0], extra[6]);
+      }
       if (twin_cap_ > 0 && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {  // the mailboxes after the launch, slot by slot
         std::vector<unsigned long long> box((size_t)twin_cap_ * kTwWords);
         ALTRO_HIP_CHECK(CopySync(box.data(), d_twin_box_, box.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1914,6 +2028,29 @@ class Engine final : public EngineBase {
         hipEventElapsedTime(&ms, prof_ev_[fused_ev], prof_ev_[fused_ev + 1]);
         timing_.fused_ms += ms;
       }
+      if (std::getenv("ALTRO_HIP_SWEEP_LOG")) {
+        // timeline of the chains of sweeps (diagnostics): per sweep its start since the solve began, the length of the list it
+        // worked on (what the sweep before it left) and the durations of its three kernels
+        for (int c = 0; c < C; ++c) {
+          const std::vector<size_t>& ev = chain[c].ev;
+          int idx = 0;
+          for (size_t e0 = 0; e0 + 3 < ev.size(); e0 += 3, ++idx) {
+            float t = 0, e = 0, b = 0, f = 0;
+            hipEventElapsedTime(&t, prof_ev_[0], prof_ev_[ev[e0]]);
+            hipEventElapsedTime(&e, prof_ev_[ev[e0]], prof_ev_[ev[e0 + 1]]);
+            hipEventElapsedTime(&b, prof_ev_[ev[e0 + 1]], prof_ev_[ev[e0 + 2]]);
+            hipEventElapsedTime(&f, prof_ev_[ev[e0 + 2]], prof_ev_[ev[e0 + 3]]);
+            if (idx % 4 == 0 || e0 + 6 >= ev.size())
+              fprintf(stderr, "SWEEPLOG chain %d sweep %3d t %7.3f ms list %5d E %6.1f B %6.1f F %6.1f us\n", c, idx, t,
+                      idx == 0 ? chain[c].hi - chain[c].lo : (int)chain[c].h_cnt[idx - 1], 1e3 * e, 1e3 * b, 1e3 * f);
+          }
+        }
+        if (persistent_launched) {
+          float t = 0;
+          hipEventElapsedTime(&t, prof_ev_[0], prof_ev_[fused_ev]);
+          fprintf(stderr, "SWEEPLOG persistent launch t %7.3f ms, %.3f ms, slots <= %d\n", t, ms, (int)timing_.twin_workgroups);
+        }
+      }
     }
     timing_.instance_iterations = -1;  // summed on demand (GetTiming): keeps a copy out of every solve
     timing_.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1936,6 +2073,17 @@ class Engine final : public EngineBase {
   ProblemDesc* d_pd_ = nullptr;
   DevArrays<T> A_{};
   double* d_tmp_ = nullptr;
+  struct SegPtrs {
+    int *end = nullptr, *next = nullptr, *flag = nullptr, *streak = nullptr, *tot0 = nullptr;
+    double *rho0 = nullptr, *drho0 = nullptr;
+  } seg_;
+  void SegArrays(DevArrays<T>& A) const {  // the bookkeeping arrays of the segments into a launch's copy of A_
+    A.seg_end = seg_.end; A.seg_next = seg_.next; A.seg_flag = seg_.flag; A.seg_streak = seg_.streak;
+    A.seg_tot0 = seg_.tot0; A.seg_rho0 = seg_.rho0; A.seg_drho0 = seg_.drho0;
+  }
+  int seg_total_ = 0, seg_col0_ = 0, seg_parts_ = 4;  // shadow columns of the batched sweeps' segments (DevArrays::seg_*)
+  int* d_seg_cursor_ = nullptr;                       // next free column of each chain's slice
+  int seg_below_pct_ = std::getenv("ALTRO_HIP_SEG_BELOW") ? atoi(std::getenv("ALTRO_HIP_SEG_BELOW")) : 65;  // split only below this share of the batch
   int twin_cap_ = 0;                          // shadow columns behind the batch (twin workgroups of the persistent kernel)
   int twin_lag_ = std::getenv("ALTRO_HIP_TWIN_LAG") ? atoi(std::getenv("ALTRO_HIP_TWIN_LAG")) : kTwinLag;
   unsigned long long* d_twin_box_ = nullptr;  // their mailboxes, [twin_cap_][kTwWords]

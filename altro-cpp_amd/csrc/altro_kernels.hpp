@@ -82,8 +82,14 @@ __device__ __forceinline__ void stamp_add(long long* acc, int slot, long long t0
 template <class T>
 ALTRO_DEV int instance_of_slot(const DevArrays<T>& A, int idx, int all) {
   if (all == 2) {
-    const int b = idx + A.chain_lo, hi = A.chain_hi ? A.chain_hi : A.B;
-    return (b < hi && A.phase[b] == 1) ? b : -1;
+    const int hi = A.chain_hi ? A.chain_hi : A.B;
+    int b = idx + A.chain_lo;
+    if (b >= hi) {  // behind the chain's own instances: its slice of shadow columns (segments of rejection streaks)
+      if (!A.seg_end) return -1;
+      b = A.seg_lo + (b - hi);
+      if (b >= A.seg_hi) return -1;
+    }
+    return A.phase[b] == 1 ? b : -1;
   }
   if (all) return idx < A.B ? idx : -1;
   const int cnt = A.act_count ? *A.act_count : A.act_count_const;
@@ -1459,6 +1465,12 @@ __global__ __launch_bounds__(kBlock) void k_solve_setup(DevArrays<T> A, DevOpts 
   if (b >= A.B) return;
   begin_inner_solve(A, o, b);
   if (activate) A.phase[b] = 1;
+  if (A.seg_end) {  // no segment bookkeeping survives a solve
+    A.seg_end[b] = kSegNoEnd;
+    A.seg_next[b] = -1;
+    A.seg_flag[b] = 0;
+    A.seg_streak[b] = 0;
+  }
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_set_rows(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
@@ -1683,6 +1695,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     }
   }
   int inner_done = 0;
+  double rho_next = 0.0, drho_next = 0.0;  // (lane 0) the regularisation entering the next iteration
   if (t == 0) {
     double cost_cur = pre.cost_cur;
     {
@@ -1692,6 +1705,8 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
       if (!accepted) increase_reg(o, &rho, &drho);  // ilqr.hpp:550
       A.rho_reg[b] = rho;
       A.drho[b] = drho;
+      rho_next = rho;
+      drho_next = drho;
       if (ff) {  // what the stall detector of the persistent kernel compares between iterations
         ff[0] = accepted ? 0.0 : 1.0;
         ff[1] = rho;
@@ -1718,6 +1733,133 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   }
   if (mode == kFwdStepOnly) return;
   inner_done = __shfl(inner_done, grp * LS);
+  // ---- segments of a rejection streak (DevArrays::seg_*): verify / retire, cancel, split ----
+  if (A.seg_end) {
+    int drop = 0, nclones = 0, first = 0, seg_len = 0;
+    if (t == 0) {
+      const bool rc = !accepted && !inner_done;  // every trial rejected, and the inner solve goes on
+      const int streak = rc ? A.seg_streak[b] + 1 : 0;
+      A.seg_streak[b] = streak;
+      const int it_next = pre.it_inner + 1, tot_next = pre.it_total + 1;
+      const int flag = A.seg_flag[b];
+      const int nxt = A.seg_next[b];
+      if (flag & kSegCancelled) {
+        drop = 1;  // a predecessor did not arrive where this column assumed it would: its work is void
+      } else if (nxt >= 0) {
+        bool cancel = !rc;
+        if (rc && it_next == A.seg_end[b]) {
+          // the end of this column's segment: does it hold, bit for bit, what the next column assumed when it started?
+          const bool same = A.seg_tot0[nxt] == tot_next && __double_as_longlong(A.seg_rho0[nxt]) == __double_as_longlong(rho_next) &&
+                            __double_as_longlong(A.seg_drho0[nxt]) == __double_as_longlong(drho_next) &&
+                            (__hip_atomic_load(A.seg_flag + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSegCancelled) == 0;
+          if (same) {
+            A.seg_flag[b] = flag | kSegRetired;  // (the next column owns the instance from here: k_seg_fixup follows the chain)
+            drop = 1;
+          } else {
+            cancel = true;
+          }
+        }
+        if (cancel) {  // an accepted step, an end of the inner solve, a regularisation off the rule: the successors are void
+          int sgd = nxt;
+          for (int guard = 0; sgd >= 0 && guard < 256; ++guard) {
+            atomicOr(A.seg_flag + sgd, kSegCancelled);
+            sgd = A.seg_next[sgd];
+          }
+          A.seg_next[b] = -1;
+          A.seg_end[b] = kSegNoEnd;
+        }
+      } else if (rc && streak >= 2 && !active_out && A.next_count && A.seg_parts > 1) {
+        // ---- split: what is left of this inner solve (ilqr.hpp:600-611 caps it) in seg_parts segments ----
+        const int r1 = o.max_iterations_inner - it_next, r2 = o.max_iterations_total - tot_next;
+        const int Rl = r1 < r2 ? r1 : r2;
+        if (Rl >= kSegMinRemaining) {
+          const int want = A.seg_parts - 1;
+          const int base = atomicAdd(A.seg_cursor, want);
+          if (base + want <= A.seg_hi - A.seg_lo) {
+            nclones = want;
+            first = A.seg_lo + base;
+            seg_len = (Rl + want) / (want + 1);
+            A.seg_end[b] = it_next + seg_len;
+            A.seg_next[b] = first;
+            double r = rho_next, d = drho_next;
+            for (int j = 1; j <= want; ++j) {
+              // the regularisation entering the segment: every iteration before it runs its backward pass
+              // (DecreaseRegularization, ilqr.hpp:440) and rejects its line search (IncreaseRegularization, :550)
+              for (int q = 0; q < seg_len; ++q) {
+                decrease_reg(o, &r, &d);
+                increase_reg(o, &r, &d);
+              }
+              const int col = first + j - 1;
+              A.seg_rho0[col] = r;
+              A.seg_drho0[col] = d;
+              A.seg_tot0[col] = tot_next + j * seg_len;
+              A.seg_next[col] = j < want ? col + 1 : -1;
+              A.seg_end[col] = j < want ? it_next + (j + 1) * seg_len : kSegNoEnd;
+              A.seg_flag[col] = 0;
+              A.seg_streak[col] = streak;
+              // per-instance solver state of the clone: this column's, with counters and regularisation advanced; the
+              // previous cost is the (unchanged) current one, as every iteration of a streak leaves it
+              A.rho_reg[col] = r;
+              A.drho[col] = d;
+              A.it_inner[col] = it_next + j * seg_len;
+              A.it_total[col] = tot_next + j * seg_len;
+              const double cc = accepted ? J_sel : pre.cost_cur;
+              A.cost_cur[col] = cc;
+              A.cost_prev[col] = cc;
+              A.initial_cost[col] = pre.initial_cost;
+              A.dV0[col] = 0.0; A.dV1[col] = 0.0; A.J0[col] = 0.0;
+              A.dJ[col] = A.dJ[b]; A.grad[col] = A.grad[b]; A.viol[col] = A.viol[b]; A.penmax[col] = A.penmax[b];
+              A.alpha[col] = A.alpha[b]; A.z[col] = A.z[b]; A.reg_log[col] = A.reg_log[b];
+              A.status[col] = ALTRO_UNSOLVED;
+              A.status_al[col] = A.status_al[b];
+              A.it_outer[col] = A.it_outer[b];
+              A.need_init_cost[col] = 0;
+              A.phase[col] = 1;
+            }
+            const int at = atomicAdd(A.next_count, want);  // the clones iterate from the next sweep on
+            for (int j = 0; j < want; ++j) A.next_list[at + j] = first + j;
+          } else {
+            atomicSub(A.seg_cursor, want);  // (no columns left in this chain's slice)
+          }
+        }
+      }
+    }
+    drop = __shfl(drop, grp * LS);
+    nclones = __shfl(nclones, grp * LS);
+    first = __shfl(first, grp * LS);
+    if (nclones > 0) {
+      // the clones' share of the instance: trajectory, multipliers, penalties, parameters -- nothing a rejected iteration
+      // changes (the stored constraint values, knot costs, records and gains are recomputed before they are read)
+      using R_ = Rec<T, M::n, M::m>;
+      for (int j = 0; j < nclones; ++j) {
+        const unsigned col = (unsigned)(first + j);
+        for (int i = t; i < (N + 1) * R_::nP; i += LS) {
+          const int k = i / R_::nP, e = i - k * R_::nP;
+          A.X[((size_t)(unsigned)k * Bp + col) * R_::nP + e] = A.X[((size_t)(unsigned)k * Bp + (unsigned)b) * R_::nP + e];
+        }
+        for (int i = t; i < N * R_::mP; i += LS) {
+          const int k = i / R_::mP, e = i - k * R_::mP;
+          A.U[((size_t)(unsigned)k * Bp + col) * R_::mP + e] = A.U[((size_t)(unsigned)k * Bp + (unsigned)b) * R_::mP + e];
+        }
+        if (t < R_::nP) A.x0[(size_t)col * R_::nP + t] = A.x0[(size_t)(unsigned)b * R_::nP + t];
+        for (int r = t; r < pd->total_rows; r += LS) {
+          A.lam[(unsigned)r * Bp + col] = A.lam[(unsigned)r * Bp + (unsigned)b];
+          A.pen[(unsigned)r * Bp + col] = A.pen[(unsigned)r * Bp + (unsigned)b];
+          A.cval[(unsigned)r * Bp + col] = A.cval[(unsigned)r * Bp + (unsigned)b];
+        }
+        T* const ip = const_cast<T*>(A.ipool);
+        for (int r = t; r < pd->nslots; r += LS) ip[(unsigned)r * Bp + col] = ip[(unsigned)r * Bp + (unsigned)b];
+      }
+    }
+    if (drop) {  // retired or cancelled: this column leaves the solve here
+      if (t == 0) {
+        if (ff) ff[3] = 1.0;
+        if (active_out) *active_out = 0;
+        A.phase[b] = 0;
+      }
+      return;
+    }
+  }
   bool active = true;
   if (inner_done) {
     if (mode == kFwdAL) {
@@ -3786,6 +3928,12 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         A.status[bT] = i0; A.status_al[bT] = i1; A.it_outer[bT] = i2; A.phase[bT] = i3; A.need_init_cost[bT] = i4;
         // ... but for what the rejected iterations up to `start` will have changed: counters, regularisation, and the
         // previous cost, which every iteration of a streak sets to the (unchanged) current one (solver_stats.cpp:54-66)
+        if (A.seg_end) {
+          A.seg_end[bT] = kSegNoEnd;
+          A.seg_next[bT] = -1;
+          A.seg_flag[bT] = 0;
+          A.seg_streak[bT] = 2;
+        }
         A.cost_prev[bT] = c4;
         A.it_inner[bT] = (int)ff[8];
         A.it_total[bT] = (int)ff[9];
@@ -3981,7 +4129,8 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
           if (!tw_closed && (tw_streak >= 2 || tw_ver != 0)) {
             const int it_in = (int)ff[6], it_tot = (int)ff[7];  // the counters entering the next iteration
             if (tw_claim == 0) {
-              if (rc && tw_streak >= 2) {
+              // (a column whose streak the batched sweeps have split into segments ends at its segment's end: no twin)
+              if (rc && tw_streak >= 2 && (!A.seg_end || A.seg_next[b] < 0)) {
                 ++tw_ver;
                 unsigned long long* buf = box + kTwSnap + 4 * (tw_ver & 1);
                 tw_store(buf, ((unsigned long long)(unsigned)it_in << 32) | (unsigned long long)(unsigned)it_tot);
@@ -4210,6 +4359,60 @@ __global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts 
     }
     __threadfence();
     if (lane == 0) __hip_atomic_store(rs.done + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The last valid column of every chain of segments (DevArrays::seg_*) over the instance's own: one workgroup per instance,
+// follows seg_next while the column it stands on has retired (= its successor started from exactly the state it arrived
+// with), then copies that column's trajectory, multipliers, constraint values, records and solver state.
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_seg_fixup(DevArrays<T> A, const ProblemDesc* __restrict__ pd) {
+  using R = Rec<T, M::n, M::m>;
+  using RS = rec_scalar_t<T, M>;
+  using RR = Rec<RS, M::n, M::m>;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= A.B) return;
+  int cur = b;
+  for (int guard = 0; guard < 4096; ++guard) {
+    const int nx = A.seg_next[cur];
+    if (!(A.seg_flag[cur] & kSegRetired) || nx < 0 || (A.seg_flag[nx] & kSegCancelled)) break;
+    cur = nx;
+  }
+  if (cur == b) return;
+  const unsigned Bp = A.Bp, src = (unsigned)cur, dst = (unsigned)b;
+  const int N = A.N;
+  for (int i = tid; i < (N + 1) * R::nP; i += kBlock) {
+    const int k = i / R::nP, e = i - k * R::nP;
+    A.X[((size_t)(unsigned)k * Bp + dst) * R::nP + e] = A.X[((size_t)(unsigned)k * Bp + src) * R::nP + e];
+  }
+  for (int i = tid; i < N * R::mP; i += kBlock) {
+    const int k = i / R::mP, e = i - k * R::mP;
+    A.U[((size_t)(unsigned)k * Bp + dst) * R::mP + e] = A.U[((size_t)(unsigned)k * Bp + src) * R::mP + e];
+  }
+  RS* const E = (RS*)A.EXP;
+  for (int i = tid; i < (N + 1) * RR::EP; i += kBlock) {
+    const int k = i / RR::EP, e = i - k * RR::EP;
+    E[((size_t)(unsigned)k * Bp + dst) * RR::EP + e] = E[((size_t)(unsigned)k * Bp + src) * RR::EP + e];
+  }
+  RS* const G = (RS*)A.KD;
+  for (int i = tid; i < N * RR::KP; i += kBlock) {
+    const int k = i / RR::KP, e = i - k * RR::KP;
+    G[((size_t)(unsigned)k * Bp + dst) * RR::KP + e] = G[((size_t)(unsigned)k * Bp + src) * RR::KP + e];
+  }
+  for (int r = tid; r <= N; r += kBlock) A.costs[(unsigned)r * Bp + dst] = A.costs[(unsigned)r * Bp + src];
+  for (int r = tid; r < pd->total_rows; r += kBlock) {
+    A.lam[(unsigned)r * Bp + dst] = A.lam[(unsigned)r * Bp + src];
+    A.pen[(unsigned)r * Bp + dst] = A.pen[(unsigned)r * Bp + src];
+    A.cval[(unsigned)r * Bp + dst] = A.cval[(unsigned)r * Bp + src];
+  }
+  if (tid == 0) {
+    A.rho_reg[dst] = A.rho_reg[src]; A.drho[dst] = A.drho[src]; A.dV0[dst] = A.dV0[src]; A.dV1[dst] = A.dV1[src]; A.J0[dst] = A.J0[src];
+    A.initial_cost[dst] = A.initial_cost[src]; A.cost_cur[dst] = A.cost_cur[src]; A.cost_prev[dst] = A.cost_prev[src];
+    A.dJ[dst] = A.dJ[src]; A.grad[dst] = A.grad[src]; A.viol[dst] = A.viol[src]; A.penmax[dst] = A.penmax[src];
+    A.alpha[dst] = A.alpha[src]; A.z[dst] = A.z[src]; A.reg_log[dst] = A.reg_log[src];
+    A.status[dst] = A.status[src]; A.status_al[dst] = A.status_al[src]; A.it_inner[dst] = A.it_inner[src];
+    A.it_outer[dst] = A.it_outer[src]; A.it_total[dst] = A.it_total[src]; A.phase[dst] = A.phase[src];
+    A.need_init_cost[dst] = A.need_init_cost[src];
   }
 }
 

@@ -164,6 +164,8 @@ def dominant_kernel_roofline(cfg, tm, config_index):
         # twin workgroups of the persistent launch: launched / claimed a streak's second half / confirmed
         "twin_workgroups": tm.get("twin_workgroups", 0), "twin_claims": tm.get("twin_claims", 0),
         "twin_handovers": tm.get("twin_handovers", 0),
+        # segments of rejection streaks in the batched sweeps: shadow columns used by this solve
+        "segment_columns": tm.get("segment_columns", 0),
         # the OTHER roof: how close the kernel's fp64 vector work comes to the fp64 VALU peak (PMC pass in profiles/)
         "compute": compute_side(key, config_index, 1e3 * avg_launch_ms),
     }
@@ -465,6 +467,7 @@ def measure_other_config(A, P, S, torch, ci, steps, warmup, device_id):
         "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"],
         "all_kernels_frac": rl["all_kernels_frac"], "kernel_wall_ms": rl["kernel_wall_ms"],
         "concurrent_chains": rl["concurrent_chains"], "sweeps": tm["sweeps"], "tail_iterations": tm["fused_sweeps"],
+        "segment_columns": rl["segment_columns"],
     }
 
 

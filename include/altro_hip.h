@@ -171,7 +171,8 @@ typedef struct altro_timing {
   int twin_handovers;      /* ... claims the primary confirmed: instances finished by their twin              */
   int fused_workgroup_iterations; /* most iterations ONE workgroup of the persistent launch ran (a twin or its    */
                            /* primary: their share of the instance's iterations)                               */
-  int reserved;
+  int segment_columns;     /* shadow columns the batched sweeps used for segments of rejection streaks (a streak   */
+                           /* split in four: three columns; 0: none split, ALTRO_HIP_SEGMENTS=0)                   */
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

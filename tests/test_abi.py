@@ -55,7 +55,7 @@ def test_struct_layouts_match_the_header(A):
                                                 "fused_ms", "sweeps", "fused_sweeps", "launches", "sweep_launches",
                                                 "instance_iterations",
                                                 "fused_instance_iterations", "host_naps", "twin_workgroups", "twin_claims",
-                                                "twin_handovers", "fused_workgroup_iterations", "reserved"]
+                                                "twin_handovers", "fused_workgroup_iterations", "segment_columns"]
 
 
 def test_default_options_are_the_reference_defaults(A):

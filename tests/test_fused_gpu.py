@@ -244,3 +244,75 @@ def test_twin_workgroups_are_bit_identical(tmp_path):
     assert a["turn90_2304_ms"][0] < 0.8 * b["turn90_2304_ms"][0], (a["turn90_2304_ms"], b["turn90_2304_ms"])
     assert a["turn90_2304_iters"][0] == b["turn90_2304_iters"][0]       # sum of iterations_total
     assert a["turn90_2304_iters"][1] >= b["turn90_2304_iters"][1]       # units executed by the persistent launch (refused twins add theirs)
+
+
+_SCRIPT_SEG = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+cases = (("obstacles_4096_r32", lambda: P.batch_three_obstacles(make, batch=4096, dtype=A.F32), "al"),   # BASELINE configs[3]: a quarter of the batch ends in 100-iteration streaks
+         ("obstacles_2048_f64", lambda: P.batch_three_obstacles(make, batch=2048, dtype=A.F64), "al"),   # fp64 records, two chains of sweeps
+         ("obstacles_1024_ilqr", lambda: P.batch_three_obstacles(make, batch=1024, dtype=A.F64), "ilqr"),  # one chain, plain iLQR on the penalised cost
+         ("turn90_4096", lambda: P.batch_turn90(make, batch=4096, seed=P.SEED_BASE + 3), "al"))          # BASELINE configs[2]: its sweeps are over before anything splits
+for name, fac, mode in cases:
+    s = fac()
+    ms = []
+    for rep in range(3):   # (later solves reuse the shadow columns)
+        s.reset_trajectory()
+        if mode == "ilqr":
+            s.rollout(); s.solve_ilqr()
+        else:
+            s.solve()
+        ms.append(s.get_timing()["total_ms"])
+    X, U = s.get_trajectory()
+    st = s.get_stats()
+    tm = s.get_timing()
+    out[name + "_X"] = X; out[name + "_U"] = U
+    K, d = s.get_gains()
+    out[name + "_K"] = K; out[name + "_d"] = d
+    out[name + "_lam"] = s.get_duals(); out[name + "_pen"] = s.get_penalties(); out[name + "_c"] = s.get_constraint_values()
+    for f in st.dtype.names:
+        out[name + "_st_" + f] = st[f]
+    for k in (0, 50, 100):
+        e = s.get_expansion(k)
+        for key, v in e.items():
+            if k < 100 or key in ("lxx", "lx"):   # (the terminal knot has no dynamics and no control blocks)
+                out[name + "_exp%%d_%%s" %% (k, key)] = v
+    out[name + "_costs"] = s.get_knot_costs()
+    out[name + "_segcols"] = np.array([tm["segment_columns"]]); out[name + "_ms"] = np.array([min(ms[1:])])
+    out[name + "_iters"] = np.array([tm["instance_iterations"], tm["sweep_launches"], tm["sweeps"]])
+    s.close()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
+    """Segments of rejection streaks in the batched sweeps (DevArrays::seg_*, forward_phase3): what is left of a
+    100-iteration streak is split into four segments that run side by side in shadow columns; each column that reaches its
+    segment's end compares its state, bit for bit, with what the next one assumed, and k_seg_fixup copies the last valid
+    column back.  Every iteration is executed with the inputs the sequential order gives it, so NOTHING may differ from a
+    solve without segments (ALTRO_HIP_SEGMENTS=0) -- while the chains of sweeps of BASELINE configs[3] get shorter."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env_extra in (("seg", {}), ("plain", {"ALTRO_HIP_SEGMENTS": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_SEG % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
+        res[tag] = np.load(out)
+    a, b = res["seg"], res["plain"]
+    for name in ("obstacles_4096_r32", "obstacles_2048_f64", "obstacles_1024_ilqr", "turn90_4096"):
+        print(name, "ms with / without segments", a[name + "_ms"][0], b[name + "_ms"][0], "shadow columns", a[name + "_segcols"][0],
+              "(iterations, sweep launches, sweeps)", a[name + "_iters"], b[name + "_iters"])
+        assert b[name + "_segcols"][0] == 0
+    for k in a.files:
+        if k.endswith(("_segcols", "_ms", "_iters")):
+            continue
+        assert np.array_equal(a[k], b[k]), (k, np.abs(np.asarray(a[k], float) - np.asarray(b[k], float)).max())
+    # the streaks of configs[3] really were split, every iteration was executed, and the chains of sweeps got shorter
+    assert a["obstacles_4096_r32_segcols"][0] > 1000
+    assert a["obstacles_4096_r32_iters"][0] == b["obstacles_4096_r32_iters"][0]
+    assert a["obstacles_4096_r32_iters"][1] < 0.75 * b["obstacles_4096_r32_iters"][1]
+    assert a["obstacles_4096_r32_ms"][0] < 0.97 * b["obstacles_4096_r32_ms"][0], (a["obstacles_4096_r32_ms"], b["obstacles_4096_r32_ms"])
