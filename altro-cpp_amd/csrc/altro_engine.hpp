@@ -1525,6 +1525,27 @@ class Engine final : public EngineBase {
 #undef ALTRO_ALLOC
   }
 
+  // ALTRO_HIP_DEBUG_POISON: shadow columns (segments of the batched sweeps, twins of the persistent kernel) start every
+  // solve full of NaN words (k_poison_columns)
+  void PoisonShadowColumns() {
+    if (!poison_on_ || seg_total_ + twin_cap_ <= 0) return;
+    const unsigned col0 = (unsigned)(Bp_ - seg_total_ - twin_cap_), ncols = (unsigned)(seg_total_ + twin_cap_);
+    auto fill = [&](void* arr, size_t rows, size_t bytes_per_column_row) {
+      if (!arr || rows == 0) return;
+      hipLaunchKernelGGL((k_poison_columns<0>), dim3(1024), dim3(256), 0, stream_, (unsigned*)arr, (unsigned)rows, (unsigned)Bp_, col0, ncols,
+                         (unsigned)(bytes_per_column_row / 4), poison_pattern_, poison_mix_);
+    };
+    fill(A_.X, N_ + 1, R::nP * sizeof(T));
+    fill(A_.U, N_, R::mP * sizeof(T));
+    fill(A_.x0, 1, R::nP * sizeof(T));
+    fill(A_.costs, N_ + 1, sizeof(T));
+    fill(A_.lam, pd_.total_rows, sizeof(T));
+    fill(A_.pen, pd_.total_rows, sizeof(T));
+    fill(A_.cval, pd_.total_rows, sizeof(T));
+    fill((void*)A_.EXP, N_ + 1, RR::EP * sizeof(RS));
+    fill((void*)A_.KD, N_, RR::KP * sizeof(RS));
+  }
+
   // ---- the sweep loop -----------------------------------------------------------------------------
   hipEvent_t ProfEvent(size_t i) {
     while (prof_ev_.size() <= i) {
@@ -1568,6 +1589,7 @@ class Engine final : public EngineBase {
     std::memset(&timing_, 0, sizeof(timing_));
     size_t nev = 0;
     cur_ = stream_;
+    PoisonShadowColumns();
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
     {
@@ -1669,7 +1691,7 @@ class Engine final : public EngineBase {
     // instead of one (config 3: 32.2 - 32.6 ms with this bound, 33 - 35 ms with 1.5 x).  Once a chain has split, the
     // hand-over itself moves to 1.5 x persist_at_: what is left when the segments retire are the long runners, whose
     // iterations the persistent kernel runs at a fifth of a batched sweep's latency.
-    const int seg_above = std::getenv("ALTRO_HIP_SEG_ABOVE") ? atoi(std::getenv("ALTRO_HIP_SEG_ABOVE")) : 3 * persist_at_;
+    const int seg_above = std::getenv("ALTRO_HIP_SEG_ABOVE") ? atoi(std::getenv("ALTRO_HIP_SEG_ABOVE")) : std::min(3 * persist_at_, B_ * 3 / 8);  // (a batch of 2048 keeps a window below its 65 %)
     const int seg_persist_at = std::getenv("ALTRO_HIP_SEG_PERSIST_AT") ? atoi(std::getenv("ALTRO_HIP_SEG_PERSIST_AT")) : persist_at_ * 3 / 2;
     const int seg_every = std::getenv("ALTRO_HIP_SEG_EVERY") ? std::max(1, atoi(std::getenv("ALTRO_HIP_SEG_EVERY"))) : kSegSplitEvery;
     auto splits_in = [&](int i) {

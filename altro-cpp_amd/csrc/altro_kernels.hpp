@@ -48,6 +48,18 @@ constexpr int kEAheadToErrWord = -7;      // kSyErr - kSyEAhead0 (FwdSyncWord, a
 constexpr int kFwdSpinLimit = 1 << 22;   // polls of an LDS sequence word (~0.1 us each) before a wave gives up
 // Debugging aid (ALTRO_HIP_DEBUG_POISON): fills the LDS of the CU it lands on with a pattern, so that a kernel that reads
 // LDS it has not written computes with the pattern instead of with whatever the previous kernel happened to leave there.
+// ALTRO_HIP_DEBUG_POISON: the shadow columns [col0, col0 + ncols) of one per-instance array ([rows][Bp][words] 32-bit words)
+// filled with the poison pattern before a solve -- a clone that forgot to copy something computes with NaN words instead
+// of with what an earlier solve left in the column.
+template <int kDummy>
+__global__ __launch_bounds__(256) void k_poison_columns(unsigned* arr, unsigned rows, unsigned Bp, unsigned col0, unsigned ncols,
+                                                         unsigned words, unsigned pattern, int mix) {
+  const size_t per_row = (size_t)ncols * words, total = (size_t)rows * per_row;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / per_row, w = i - r * per_row;
+    arr[(r * Bp + col0) * words + w] = mix ? (pattern ^ ((unsigned)i * 2654435761u)) : pattern;
+  }
+}
 template <int kDummy>
 __global__ __launch_bounds__(256) void k_poison_lds(unsigned pattern, int words, int mix, int* sink) {
   extern __shared__ unsigned poison_smem[];

@@ -228,11 +228,15 @@ def test_twin_workgroups_are_bit_identical(tmp_path):
     with fp32 records."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env_extra in (("twin", {}), ("solo", {"ALTRO_HIP_TWIN": "0"})):
+    # (third run: with the shadow columns, LDS and the candidate buffer full of NaN words before every solve)
+    for tag, env_extra in (("twin", {}), ("solo", {"ALTRO_HIP_TWIN": "0"}), ("twin_poisoned", {"ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"})):
         out = str(tmp_path / f"{tag}.npz")
         subprocess.run([sys.executable, "-c", _SCRIPT_TWIN % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
         res[tag] = np.load(out)
     a, b = res["twin"], res["solo"]
+    for k in a.files:
+        if not k.endswith(("_twins", "_ms", "_iters")):
+            assert np.array_equal(res["twin_poisoned"][k], b[k]), ("poisoned", k)
     for name in ("turn90_512", "turn90_2304", "obstacles_192", "obstacles_r32"):
         assert a[name + "_twins"][0] > 0 and b[name + "_twins"][0] == 0, name
         print(name, "ms with / without twins", a[name + "_ms"][0], b[name + "_ms"][0], "iterations", a[name + "_iters"], b[name + "_iters"])
@@ -298,11 +302,17 @@ def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
     solve without segments (ALTRO_HIP_SEGMENTS=0) -- while the chains of sweeps of BASELINE configs[3] get shorter."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env_extra in (("seg", {}), ("plain", {"ALTRO_HIP_SEGMENTS": "0"})):
+    # (third run: LDS, the candidate buffer and -- before every solve -- the shadow columns of every per-instance array full
+    #  of NaN words: a clone that forgot to copy something, or a column read before it is rewritten, shows)
+    for tag, env_extra in (("seg", {}), ("plain", {"ALTRO_HIP_SEGMENTS": "0"}), ("seg_poisoned", {"ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"})):
         out = str(tmp_path / f"{tag}.npz")
         subprocess.run([sys.executable, "-c", _SCRIPT_SEG % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
         res[tag] = np.load(out)
     a, b = res["seg"], res["plain"]
+    for k in a.files:
+        if not k.endswith(("_segcols", "_ms", "_iters")):
+            assert np.array_equal(res["seg_poisoned"][k], b[k]), ("poisoned", k)
+    assert res["seg_poisoned"]["obstacles_4096_r32_segcols"][0] > 1000
     for name in ("obstacles_4096_r32", "obstacles_2048_f64", "obstacles_1024_ilqr", "turn90_4096"):
         print(name, "ms with / without segments", a[name + "_ms"][0], b[name + "_ms"][0], "shadow columns", a[name + "_segcols"][0],
               "(iterations, sweep launches, sweeps)", a[name + "_iters"], b[name + "_iters"])
