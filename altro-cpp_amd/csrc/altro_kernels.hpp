@@ -3538,8 +3538,21 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   ALTRO_STAMP_ADD(6, st_w1d);
 }
 
+// Waves per SIMD the kernel is compiled for (second argument of HIP's __launch_bounds__).  EXPERIMENT SWITCH, default 1 = the
+// compiler's own choice: the variant of the small models that reads its inputs from global memory exists for occupancy, and
+// with fp64 records in flight it lands on 171 VGPRs -- three above the step to three waves per SIMD.  Built with
+// -DALTRO_FWD_GLB_WAVES=3 it has 168 VGPRs + 20 B of scratch, the engine then picks it for config 2 (nine instances per CU
+// instead of six) -- and config 2 runs 6.27 - 6.33 ms against 6.31 - 6.38 ms: the forward pass of the full batch is not
+// bound by its occupancy (profiles/r05_experiments.txt #5).
+#ifndef ALTRO_FWD_GLB_WAVES
+#define ALTRO_FWD_GLB_WAVES 1
+#endif
+template <class M, int SRC>
+constexpr int fwd_min_waves() {
+  return (SRC == kSrcGlb && M::n <= 4) ? ALTRO_FWD_GLB_WAVES : 1;
+}
 template <class T, class M, int SRC>
-__global__ __launch_bounds__(kFwdWaves * kBlock) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+__global__ __launch_bounds__(kFwdWaves * kBlock, (fwd_min_waves<M, SRC>())) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                          const ProblemDesc pd_arg, DevOpts o, int mode, int all,
                                                          int per_wave) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
