@@ -2062,7 +2062,7 @@ class Engine final : public EngineBase {
             hipEventElapsedTime(&e, prof_ev_[ev[e0]], prof_ev_[ev[e0 + 1]]);
             hipEventElapsedTime(&b, prof_ev_[ev[e0 + 1]], prof_ev_[ev[e0 + 2]]);
             hipEventElapsedTime(&f, prof_ev_[ev[e0 + 2]], prof_ev_[ev[e0 + 3]]);
-            if (idx % 4 == 0 || e0 + 6 >= ev.size())
+            if (idx % 4 == 0 || e0 + 6 >= ev.size() || std::string(std::getenv("ALTRO_HIP_SWEEP_LOG")) == "all")
               fprintf(stderr, "SWEEPLOG chain %d sweep %3d t %7.3f ms list %5d E %6.1f B %6.1f F %6.1f us\n", c, idx, t,
                       idx == 0 ? chain[c].hi - chain[c].lo : (int)chain[c].h_cnt[idx - 1], 1e3 * e, 1e3 * b, 1e3 * f);
           }
