@@ -1592,6 +1592,10 @@ class Engine final : public EngineBase {
     PoisonShadowColumns();
     if (prof) hipEventRecord(ProfEvent(nev++), stream_);
     if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+    // (no shadow column starts a solve as an active instance, whatever the last solve left in it: the dense expansion
+    //  launches rebuild their lists from these flags)
+    if (seg_total_ + twin_cap_ > 0)
+      ALTRO_HIP_CHECK(hipMemsetAsync(A_.phase + (Bp_ - seg_total_ - twin_cap_), 0, (size_t)(seg_total_ + twin_cap_) * sizeof(int), stream_));
     {
       DevArrays<T> As = A_;
       if (seg_total_ > 0) SegArrays(As);  // (resets the bookkeeping of the segments, DevArrays::seg_*)

@@ -262,16 +262,38 @@ cases = (("obstacles_4096_r32", lambda: P.batch_three_obstacles(make, batch=4096
          ("obstacles_2048_f64", lambda: P.batch_three_obstacles(make, batch=2048, dtype=A.F64), "al"),   # fp64 records, two chains of sweeps
          ("obstacles_1024_ilqr", lambda: P.batch_three_obstacles(make, batch=1024, dtype=A.F64), "ilqr"),  # one chain, plain iLQR on the penalised cost
          ("turn90_4096", lambda: P.batch_turn90(make, batch=4096, seed=P.SEED_BASE + 3), "al"))          # BASELINE configs[2]: its sweeps are over before anything splits
+cases = cases + (
+    # iteration caps that cut the streaks short (the remainder of a streak is min(inner, total) iterations, ilqr.hpp:600-611)
+    ("obstacles_4096_caps", lambda: P.batch_three_obstacles(make, batch=4096, dtype=A.F32), "caps"),
+    # MPC pattern behind a solve that split (al_solver.hpp:292-297): warm start, duals and penalties kept, the initial
+    # state moved -- the shadow columns of the first solve are still in the arrays
+    ("obstacles_4096_warm", lambda: P.batch_three_obstacles(make, batch=4096, dtype=A.F32), "warm"),
+    # two handles in flight on one device (altro_solve_al_async), both splitting
+    ("obstacles_4096_pair", lambda: P.batch_three_obstacles(make, batch=4096, dtype=A.F32), "pair"))
 for name, fac, mode in cases:
     s = fac()
     ms = []
+    if mode == "caps":
+        s.set_options(max_iterations_inner=70, max_iterations_total=130)
+    other = fac() if mode == "pair" else None
     for rep in range(3):   # (later solves reuse the shadow columns)
         s.reset_trajectory()
         if mode == "ilqr":
             s.rollout(); s.solve_ilqr()
+        elif mode == "pair":
+            other.reset_trajectory()
+            s.solve_async(); other.solve_async(); s.wait(); other.wait()
+            assert np.array_equal(s.get_trajectory()[0], other.get_trajectory()[0])
         else:
             s.solve()
         ms.append(s.get_timing()["total_ms"])
+    if mode == "warm":
+        X0 = s.get_trajectory()[0][:, 0, :].copy()
+        s.set_options(reset_duals=0, initial_penalty=0.0)
+        s.set_initial_state(X0 + 1e-3)
+        s.solve()
+    if other is not None:
+        other.close()
     X, U = s.get_trajectory()
     st = s.get_stats()
     tm = s.get_timing()
@@ -313,7 +335,8 @@ def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
         if not k.endswith(("_segcols", "_ms", "_iters")):
             assert np.array_equal(res["seg_poisoned"][k], b[k]), ("poisoned", k)
     assert res["seg_poisoned"]["obstacles_4096_r32_segcols"][0] > 1000
-    for name in ("obstacles_4096_r32", "obstacles_2048_f64", "obstacles_1024_ilqr", "turn90_4096"):
+    for name in ("obstacles_4096_r32", "obstacles_2048_f64", "obstacles_1024_ilqr", "turn90_4096", "obstacles_4096_caps",
+                 "obstacles_4096_warm", "obstacles_4096_pair"):
         print(name, "ms with / without segments", a[name + "_ms"][0], b[name + "_ms"][0], "shadow columns", a[name + "_segcols"][0],
               "(iterations, sweep launches, sweeps)", a[name + "_iters"], b[name + "_iters"])
         assert b[name + "_segcols"][0] == 0
@@ -322,7 +345,7 @@ def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
             continue
         assert np.array_equal(a[k], b[k]), (k, np.abs(np.asarray(a[k], float) - np.asarray(b[k], float)).max())
     # the streaks of configs[3] really were split, every iteration was executed, and the chains of sweeps got shorter
-    assert a["obstacles_4096_r32_segcols"][0] > 1000
+    assert a["obstacles_4096_r32_segcols"][0] > 1000 and a["obstacles_4096_caps_segcols"][0] > 500 and a["obstacles_4096_pair_segcols"][0] > 1000
     assert a["obstacles_4096_r32_iters"][0] == b["obstacles_4096_r32_iters"][0]
     assert a["obstacles_4096_r32_iters"][1] < 0.75 * b["obstacles_4096_r32_iters"][1]
     assert a["obstacles_4096_r32_ms"][0] < 0.97 * b["obstacles_4096_r32_ms"][0], (a["obstacles_4096_r32_ms"], b["obstacles_4096_r32_ms"])
