@@ -1478,7 +1478,10 @@ class Engine final : public EngineBase {
       if constexpr (kMfmaBackward) {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
         {
-          const void* variants[8] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
+          // (+ the two variants that know the segments of rejection streaks: default speculation modes only, see Solve)
+          const void* variants[10] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecFree, true>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave, true>),
+                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecWave>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave>),
@@ -1626,7 +1629,8 @@ class Engine final : public EngineBase {
     }
     ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
     // segments of rejection streaks: not with a recorded history (its rows are appended in iteration order)
-    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_;
+    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_ &&
+                        this->spec_mode_ == kSpecAuto;  // (the persistent kernel's variants that know the segments: default modes only)
     const int seg_capc = seg_on ? (seg_total_ / C) / kBlock * kBlock : 0;  // shadow columns per chain
     if (seg_on) ALTRO_HIP_CHECK(hipMemsetAsync(d_seg_cursor_, 0, kMaxChains * sizeof(int), stream_));
     Chain chain[kMaxChains];
@@ -1925,7 +1929,14 @@ class Engine final : public EngineBase {
         }
 #define ALTRO_FUSED(CC, S, BLK) \
   hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw)
-        if (circles) {
+        if (any_split()) {
+          // columns of split streaks may be in the lists: the variants with the segments' bookkeeping compiled in (it costs
+          // the kernel 560 B of scratch per lane and ~10 % per iteration, which is why nothing else runs them)
+          if (circles)
+            hipLaunchKernelGGL((k_sweep_fused<T, M, true, kSpecWave, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw);
+          else
+            hipLaunchKernelGGL((k_sweep_fused<T, M, false, kSpecFree, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw);
+        } else if (circles) {
           if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
           else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
           else if (spec_mode_ == kSpecFree) ALTRO_FUSED(true, kSpecFree, b4);

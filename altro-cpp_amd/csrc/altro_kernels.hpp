@@ -1661,7 +1661,12 @@ ALTRO_DEV bool conv_stats_and_done_pre(const DevArrays<T>& A, const DevOpts& o, 
 // Phase 3 of the forward pass: per-instance state machine (shared by both forward kernels).
 // Lane 0 of the instance takes the decisions; the row sweeps of the AL transition (dual and penalty
 // updates) are spread over its 20 lanes.  sKD / sU: LDS copies of the gains / controls (or nullptr).
-template <class T, class M>
+// SPLIT: this caller may split rejection streaks into segments (the batched forward kernel; the persistent kernel only
+// verifies / retires / cancels the segments it is handed -- with the split compiled in, its register allocation falls back
+// to 560 B of scratch per lane and every iteration of it gets ~10 % slower)
+// SEGCODE: the bookkeeping of the segments is compiled in at all (the persistent kernel has a variant without: the one every
+// solve that never split runs, at the register allocation it had before the segments existed)
+template <class T, class M, bool SPLIT = false, bool SEGCODE = true>
 ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, const DevOpts& o, int mode, int b, int grp,
                               int t, bool accepted, double alpha_sel, double J_sel, double z_sel, double g_sel,
                               int last_status, double viol, const T* sKD, const T* sU, const InstPre& pre,
@@ -1746,7 +1751,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
   if (mode == kFwdStepOnly) return;
   inner_done = __shfl(inner_done, grp * LS);
   // ---- segments of a rejection streak (DevArrays::seg_*): verify / retire, cancel, split ----
-  if (A.seg_end) {
+  if (SEGCODE && A.seg_end) {
     int drop = 0, nclones = 0, first = 0, seg_len = 0;
     if (t == 0) {
       const bool rc = !accepted && !inner_done;  // every trial rejected, and the inner solve goes on
@@ -1780,7 +1785,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
           A.seg_next[b] = -1;
           A.seg_end[b] = kSegNoEnd;
         }
-      } else if (rc && streak >= 2 && !active_out && A.next_count && A.seg_parts > 1) {
+      } else if (SPLIT && rc && streak >= 2 && !active_out && A.next_count && A.seg_parts > 1) {
         // ---- split: what is left of this inner solve (ilqr.hpp:600-611 caps it) in seg_parts segments ----
         const int r1 = o.max_iterations_inner - it_next, r2 = o.max_iterations_total - tot_next;
         const int Rl = r1 < r2 ? r1 : r2;
@@ -1839,7 +1844,7 @@ ALTRO_DEV void forward_phase3(const DevArrays<T>& A, const ProblemDesc* pd, cons
     drop = __shfl(drop, grp * LS);
     nclones = __shfl(nclones, grp * LS);
     first = __shfl(first, grp * LS);
-    if (nclones > 0) {
+    if (SPLIT && nclones > 0) {
       // the clones' share of the instance: trajectory, multipliers, penalties, parameters -- nothing a rejected iteration
       // changes (the stored constraint values, knot costs, records and gains are recomputed before they are read)
       using R_ = Rec<T, M::n, M::m>;
@@ -3053,7 +3058,7 @@ struct FwdSpec {
   double* inbox;  // {rho, drho} the pass assumed
   bool armed;     // speculate in this forward pass (the previous line search was rejected: a streak is likely)
 };
-template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false, bool SOFT = false>
+template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false, bool SOFT = false, bool SEG = true>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
@@ -3532,7 +3537,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     for (int k = 0; k < N; ++k) gsum += (double)rk[k];
     g_sel = gsum;
   }
-  forward_phase3<T, M>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
+  forward_phase3<T, M, !FUSED, SEG>(A, pdg, o, mode, b, grp, t, accepted, (double)alpha_sel, J_sel, z_sel, g_sel, last_status,
                        (double)viol, sKD, sU, pre, FUSED ? active_out : nullptr, FUSED ? sLam : nullptr,
                        FUSED ? sPen : nullptr, FUSED ? ff : nullptr, kKdStride, kKdOff, eahead_words, eahead_waves, eahead_tag);
   ALTRO_STAMP_ADD(6, st_w1d);
@@ -3728,7 +3733,7 @@ ALTRO_DEV bool tw_cas(unsigned long long* p, unsigned long long expect, unsigned
 ALTRO_DEV unsigned long long tw_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
 ALTRO_DEV double tw_dbl(unsigned long long x) { return __longlong_as_double((long long)x); }
 
-template <class T, class M, bool CIRC, int SPEC>
+template <class T, class M, bool CIRC, int SPEC, bool SEG = false>
 __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
     DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
     int* sweeps_out, SpecRemote<T> rs, TwinCtl tw) {
@@ -3953,7 +3958,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         A.status[bT] = i0; A.status_al[bT] = i1; A.it_outer[bT] = i2; A.phase[bT] = i3; A.need_init_cost[bT] = i4;
         // ... but for what the rejected iterations up to `start` will have changed: counters, regularisation, and the
         // previous cost, which every iteration of a streak sets to the (unchanged) current one (solver_stats.cpp:54-66)
-        if (A.seg_end) {
+        if (SEG && A.seg_end) {
           A.seg_end[bT] = kSegNoEnd;
           A.seg_next[bT] = -1;
           A.seg_flag[bT] = 0;
@@ -4048,7 +4053,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     const bool st_adopted = adopt;
     // ---- F ----
     spec.armed = armed;
-    forward2_body<T, M, true, kSrcLds, CIRC, kSoft>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
+    forward2_body<T, M, true, kSrcLds, CIRC, kSoft, SEG>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
                                                     kWave4 ? &spec : nullptr, alpha_tab,
                                                     FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh,
                                                     sync_words + kSyEAhead0, persistent ? (kWave4 ? 3 : 2) : 0, loops + 1, b);
@@ -4155,7 +4160,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
             const int it_in = (int)ff[6], it_tot = (int)ff[7];  // the counters entering the next iteration
             if (tw_claim == 0) {
               // (a column whose streak the batched sweeps have split into segments ends at its segment's end: no twin)
-              if (rc && tw_streak >= 2 && (!A.seg_end || A.seg_next[b] < 0)) {
+              if (rc && tw_streak >= 2 && (!SEG || !A.seg_end || A.seg_next[b] < 0)) {
                 ++tw_ver;
                 unsigned long long* buf = box + kTwSnap + 4 * (tw_ver & 1);
                 tw_store(buf, ((unsigned long long)(unsigned)it_in << 32) | (unsigned long long)(unsigned)it_tot);
