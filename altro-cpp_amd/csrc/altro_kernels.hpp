@@ -4053,7 +4053,7 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     const bool st_adopted = adopt;
     // ---- F ----
     spec.armed = armed;
-    forward2_body<T, M, true, kSrcLds, CIRC, kSoft, SEG>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
+    forward2_body<T, M, true, kSrcLds, CIRC, kSoft, false>(A, pdg, pd, o, mode, 0, 1, smem_raw, fh, active_flag, sCand, ff,
                                                     kWave4 ? &spec : nullptr, alpha_tab,
                                                     FwdSync<kSoft>{sync_words, loops * kFwdSeqStride}, sCost, fh,
                                                     sync_words + kSyEAhead0, persistent ? (kWave4 ? 3 : 2) : 0, loops + 1, b);
@@ -4146,6 +4146,50 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         // is no expansion phase in between any more to hide the race)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+    }
+    // ---- segments of rejection streaks (DevArrays::seg_*) that the batched sweeps handed over: a column with a successor
+    //      verifies the successor's assumptions at its segment's end and retires, or cancels the chain; a cancelled column
+    //      leaves.  (The batched kernels do this inside forward_phase3; here it sits beside the twins' bookkeeping: compiled
+    //      into phase 3 it cost this kernel's register allocation 560 B of scratch per lane.)  The iteration that just ended
+    //      is complete either way; a column that leaves does so through the loop's normal exit. ----
+    bool seg_leave = false;
+    if (SEG && A.seg_end) {
+      if (tid == 0) {
+        double leave = 0.0;
+        const int flag = A.seg_flag[b];
+        const int nxt = A.seg_next[b];
+        const bool rc = ff[0] != 0.0 && ff[3] == 0.0;  // every trial rejected, and the inner solve goes on
+        if (flag & kSegCancelled) {
+          leave = 1.0;  // a predecessor did not arrive where this column assumed it would: its work is void
+        } else if (nxt >= 0) {
+          bool cancel = !rc;
+          if (rc && (int)ff[6] == A.seg_end[b]) {
+            const bool same = A.seg_tot0[nxt] == (int)ff[7] && tw_bits(A.seg_rho0[nxt]) == tw_bits(ff[1]) &&
+                              tw_bits(A.seg_drho0[nxt]) == tw_bits(ff[2]) &&
+                              (__hip_atomic_load(A.seg_flag + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSegCancelled) == 0;
+            if (same) {
+              A.seg_flag[b] = flag | kSegRetired;  // (the next column owns the instance from here: k_seg_fixup follows the chain)
+              leave = 1.0;
+            } else {
+              cancel = true;
+            }
+          }
+          if (cancel) {
+            int sgd = nxt;
+            for (int guard = 0; sgd >= 0 && guard < 256; ++guard) {
+              atomicOr(A.seg_flag + sgd, kSegCancelled);
+              sgd = A.seg_next[sgd];
+            }
+            A.seg_next[b] = -1;
+            A.seg_end[b] = kSegNoEnd;
+          }
+        }
+        if (leave != 0.0) A.phase[b] = 0;
+        ff[12] = leave;
+      }
+      if (SPEC && adopt) lds_barrier(); else __syncthreads();
+      seg_leave = ff[12] != 0.0;
+      if (seg_leave) break;
     }
     // ---- twin workgroups (TwinCtl).  Primary: publish the state this iteration leaves while a streak is on, answer a
     //      claim when the iteration it names is reached.  Twin: a look at the verdict now and then. ----
