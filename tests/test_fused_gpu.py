@@ -247,7 +247,8 @@ def test_twin_workgroups_are_bit_identical(tmp_path):
     # the twins really took their share: a batch with stragglers finishes sooner, and every iteration was executed
     assert a["turn90_2304_ms"][0] < 0.8 * b["turn90_2304_ms"][0], (a["turn90_2304_ms"], b["turn90_2304_ms"])
     assert a["turn90_2304_iters"][0] == b["turn90_2304_iters"][0]       # sum of iterations_total
-    assert a["turn90_2304_iters"][1] >= b["turn90_2304_iters"][1]       # units executed by the persistent launch (refused twins add theirs)
+    # (the units executed by the persistent launch, iters[1], are not compared: which sweep hands over to it depends on
+    #  when the host sees the counts, with or without twins -- 5 622 or 5 637 of the 32 097 in different runs)
 
 
 _SCRIPT_SEG = r'''
