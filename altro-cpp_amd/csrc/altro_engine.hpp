@@ -1930,8 +1930,8 @@ class Engine final : public EngineBase {
 #define ALTRO_FUSED(CC, S, BLK) \
   hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw)
         if (any_split()) {
-          // columns of split streaks may be in the lists: the variants with the segments' bookkeeping compiled in (it costs
-          // the kernel 560 B of scratch per lane and ~10 % per iteration, which is why nothing else runs them)
+          // columns of split streaks may be in the lists: the variants that verify / retire / cancel them in the loop's
+          // bookkeeping step (every other launch runs the kernels as they were before the segments existed)
           if (circles)
             hipLaunchKernelGGL((k_sweep_fused<T, M, true, kSpecWave, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw);
           else
