@@ -1,4 +1,6 @@
 # Round 5: the build before the segments (altro-cpp_amd/csrc/_x/libaltro_pre_segments.so, commit 0c36f99) against the shipped one
+# (built with: git archive 0c36f99 altro-cpp_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/altro-cpp_amd/csrc libaltro_hip.so;
+#  copied to altro-cpp_amd/csrc/_x/, which is not tracked)
 # on ONE box: config 2 / 3 medians and the single-instance latencies (boxes differ by up to 8 % in latency-bound launches)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp REPS=16
