@@ -245,7 +245,7 @@ def test_twin_workgroups_are_bit_identical(tmp_path):
             continue
         assert np.array_equal(a[k], b[k]), (k, np.abs(np.asarray(a[k], float) - np.asarray(b[k], float)).max())
     # the twins really took their share: a batch with stragglers finishes sooner, and every iteration was executed
-    assert a["turn90_2304_ms"][0] < 0.8 * b["turn90_2304_ms"][0], (a["turn90_2304_ms"], b["turn90_2304_ms"])
+    assert a["turn90_2304_ms"][0] < 0.9 * b["turn90_2304_ms"][0], (a["turn90_2304_ms"], b["turn90_2304_ms"])  # (measured 0.72 - 0.75)
     assert a["turn90_2304_iters"][0] == b["turn90_2304_iters"][0]       # sum of iterations_total
     # (the units executed by the persistent launch, iters[1], are not compared: which sweep hands over to it depends on
     #  when the host sees the counts, with or without twins -- 5 622 or 5 637 of the 32 097 in different runs)
@@ -349,4 +349,5 @@ def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
     assert a["obstacles_4096_r32_segcols"][0] > 1000 and a["obstacles_4096_caps_segcols"][0] > 500 and a["obstacles_4096_pair_segcols"][0] > 1000
     assert a["obstacles_4096_r32_iters"][0] == b["obstacles_4096_r32_iters"][0]
     assert a["obstacles_4096_r32_iters"][1] < 0.75 * b["obstacles_4096_r32_iters"][1]
-    assert a["obstacles_4096_r32_ms"][0] < 0.97 * b["obstacles_4096_r32_ms"][0], (a["obstacles_4096_r32_ms"], b["obstacles_4096_r32_ms"])
+    # (measured 32.7 - 33.3 against 35.8 - 36.2 ms; asserted loosely: a timing, the sweep count above is the structural check)
+    assert a["obstacles_4096_r32_ms"][0] < 1.0 * b["obstacles_4096_r32_ms"][0], (a["obstacles_4096_r32_ms"], b["obstacles_4096_r32_ms"])
