@@ -1153,7 +1153,49 @@ class iLQR {
 };
 }  // namespace ilqr
 
+namespace constraints {
+// altro/constraints/constraint_values.hpp:33-300: the values a constraint carries inside the AL cost -- here a LIVE view of
+// one constraint of one knot of instance `b` on the device: every getter downloads what the solver holds now (the
+// reference hands out the object itself; auglag_test.cpp:256-270 reads its duals again after UpdateDuals()).
+template <int n, int m, class ConType>
+class ConstraintValues {
+ public:
+  ConstraintValues(std::shared_ptr<ilqr::detail_ilqr::Core<n, m>> core, int row0, int p, int rows, int b, std::string label)
+      : c_(std::move(core)), row0_(row0), p_(p), rows_(rows), b_(b), label_(std::move(label)) {}
+  int OutputDimension() const { return p_; }           // constraint_values.hpp:100
+  const std::string& GetLabel() const { return label_; }
+  std::vector<double> GetDuals() const { return Rows(&altro_get_duals, "altro_get_duals"); }                      // lambda_
+  std::vector<double> GetPenalty() const { return Rows(&altro_get_penalties, "altro_get_penalties"); }            // penalty_
+  std::vector<double> GetConstraintValue() const { return Rows(&altro_get_constraint_values, "altro_get_constraint_values"); }  // c_
+
+ private:
+  std::vector<double> Rows(altro_status (*get)(altro_handle, double*), const char* what) const {
+    std::vector<double> all((size_t)c_->B * rows_);
+    if (!all.empty()) detail::Check(c_->h, get(c_->h, all.data()), what);
+    const size_t at = (size_t)b_ * rows_ + row0_;
+    return std::vector<double>(all.begin() + at, all.begin() + at + p_);
+  }
+  std::shared_ptr<ilqr::detail_ilqr::Core<n, m>> c_;
+  int row0_, p_, rows_, b_;
+  std::string label_;
+};
+}  // namespace constraints
+
 namespace augmented_lagrangian {
+// altro/augmented_lagrangian/al_cost.hpp:41-120: the AL cost of one knot, as far as callers look into it -- its constraint
+// values by cone, in the order the constraints were added (example_unicycle_test.cpp:66,105; auglag_test.cpp:256-258)
+template <int n, int m>
+class ALCost {
+ public:
+  using EqVals = std::shared_ptr<constraints::ConstraintValues<n, m, constraints::Equality>>;
+  using IneqVals = std::shared_ptr<constraints::ConstraintValues<n, m, constraints::Inequality>>;
+  const std::vector<EqVals>& GetEqualityConstraints() const { return eq_; }        // al_cost.hpp:100
+  const std::vector<IneqVals>& GetInequalityConstraints() const { return ineq_; }  // al_cost.hpp:103
+  int NumConstraints() const { return rows_; }                                      // al_cost.hpp:96
+  std::vector<EqVals> eq_;
+  std::vector<IneqVals> ineq_;
+  int rows_ = 0;
+};
 // altro/augmented_lagrangian/al_solver.hpp:28-224
 template <int n, int m>
 class AugmentedLagrangianiLQR {
@@ -1194,6 +1236,37 @@ class AugmentedLagrangianiLQR {
     ilqr_solver_.Pull(true, true);
     status_ = ilqr_solver_.StatusAL();
     ilqr_solver_.AfterSolve();
+  }
+  // al_solver.hpp:287-302: duals and penalties reset as the options say, statistics reset, "viol" and "pen" logged
+  void Init() {
+    ilqr_solver_.Push();  // (options and the caller's trajectory)
+    detail::Check(Handle(), altro_al_init(Handle()), "altro_al_init");
+  }
+  // al_solver.hpp:215, al_cost.hpp:372-379: every multiplier of every instance back to zero
+  void ResetDualVariables() {
+    std::vector<double> zero((size_t)BatchSize() * NumConstraints(), 0.0);
+    if (!zero.empty()) detail::Check(Handle(), altro_set_duals(Handle(), zero.data()), "altro_set_duals");
+  }
+  // al_solver.hpp:46: the AL cost of knot k (of instance b): live views of its constraint values by cone
+  std::shared_ptr<ALCost<n, m>> GetALCost(int k, int b = 0) {
+    auto core = ilqr_solver_.CorePtr();
+    const auto& cons = core->cons;
+    if (k < 0 || k >= (int)cons.size()) throw std::out_of_range("GetALCost: knot index");
+    const int R = NumConstraints();
+    int row = 0;
+    for (int j = 0; j < k; ++j)
+      for (const examples::ConstraintDesc& cd : cons[j]) row += cd.OutputDimension();
+    auto cost = std::make_shared<ALCost<n, m>>();
+    for (const examples::ConstraintDesc& cd : cons[k]) {
+      const int p = cd.OutputDimension();
+      if (cd.IsEquality())
+        cost->eq_.push_back(std::make_shared<constraints::ConstraintValues<n, m, constraints::Equality>>(core, row, p, R, b, cd.label));
+      else
+        cost->ineq_.push_back(std::make_shared<constraints::ConstraintValues<n, m, constraints::Inequality>>(core, row, p, R, b, cd.label));
+      row += p;
+      cost->rows_ += p;
+    }
+    return cost;
   }
   void UpdateDuals() { detail::Check(Handle(), altro_update_duals(Handle()), "altro_update_duals"); }
   void UpdatePenalties() { detail::Check(Handle(), altro_update_penalties(Handle()), "altro_update_penalties"); }

@@ -23,6 +23,7 @@ def _syntax(path, *flags):
 
 def test_reference_call_style_compiles():
     _syntax(os.path.join(ROOT, "tests", "cpp", "reference_call_style.cpp"))
+    _syntax(os.path.join(ROOT, "tests", "cpp", "al_cost_views.cpp"))  # Init(), GetALCost(k)->...->GetDuals(): auglag_test.cpp:250-275
 
 
 def test_perf_drivers_and_reference_gtests_compile():

@@ -90,3 +90,13 @@ def test_reference_call_style_program_runs(tmp_path):
     for name in ("profiler_unicycle.out", "profiler_unicycle-loop.out", "profiler_triple_integrator.out"):
         text = (tmp_path / name).read_text()
         assert "Description                  Time (us)   %Total  %Parent" in text and "backward_pass" in text, text
+
+
+@pytest.mark.gpu
+def test_al_cost_views_program_runs(tmp_path):
+    """tests/cpp/al_cost_views.cpp: the reference's callers that look INTO the AL solver -- Init() sets the initial penalty
+    (example_unicycle_test.cpp:95-106), a ConstraintValues pointer taken from GetALCost(N) before the solve shows the goal
+    duals after UpdateDuals() (auglag_test.cpp:250-275), ResetDualVariables() zeroes them."""
+    exe = _build(os.path.join("tests", "cpp"), "al_cost_views")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "al_cost_views: 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
