@@ -921,7 +921,24 @@ class iLQR {
     SetRecordHistory(c_->B <= kHistoryBatchLimit);
     ctg_auto_ = c_->B <= kHistoryBatchLimit;  // (see SetRecordCostToGo)
   }
+  // ilqr.hpp:97-124: the reference copies knot points [k_start, k_stop) and is always called with the whole range
+  // (ilqr.hpp:131, al_solver.hpp:246, ilqr_class_test.cpp:76); the device engine is built from a whole problem
+  template <int n2 = n, int m2 = m>
+  void CopyFromProblem(const problem::Problem& prob, int k_start, int k_stop, int dtype = ALTRO_F64, int device_id = 0) {
+    if (k_start < 0 || k_start > c_->N) throw std::runtime_error("Start index must be in the interval [0,N]");
+    if (k_stop < 0 || k_stop > c_->N + 1) throw std::runtime_error("Stop index must be in the interval [0,N+1]");
+    if (k_start != 0 || k_stop != c_->N + 1)
+      throw std::runtime_error("CopyFromProblem: the device engine takes a problem whole -- CopyFromProblem(prob, 0, N + 1)");
+    InitializeFromProblem(prob, dtype, device_id);
+  }
   bool IsInitialized() const { return c_->h != nullptr; }
+  // ilqr.hpp:163: the per-knot costs of the last cost evaluation (of the selected instance), k = 0 .. N
+  std::vector<double> GetCosts() {
+    std::vector<double> all((size_t)c_->B * (c_->N + 1));
+    detail::Check(Need(), altro_get_knot_costs(c_->h, all.data()), "altro_get_knot_costs");
+    const size_t at = (size_t)c_->stats_instance * (c_->N + 1);
+    return std::vector<double>(all.begin() + at, all.begin() + at + c_->N + 1);
+  }
 
   int NumSegments() const { return c_->N; }
   int BatchSize() const { return c_->B; }

@@ -74,6 +74,28 @@ int main() {
       for (double v : goal_vals->GetDuals()) EXPECT(v == 0.0);
       for (double v : alsolver.GetALCost(3)->GetInequalityConstraints()[0]->GetDuals()) EXPECT(v == 0.0);
     }
+    {  // ilqr_class_test.cpp:72-82 (CopyFromProblem over the whole range), ilqr.hpp:163 (GetCosts)
+      problem::Problem prob = def.MakeProblem(false);
+      ilqr::iLQR<NStates, NControls> ilqr(N);
+      ilqr.CopyFromProblem(prob, 0, N + 1);
+      EXPECT(ilqr.NumSegments() == N);
+      ilqr.SetTrajectory(std::make_shared<altro::Trajectory<NStates, NControls>>(def.InitialTrajectory<NStates, NControls>()));
+      ilqr.Rollout();
+      const double J = ilqr.Cost();
+      const std::vector<double> costs = ilqr.GetCosts();
+      EXPECT((int)costs.size() == N + 1);
+      double sum = 0.0;
+      for (double c : costs) sum += c;
+      EXPECT(std::abs(sum - J) <= 1e-12 * std::abs(J));
+      bool threw = false;
+      try {
+        ilqr::iLQR<NStates, NControls> part(N);
+        part.CopyFromProblem(prob, 0, N);
+      } catch (const std::runtime_error&) {
+        threw = true;
+      }
+      EXPECT(threw);
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 2;
