@@ -362,6 +362,17 @@ class Trajectory {
     t_.at(k) = t;
   }
   float GetStep(int k) const { return h_.at(k); }
+  // trajectory.hpp:138-153: t[k+1] - t[k] == h[k] for all k
+  bool CheckTimeConsistency(const double eps = 1e-6, const bool verbose = false) const {
+    for (int k = 0; k < N_; ++k) {
+      const float h_calc = t_[k + 1] - t_[k], h_stored = h_[k];
+      if (std::abs(h_stored - h_calc) > eps) {
+        if (verbose) std::printf("k=%d\t h=%g\nt-=%g\t t+=%g\t dt=%g\n", k, h_stored, t_[k], t_[k + 1], h_calc);
+        return false;
+      }
+    }
+    return true;
+  }
   float GetTime(int k) const { return t_.at(k); }
   // every step and time is what SetUniformStep wrote (the solver then runs its uniform-step kernels)
   bool IsUniformStep() const { return uniform_; }
@@ -667,6 +678,36 @@ class Problem {
     int p = 0;
     for (int k = 0; k <= N_; ++k) p += NumConstraints(k);
     return p;
+  }
+  // problem.hpp:213-240: what a knot was given, as the reference's base-class pointers (copies of the stored descriptors:
+  // problem_test.cpp:32-60, ilqr_class_test.cpp:39-69).  An unset cost function is a nullptr, unset dynamics an error.
+  std::shared_ptr<CostFunction> GetCostFunction(int k) const {
+    Range(k);
+    if (!has_cost_[k]) return nullptr;
+    return std::make_shared<examples::QuadraticCost>(costs_[k]);
+  }
+  std::shared_ptr<DiscreteDynamics> GetDynamics(int k) const {
+    Range(k);
+    if (!has_dyn_[k]) throw std::runtime_error("Dynamics have not been defined at this knot point.");
+    struct Stored final : DiscreteDynamics {
+      int kind, n, m, index;
+      std::vector<double> params;
+      int Kind() const override { return kind; }
+      int StateDimension() const override { return n; }
+      int ControlDimension() const override { return m; }
+      std::vector<double> Params() const override { return params; }
+      int ModelIndex() const override { return index; }
+    };
+    auto d = std::make_shared<Stored>();
+    d->kind = model_kind_;
+    d->n = n_;
+    d->m = m_;
+    d->index = k < N_ ? knot_model_[k] : 0;
+    d->params = model_params_;
+    return d;
+  }
+  std::shared_ptr<std::vector<double>> GetInitialStatePointer() const {  // problem.hpp:242 (a copy)
+    return std::make_shared<std::vector<double>>(x0_);
   }
   bool IsFullyDefined() const {  // problem.hpp:271-297
     for (int k = 0; k <= N_; ++k)

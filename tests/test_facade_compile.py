@@ -75,3 +75,14 @@ int main() {
                             "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_host_side_types_behave_like_the_reference(tmp_path):
+    """tests/cpp/host_types.cpp -- the statements of the reference's problem_test.cpp:24-62, ilqr_class_test.cpp:36-70 and
+    trajectory_test.cpp:40-100 about Problem::GetDynamics / GetCostFunction / GetInitialStatePointer and
+    Trajectory::CheckTimeConsistency -- built and RUN here: these types live on the host (the library is linked, no device
+    call is made)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "host_types"])
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "host_types")], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0 and "host_types: 0 failures" in r.stdout, r.stdout + r.stderr
