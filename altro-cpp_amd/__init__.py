@@ -77,7 +77,9 @@ class Timing(C.Structure):
                 ("instance_iterations", C.c_longlong), ("fused_instance_iterations", C.c_longlong),
                 ("host_naps", C.c_int), ("twin_workgroups", C.c_int),
                 ("twin_claims", C.c_int), ("twin_handovers", C.c_int),
-                ("fused_workgroup_iterations", C.c_int), ("segment_columns", C.c_int)]
+                ("fused_workgroup_iterations", C.c_int), ("segment_columns", C.c_int),
+                ("loop_ms", C.c_double), ("loop_workgroups", C.c_int), ("loop_iterations", C.c_int),
+                ("loop_handover", C.c_int), ("loop_instance_iterations", C.c_longlong)]
 
 
 class AltroError(RuntimeError):

@@ -734,6 +734,8 @@ class Engine final : public EngineBase {
     seg_total_ = 0;
     d_list_[0] = d_list_[1] = nullptr;
     d_iota_ = d_merged_ = nullptr;
+    d_loop_win_ = d_loop_ctl_ = d_loop_tail_ = nullptr;
+    loop_groups_ = 0;
     d_spec_go_ = nullptr;
     d_spec_io_ = nullptr;
     d_spec_kd_ = nullptr;
@@ -1494,6 +1496,41 @@ class Engine final : public EngineBase {
         }
       }
     }
+    // The device-side sweep loop (k_sweep_loop, round 6): persistent workgroups of the forward pass's shape that run
+    // E -> B -> F for the instances in their slots; as many workgroups as the GPU holds at once (registers: two waves per
+    // SIMD; LDS: the forward block, which the gain buffer of the backward pass shares), never more than the batch fills.
+    loop_groups_ = 0;
+    if constexpr (kMfmaBackward) {
+      const char* e = std::getenv("ALTRO_HIP_SWEEP_LOOP");
+      if (!(e && atoi(e) == 0) && fwd_lds_bytes_ > 0 && !kdg_ && fwd_per_wave_ == lanes_per_wave() && B_ > persist_at_) {
+        const size_t bwd_bytes = ((size_t)kBwdChunk * 4 * R::KP + kBlock) * sizeof(double);
+        loop_lds_bytes_ = std::max(fwd_lds_bytes_, bwd_bytes);
+        const void* fn = rg_ ? LoopKernel<kSrcGlb>() : LoopKernel<kSrcLds>();
+        if (fn && loop_lds_bytes_ <= 160 * 1024) {
+          if (loop_lds_bytes_ > 64 * 1024)
+            ALTRO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_lds_bytes_));
+          int per_cu = 0;
+          ALTRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFwdWaves * kBlock, loop_lds_bytes_));
+          if (const char* e2 = std::getenv("ALTRO_HIP_LOOP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e2)));
+          const int slots = lanes_per_wave();
+          loop_groups_ = std::max(0, std::min(per_cu * num_cus_, (B_ + slots - 1) / slots));
+          if (const char* e2 = std::getenv("ALTRO_HIP_LOOP_GROUPS")) loop_groups_ = std::max(1, std::min(loop_groups_, atoi(e2)));
+          loop_per_cu_ = per_cu;
+          // WHEN it takes the bulk phase (measured, profiles/r06_experiments.txt #1): a batch that fits the slots of the
+          // resident workgroups (two per CU, three slots each: 1536 instances on an MI355X) runs as fast (kTurn90) or up to
+          // 23 % faster (obstacles, 1024 instances) than the host-paced sweeps, with no host in the loop; a larger batch is
+          // worked off in generations -- slots refilled as instances finish -- at 1536 instances in flight against the
+          // sweeps' whole batch over four chains, and is 15 - 25 % slower (4096 kTurn90: 7.5 against 6.3 ms).  So: the
+          // loop by default iff the batch fits the slots; ALTRO_HIP_SWEEP_LOOP=1 forces it for any batch, =0 never.
+          if (!(e && atoi(e) != 0) && B_ > per_cu * num_cus_ * slots) loop_groups_ = 0;
+        }
+        if (loop_groups_ > 0) {
+          ALTRO_ALLOC(d_loop_win_, (size_t)loop_groups_ * 4);
+          ALTRO_ALLOC(d_loop_ctl_, (size_t)kLwWords + 8);  // (+ the words the persistent tail kernel reports)
+          ALTRO_ALLOC(d_loop_tail_, (size_t)B_ + 16);
+        }
+      }
+    }
     // candidates of the batched line search: the first 6 trials and the last live one own a slot, deeper winners are
     // replayed (CandLayout); ALTRO_HIP_CAND_FRONT=19 stores every trial (round 3), 0 replays every accepted trial (tests).
     // Measured (ms per solve, configs 2 / 3 / 4): front 19: 8.31 / 39.9 / 5.78; 12: 8.15 / 39.5 / 5.75; 8: 8.04 / 38.8 / 5.70;
@@ -1628,8 +1665,11 @@ class Engine final : public EngineBase {
       if (rs != ALTRO_OK) return rs;
     }
     ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+    // the device-side sweep loop takes the bulk phase whenever the persistent tail kernel can follow it (FusedOk: MFMA
+    // backward pass, staged forward pass, uniform step, <= 20 line-search trials, no cost-to-go records)
+    const bool loop_on = loop_groups_ > 0 && FusedOk(d);
     // segments of rejection streaks: not with a recorded history (its rows are appended in iteration order)
-    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_ &&
+    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_ && !loop_on &&
                         this->spec_mode_ == kSpecAuto;  // (the persistent kernel's variants that know the segments: default modes only)
     const int seg_capc = seg_on ? (seg_total_ / C) / kBlock * kBlock : 0;  // shadow columns per chain
     if (seg_on) ALTRO_HIP_CHECK(hipMemsetAsync(d_seg_cursor_, 0, kMaxChains * sizeof(int), stream_));
@@ -1774,7 +1814,38 @@ class Engine final : public EngineBase {
       timing_.sweep_launches += 1;
       return ALTRO_OK;
     };
-    for (int c = 0; c < C; ++c) {
+    bool loop_launched = false;
+    size_t loop_ev = 0;
+    const int loop_handover = std::min(B_, persist_at_);
+    if (loop_on) {
+      // ONE launch instead of the chains of sweeps: persistent workgroups pull instances, run E -> B -> F for them until
+      // they finish, and leave what is unfinished when `loop_handover` instances are left to the persistent tail kernel,
+      // which is enqueued right behind (the host never looks in between)
+      if constexpr (kMfmaBackward) {
+        ALTRO_HIP_CHECK(hipMemsetAsync(d_loop_ctl_, 0, (size_t)(kLwWords + 8) * sizeof(int), stream_));
+        const int per_xcd = ((B_ + kLoopXcds - 1) / kLoopXcds + 15) / 16 * 16;
+        const LoopCtl lc{d_loop_win_, d_loop_ctl_, d_loop_tail_, loop_handover, per_xcd};
+        PoisonLds();
+        if (prof) {
+          loop_ev = nev;
+          hipEventRecord(ProfEvent(nev++), stream_);
+        }
+        const dim3 gl(loop_groups_), bl(kFwdWaves * kBlock);
+        if (rg_) {
+          if constexpr (kRgEligible)
+            hipLaunchKernelGGL((k_sweep_loop<T, M, kSrcGlb>), gl, bl, loop_lds_bytes_, stream_, A_, d_pd_, pd_, d, mode, lc);
+        } else {
+          hipLaunchKernelGGL((k_sweep_loop<T, M, kSrcLds>), gl, bl, loop_lds_bytes_, stream_, A_, d_pd_, pd_, d, mode, lc);
+        }
+        if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+        timing_.launches += 1;
+        timing_.sweep_launches += 1;
+        for (int c = 0; c < C; ++c) chain[c].done = true;
+        tail_mode = true;
+        loop_launched = true;
+      }
+    }
+    for (int c = 0; c < C && !loop_launched; ++c) {
       altro_status st = enqueue_sweep(chain[c], 0);
       if (st != ALTRO_OK) return st;
       if (!chain[c].tail) chain[c].sweeps = 1;  // (tail already: the persistent kernel takes the batch from its first sweep)
@@ -1876,9 +1947,16 @@ class Engine final : public EngineBase {
             hipStreamWaitEvent(stream_, chain_ev_[c], 0);
           }
         }
+        if (loop_launched) {
+          ninst_l = loop_handover;  // (an upper bound: the list's length stays on the device)
+          A.chain_size = 0;
+        }
         const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), (long long)B_ + (seg_on ? seg_total_ : 0));
         if (any_split()) SegArrays(A);
-        if (whole_batch) {
+        if (loop_launched) {
+          A.act_list = d_loop_tail_;
+          A.act_count = d_loop_ctl_ + kLwTail;
+        } else if (whole_batch) {
           A.act_list = nullptr;
           A.act_count = nullptr;
           A.act_count_const = B_;
@@ -1905,7 +1983,7 @@ class Engine final : public EngineBase {
         for (int r = 0; r < pd_.nruns; ++r)
           circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
         // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
-        int* const out = d_counter_ + max_sweeps + 2;
+        int* const out = loop_launched ? d_loop_ctl_ + kLwWords : d_counter_ + max_sweeps + 2;
         SpecRemote<T> rs{};
         const int spec_mode_ = this->spec_mode_ == kSpecAuto ? (circles ? (int)kSpecWave : (int)kSpecFree) : this->spec_mode_;
         // twin workgroups (TwinCtl): one behind every primary, dispatched after all of them (same launch, higher block
@@ -1984,7 +2062,25 @@ class Engine final : public EngineBase {
     for (int c = 0; c < C; ++c) sweeps = std::max(sweeps, chain[c].sweeps);
     if (persistent_launched) {
       int extra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      if (loop_launched) {
+        int words[kLwWords + 8];
+        ALTRO_HIP_CHECK(CopySync(words, d_loop_ctl_, sizeof(words), hipMemcpyDeviceToHost));
+        std::memcpy(extra, words + kLwWords, sizeof(extra));
+        timing_.loop_workgroups = words[kLwGroups];
+        timing_.loop_instance_iterations = words[kLwUnits];
+        timing_.loop_handover = words[kLwTail];
+        timing_.loop_iterations = words[kLwMaxLoops];
+        sweeps = words[kLwMaxLoops];
+        extra[2] += words[kLwMaxLoops];
+        if (std::getenv("ALTRO_HIP_LOOP_LOG")) {
+          const double per = words[kLwGroups] > 0 ? 0.01 / words[kLwGroups] : 0.0;  // 100 MHz ticks -> us per workgroup
+          fprintf(stderr, "LOOPLOG %d workgroups (%d per CU), %d units, longest %d iterations, handed over %d | us per workgroup: slots %.1f E %.1f B %.1f F %.1f\n",
+                  words[kLwGroups], loop_per_cu_, words[kLwUnits], words[kLwMaxLoops], words[kLwTail], per * words[kLwTicks],
+                  per * words[kLwTicks + 1], per * words[kLwTicks + 2], per * words[kLwTicks + 3]);
+        }
+      } else {
+        ALTRO_HIP_CHECK(CopySync(extra, d_counter_ + max_sweeps + 2, sizeof(extra), hipMemcpyDeviceToHost));
+      }
       timing_.twin_handovers = extra[4];
       timing_.twin_claims = extra[5];
       timing_.fused_workgroup_iterations = extra[6];
@@ -2064,6 +2160,11 @@ class Engine final : public EngineBase {
       if (persistent_launched) {
         hipEventElapsedTime(&ms, prof_ev_[fused_ev], prof_ev_[fused_ev + 1]);
         timing_.fused_ms += ms;
+      }
+      if (loop_launched) {
+        float lms = 0;
+        hipEventElapsedTime(&lms, prof_ev_[loop_ev], prof_ev_[loop_ev + 1]);
+        timing_.loop_ms = lms;
       }
       if (std::getenv("ALTRO_HIP_SWEEP_LOG")) {
         // timeline of the chains of sweeps (diagnostics): per sweep its start since the solve began, the length of the list it
@@ -2183,6 +2284,18 @@ class Engine final : public EngineBase {
     const char* e = std::getenv("ALTRO_HIP_HOST_WAIT");
     return !(e && std::string(e) == "spin");
   }();
+  // the device-side sweep loop (k_sweep_loop): persistent workgroups, their windows, the control words, the tail list
+  int loop_groups_ = 0, loop_per_cu_ = 0;
+  size_t loop_lds_bytes_ = 0;
+  int *d_loop_win_ = nullptr, *d_loop_ctl_ = nullptr, *d_loop_tail_ = nullptr;
+  static constexpr int lanes_per_wave() { return kBlock / kLineSearchLanes; }
+  template <int SRC>
+  static const void* LoopKernel() {
+    if constexpr (kMfmaBackward && (SRC != kSrcGlb || kRgEligible))
+      return reinterpret_cast<const void*>(&k_sweep_loop<T, M, SRC>);
+    else
+      return nullptr;
+  }
   int* d_iota_ = nullptr;    // 0, 1, 2, ...: the active list of a chain's first sweep
   int* d_merged_ = nullptr;  // the lists of all chains, concatenated for the persistent kernel
   hipStream_t cur_ = nullptr;  // the stream the launch helpers enqueue on (a chain's, otherwise the engine's)

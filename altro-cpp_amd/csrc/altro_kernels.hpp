@@ -678,7 +678,7 @@ constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bu
 // this wave writes is read before the kernel's own __syncthreads.  (Schedules that decouple the two paces -- 70 % or
 // 88 % of the recursion's knots spread over the loop's barriers, the rest behind barriers A / S / V -- measured
 // 4 - 9 % slower than this lock step: profiles/r02_experiments_not_kept.txt.)
-template <class T, class M, bool CTG, bool FUSED, bool SPEC = false>
+template <class T, class M, bool CTG, bool FUSED, bool SPEC = false, int AHEAD = kBwdAhead>
 ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int all, int lane, int slot_base,
                                   double* sKD, T* sKDf, int fused_junk, double* fh, double spec_rho = 0.0,
                                   double spec_drho = 0.0, int* nbar = nullptr, int b_fixed = -1) {
@@ -741,7 +741,8 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   // the loads of the next block are issued right after the first knot of the current one, so every
   // wait -- including the conservative one the compiler places at the loop header -- only covers
   // loads that are at least kBwdAhead - 1 knots old.
-  constexpr int H = kBwdAhead;
+  constexpr int H = AHEAD;  // (<= kBwdAhead: the front pad is sized for that)
+  static_assert(AHEAD >= 1 && AHEAD <= kBwdAhead, "prefetch depth");
   unsigned iA, iB, i1, i2, i3;
   Tiles Sa[H], Sb[H];
   double Pp;
@@ -3065,7 +3066,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
                              const FwdSpec<T>* spec = nullptr, const T* alpha_tab = nullptr,
                              const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
                              double* fhw = nullptr, const int* eahead_words = nullptr, int eahead_waves = 0,
-                             int eahead_tag = 0, int b_fixed = -1) {
+                             int eahead_tag = 0, int b_fixed = -1, int bid_fixed = -1) {
   static_assert(!SOFT || FUSED, "software synchronisation is a mode of the persistent kernel");
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
@@ -3075,7 +3076,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   const int grp = lane / LS;
   const int t = lane - grp * LS;
   // (batched kernel: the workgroups that share cache lines of the instance-minor arrays run on one XCD, see xcd_block)
-  const int bid = FUSED ? (int)blockIdx.x : xcd_block((int)blockIdx.x, (int)gridDim.x, A.xcd_remap);
+  // (bid_fixed: the device-side sweep loop, k_sweep_loop -- a persistent workgroup names its window of the list itself)
+  const int bid = bid_fixed >= 0 ? bid_fixed : (FUSED ? (int)blockIdx.x : xcd_block((int)blockIdx.x, (int)gridDim.x, A.xcd_remap));
   const int b0 = (grp < per_wave) ? (b_fixed >= 0 ? b_fixed : instance_of_slot(A, bid * per_wave + grp, all)) : -1;
   const int N = A.N;
   const bool valid = b0 >= 0;
@@ -4487,6 +4489,191 @@ __global__ __launch_bounds__(kBlock) void k_seg_fixup(DevArrays<T> A, const Prob
     A.status[dst] = A.status[src]; A.status_al[dst] = A.status_al[src]; A.it_inner[dst] = A.it_inner[src];
     A.it_outer[dst] = A.it_outer[src]; A.it_total[dst] = A.it_total[src]; A.phase[dst] = A.phase[src];
     A.need_init_cost[dst] = A.need_init_cost[src];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// THE DEVICE-SIDE SWEEP LOOP (round 6): the bulk phase of a batched solve without the host.
+//
+// What every instance runs is iLQR::Solve's loop (altro/ilqr/ilqr.hpp:300-313: UpdateExpansions, BackwardPass, ForwardPass,
+// UpdateConvergenceStatistics until IsDone) inside the AL loop (al_solver.hpp:313-401) -- nothing in it needs the host, and
+// nothing in it couples two instances.  Rounds 1 - 5 ran it as SWEEPS: three launches per iteration and chain of sweeps
+// (k_expansions, k_backward_mfma, k_forward2), the host one sweep ahead, polling pinned counters to size the next grids.
+// Here ONE launch of persistent workgroups does the same work: a workgroup (rollout / cost / auxiliary wave, the block of
+// k_forward2) holds up to three instances in its SLOTS and runs E -> B -> F for them, iteration after iteration, with the
+// bodies of the three kernels as they are -- expansion_body over the workgroup's threads, backward_mfma_body on wave 0 (three
+// of the four 4 x 4 x 4 blocks carry an instance), forward2_body on all three waves -- separated by workgroup barriers
+// instead of kernel boundaries: what a phase writes to global memory its successor reads through the CU's own L1, which the
+// waves of a workgroup share (same argument as k_sweep_fused).  A slot whose instance has finished (the state machine of
+// forward_phase3 clears DevArrays::phase) is refilled from a queue of not yet started instances -- one cursor per XCD over a
+// contiguous eighth of the batch, so that the workgroups of an XCD work on neighbouring columns of the instance-minor
+// arrays (see xcd_block); a workgroup whose range has run dry steals from the others.  No sweep boundary, no list rebuild,
+// no counter for the host: instances advance at their own pace.
+// HAND-OVER: when lc.handover or fewer instances of the batch are unfinished (started or not), every workgroup appends what
+// it holds (and what is left in the queues) to the tail list and leaves; k_sweep_fused -- enqueued behind this launch by a
+// host that never looked -- takes that list, one workgroup per straggler, twins and all.  Same device code on the same
+// inputs in the same per-instance order: results are bit-identical to the host-paced sweeps
+// (tests/test_fused_gpu.py::test_launch_variants_are_bit_identical, ALTRO_HIP_SWEEP_LOOP=0 restores the sweeps).
+// -------------------------------------------------------------------------------------------------
+enum LoopWord {
+  kLwFinished = 0,  // instances that have left the solve inside this launch
+  kLwTail = 1,      // length of the tail list
+  kLwUnits = 2,     // (instance, iteration) units this launch ran
+  kLwMaxLoops = 3,  // most iterations one workgroup ran
+  kLwGroups = 4,    // workgroups that ran at least one iteration
+  kLwTicks = 8,     // [4] 100 MHz ticks all workgroups spent in: slot bookkeeping, E, B, F (diagnostics: ALTRO_HIP_LOOP_LOG)
+  kLwCursor = 16,   // [8] instances handed out of each XCD's range
+  kLwWords = 24
+};
+struct LoopCtl {
+  int* win;        // [gridDim.x][4]: the instances in the workgroup's slots this iteration (-1: empty; [3] is always empty)
+  int* ctl;        // [kLwWords], zeroed by the host before the launch
+  int* tail_list;  // [handover + slots of the launch]: what is handed to the persistent tail kernel
+  int handover;    // unfinished instances of the batch at or below which the workgroups hand over and leave
+  int per_xcd;     // instances per XCD range (a multiple of 16: the instances of one 128-byte line of the row arrays)
+};
+constexpr int kLoopXcds = 8;
+#ifndef ALTRO_LOOP_BWD_AHEAD
+#define ALTRO_LOOP_BWD_AHEAD 3
+#endif
+// prefetch depth of the backward pass inside the loop kernel: the stand-alone kernel's six knots in two ping-pong blocks are
+// 120 of its 256 registers; here the workgroup shares its SIMDs with a second one (two waves per SIMD, 256 registers each)
+constexpr int kLoopBwdAhead = ALTRO_LOOP_BWD_AHEAD;
+// up to `want` not yet started instances for a workgroup of XCD `xcd`: own range first, then the others' (thread 0 only)
+ALTRO_DEV int loop_pull(const LoopCtl& lc, int B, int xcd, int want, int* out) {
+  int got = 0;
+  for (int q = 0; q < kLoopXcds && got < want; ++q) {
+    const int x = (xcd + q) % kLoopXcds;
+    const int lo = x * lc.per_xcd, len = (B - lo < lc.per_xcd ? B - lo : lc.per_xcd);
+    if (len <= 0) continue;
+    int* cur = lc.ctl + kLwCursor + x;
+    if (__hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+    const int need = want - got;
+    const int at = atomicAdd(cur, need);
+    for (int j = 0; j < need && at + j < len; ++j) out[got++] = lo + at + j;
+  }
+  return got;
+}
+// The two big phases as functions of their own (A/B builds, -DALTRO_LOOP_NOINLINE_B / _F): the register allocator then
+// treats the recursion's prefetch blocks and the forward pass's knot loops separately instead of spilling one inside the other
+#ifdef ALTRO_LOOP_NOINLINE_B
+#define ALTRO_LOOP_B_ATTR __device__ __attribute__((noinline))
+#else
+#define ALTRO_LOOP_B_ATTR ALTRO_DEV
+#endif
+#ifdef ALTRO_LOOP_NOINLINE_F
+#define ALTRO_LOOP_F_ATTR __device__ __attribute__((noinline))
+#else
+#define ALTRO_LOOP_F_ATTR ALTRO_DEV
+#endif
+template <class T, class M>
+ALTRO_LOOP_B_ATTR void loop_backward(const DevArrays<T>& Aw, const DevOpts& o, int lane, double* sKD) {
+  backward_mfma_body<T, M, false, false, false, kLoopBwdAhead>(Aw, o, 0, lane, 0, sKD, nullptr, 0, nullptr);
+}
+template <class T, class M, int SRC>
+ALTRO_LOOP_F_ATTR void loop_forward(const DevArrays<T>& Aw, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd, const DevOpts& o,
+                                    int mode, int per_wave, unsigned char* smem_raw) {
+  forward2_body<T, M, false, SRC>(Aw, pdg, pd, o, mode, 0, per_wave, smem_raw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  FwdSync<false>{nullptr, 0}, nullptr, nullptr, nullptr, 0, 0, -1, 0);
+}
+template <class T, class M, int SRC>
+__global__ __launch_bounds__(kFwdWaves * kBlock, 2) void k_sweep_loop(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+                                                                        const ProblemDesc pd_arg, DevOpts o, int mode, LoopCtl lc) {
+  constexpr int PW = kBlock / kLineSearchLanes;  // slots of a workgroup (instances per wave of the forward pass)
+  static_assert(PW <= 3, "a window holds four entries, the fourth stays empty for the backward pass's fourth block");
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ int s_slot[4];
+  __shared__ int s_go;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int N = A.N;
+  int* const win = lc.win + (size_t)blockIdx.x * 4;
+  // what the bodies of the batched kernels see: a list of four entries -- this workgroup's window -- and nobody to append to
+  DevArrays<T> Aw = A;
+  Aw.act_list = win;
+  Aw.act_count = nullptr;
+  Aw.act_count_const = 4;
+  Aw.next_list = nullptr;
+  Aw.next_count = nullptr;
+  Aw.host_count = nullptr;
+  Aw.seg_end = nullptr;
+  if (tid < 4) s_slot[tid] = -1;
+  int loops = 0, units = 0;
+  int ticks[4] = {0, 0, 0, 0};
+  long long t_mark = wall_clock64();
+  auto mark = [&](int which) __attribute__((always_inline)) {
+    if (tid == 0) {
+      const long long now = wall_clock64();
+      ticks[which] += (int)(now - t_mark);
+      t_mark = now;
+    }
+  };
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) {
+      // ---- slots: drop what has finished, hand over or refill ----
+      int fin = 0, held = 0;
+      for (int g = 0; g < PW; ++g) {
+        const int b = s_slot[g];
+        if (b < 0) continue;
+        if (A.phase[b] != 1) {
+          s_slot[g] = -1;
+          ++fin;
+        } else {
+          ++held;
+        }
+      }
+      const int done = fin ? atomicAdd(lc.ctl + kLwFinished, fin) + fin
+                           : __hip_atomic_load(lc.ctl + kLwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int xcd = (int)(blockIdx.x % kLoopXcds);
+      int go = 0;
+      if (A.B - done <= lc.handover) {
+        // the tail: whatever this workgroup holds, and whatever nobody has started yet, goes to the persistent kernel
+        for (int g = 0; g < PW; ++g) {
+          if (s_slot[g] >= 0) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = s_slot[g];
+          s_slot[g] = -1;
+        }
+        int b1;
+        while (loop_pull(lc, A.B, xcd, 1, &b1) == 1) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = b1;
+      } else {
+        if (held < PW) {
+          int fresh[PW];
+          const int got = loop_pull(lc, A.B, xcd, PW - held, fresh);
+          for (int g = 0, j = 0; g < PW && j < got; ++g)
+            if (s_slot[g] < 0) s_slot[g] = fresh[j++];
+          held += got;
+        }
+        go = held > 0 ? 1 : 0;
+        units += held;
+      }
+      for (int g = 0; g < 4; ++g) win[g] = s_slot[g];
+      s_go = go;
+    }
+    __syncthreads();  // (s_waitcnt vmcnt(0) in front of the barrier: the window is in memory)
+    if (!s_go) break;
+    ++loops;
+    mark(0);
+    // ---- E: iLQR::UpdateExpansions (ilqr.hpp:670-677) of the slots' instances, one (instance, knot) per thread and round ----
+    for (int u = tid; u < PW * (N + 1); u += kFwdWaves * kBlock) {
+      const int g = u / (N + 1), k = u - g * (N + 1);
+      const int b = s_slot[g];
+      if (b >= 0) expansion_body<T, M>(A, pdg, b, k);
+    }
+    __syncthreads();
+    mark(1);
+    // ---- B: iLQR::BackwardPass (ilqr.hpp:385-445) on wave 0, one 4 x 4 x 4 block per slot ----
+    if (wave == 0) loop_backward<T, M>(Aw, o, lane, reinterpret_cast<double*>(smem_raw));
+    __syncthreads();
+    mark(2);
+    // ---- F: iLQR::ForwardPass + the state machine (ilqr.hpp:512-619, al_solver.hpp:313-401) on the three waves ----
+    loop_forward<T, M, SRC>(Aw, pdg, &pd_arg, o, mode, PW, smem_raw);
+    __syncthreads();
+    mark(3);
+  }
+  if (tid == 0 && loops > 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(lc.ctl + kLwTicks + i, ticks[i]);
+    atomicAdd(lc.ctl + kLwUnits, units);
+    atomicMax(lc.ctl + kLwMaxLoops, loops);
+    atomicAdd(lc.ctl + kLwGroups, 1);
   }
 }
 

@@ -173,6 +173,13 @@ typedef struct altro_timing {
                            /* primary: their share of the instance's iterations)                               */
   int segment_columns;     /* shadow columns the batched sweeps used for segments of rejection streaks (a streak   */
                            /* split in four: three columns; 0: none split, ALTRO_HIP_SEGMENTS=0)                   */
+  /* the device-side sweep loop (k_sweep_loop, round 6): ONE launch of persistent workgroups runs the bulk phase --   */
+  /* expansions, backward pass, forward pass of every instance, iteration after iteration -- without the host         */
+  double loop_ms;          /* duration of that launch (0: the host-paced sweeps ran, ALTRO_HIP_SWEEP_LOOP=0)        */
+  int loop_workgroups;     /* persistent workgroups that ran at least one iteration                                */
+  int loop_iterations;     /* most iterations one of them ran                                                      */
+  int loop_handover;       /* instances it handed to the persistent tail kernel                                    */
+  long long loop_instance_iterations; /* (instance, iteration) units it ran                                        */
 } altro_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

@@ -3,7 +3,7 @@
 #   scripts/kernel_resources.sh inst_unicycle_f64.hip
 cd "$(dirname "$0")/../altro-cpp_amd/csrc" || exit 1
 FLAGS=$(grep '^CXXFLAGS' Makefile | sed 's/^CXXFLAGS := //; s/\$(ARCH)/gfx950/')
-/opt/rocm/bin/hipcc $FLAGS --cuda-device-only -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
+/opt/rocm/bin/hipcc $FLAGS $EXTRA --cuda-device-only -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
   python3 -c "
 import sys, re, subprocess
 name = None; rows = {}

@@ -49,13 +49,16 @@ def test_struct_layouts_match_the_header(A):
     assert [f for f, _ in A.Options._fields_][:5] == ["max_iterations_total", "max_iterations_outer",
                                                       "max_iterations_inner", "cost_tolerance", "gradient_tolerance"]
     assert ctypes.sizeof(A.Options) % 8 == 0
-    # altro_timing: 6 doubles, 4 ints, 2 long longs, 6 ints
-    assert ctypes.sizeof(A.Timing) == 6 * 8 + 4 * 4 + 2 * 8 + 6 * 4
+    # altro_timing: 6 doubles, 4 ints, 2 long longs, 6 ints, then the device-side sweep loop's: 1 double, 3 ints (+ 4 bytes of
+    # padding), 1 long long
+    assert ctypes.sizeof(A.Timing) == 6 * 8 + 4 * 4 + 2 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8
     assert [f for f, _ in A.Timing._fields_] == ["total_ms", "init_ms", "expansions_ms", "backward_pass_ms", "forward_pass_ms",
                                                 "fused_ms", "sweeps", "fused_sweeps", "launches", "sweep_launches",
                                                 "instance_iterations",
                                                 "fused_instance_iterations", "host_naps", "twin_workgroups", "twin_claims",
-                                                "twin_handovers", "fused_workgroup_iterations", "segment_columns"]
+                                                "twin_handovers", "fused_workgroup_iterations", "segment_columns",
+                                                "loop_ms", "loop_workgroups", "loop_iterations", "loop_handover",
+                                                "loop_instance_iterations"]
 
 
 def test_default_options_are_the_reference_defaults(A):

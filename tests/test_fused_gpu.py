@@ -112,6 +112,7 @@ np.savez(sys.argv[1], **out)
                                     {"ALTRO_HIP_NO_SPECULATION": "1"}, {"ALTRO_HIP_SPECULATION": "helper"},
                                     {"ALTRO_HIP_SPECULATION": "free"}, {"ALTRO_HIP_SPECULATION": "wave"},
                                     {"ALTRO_HIP_SPECULATION": "free", "ALTRO_HIP_DEBUG_POISON": "12345678,mix"},
+                                    {"ALTRO_HIP_SWEEP_LOOP": "0"}, {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_LOOP_PER_CU": "1"},
                                     {"ALTRO_HIP_PERSIST_AT": "600"}, {"ALTRO_HIP_CHAINS": "4"}, {"ALTRO_HIP_CHAINS": "3", "ALTRO_HIP_PERSIST_AT": "100"}, {"ALTRO_HIP_DEBUG_POISON": "ffffffff"},
                                     {"ALTRO_HIP_DEBUG_POISON": "12345678,mix"}],
                          ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
@@ -351,3 +352,71 @@ def test_segments_of_rejection_streaks_are_bit_identical(tmp_path):
     assert a["obstacles_4096_r32_iters"][1] < 0.75 * b["obstacles_4096_r32_iters"][1]
     # (measured 32.7 - 33.3 against 35.8 - 36.2 ms; asserted loosely: a timing, the sweep count above is the structural check)
     assert a["obstacles_4096_r32_ms"][0] < 1.0 * b["obstacles_4096_r32_ms"][0], (a["obstacles_4096_r32_ms"], b["obstacles_4096_r32_ms"])
+
+
+_SCRIPT_LOOP = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+cases = (("turn90_2304", lambda: P.batch_turn90(make, batch=2304, seed=P.SEED_BASE + 3)),       # more instances than slots: generations, refills
+         ("turn90_640", lambda: P.batch_turn90(make, batch=640, seed=P.SEED_BASE + 5)),         # fits the slots
+         ("obstacles_r32", lambda: P.batch_three_obstacles(make, batch=1100, dtype=A.F32)),   # fp32 records, circle constraints, global-source forward pass
+         ("ilqr_800", lambda: P.batch_turn90(make, batch=800, seed=P.SEED_BASE + 7)))            # plain iLQR (no AL loop)
+for name, fac in cases:
+    s = fac()
+    for rep in range(2):   # (the second solve reuses windows, control words and the tail list)
+        s.reset_trajectory()
+        if name.startswith("ilqr"):
+            s.solve_ilqr()
+        else:
+            s.solve()
+    X, U = s.get_trajectory()
+    st = s.get_stats()
+    tm = s.get_timing()
+    K, d = s.get_gains()
+    out[name + "_X"] = X; out[name + "_U"] = U; out[name + "_K"] = K; out[name + "_d"] = d
+    out[name + "_lam"] = s.get_duals(); out[name + "_pen"] = s.get_penalties(); out[name + "_c"] = s.get_constraint_values()
+    out[name + "_costs"] = s.get_knot_costs()
+    for f in st.dtype.names:
+        out[name + "_st_" + f] = st[f]
+    for k in (0, 50, 100):
+        e = s.get_expansion(k)
+        for key, v in e.items():
+            if k < 100 or key in ("lxx", "lx"):
+                out[name + "_exp%%d_%%s" %% (k, key)] = v
+    out[name + "_tm"] = np.array([tm["loop_workgroups"], tm["loop_instance_iterations"], tm["loop_handover"], tm["sweep_launches"]])
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_device_side_sweep_loop_is_bit_identical(tmp_path):
+    """k_sweep_loop (round 6): ONE launch of persistent workgroups runs the bulk phase -- expansions, backward pass, forward pass
+    of the instances in their slots, iteration after iteration, slots refilled from a queue -- instead of the host-paced chains
+    of sweeps, and hands what is left to the persistent tail kernel through a list the host never reads.  Same device code on
+    the same inputs in the same per-instance order: trajectories, gains, multipliers, penalties, stored constraint values,
+    expansion records, knot costs and every statistic must be those of the sweeps (ALTRO_HIP_SWEEP_LOOP=0), also with LDS and
+    the shadow columns full of NaN words before every launch, and with one workgroup per CU instead of two."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, env_extra):
+        out = str(tmp_path / f"loop_{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_LOOP % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
+        return np.load(out)
+    ref = run("sweeps", {"ALTRO_HIP_SWEEP_LOOP": "0"})
+    assert ref["turn90_2304_tm"][0] == 0 and ref["turn90_2304_tm"][3] > 8     # host-paced sweeps, no loop launch
+    for tag, env in (("loop", {"ALTRO_HIP_SWEEP_LOOP": "1"}),
+                     ("loop_poisoned", {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"}),
+                     ("loop_1_per_cu", {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_LOOP_PER_CU": "1"}),
+                     ("loop_no_twins", {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_TWIN": "0"})):
+        got = run(tag, env)
+        for name in ("turn90_2304", "turn90_640", "obstacles_r32", "ilqr_800"):
+            assert got[name + "_tm"][0] > 0 and got[name + "_tm"][3] == 1, (tag, name)   # the loop really ran, as one launch
+            assert got[name + "_tm"][1] > 0
+        for k in ref.files:
+            if k.endswith("_tm"):
+                continue
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (tag, k)
