@@ -2031,7 +2031,7 @@ class Engine final : public EngineBase {
         timing_.launches += 1;
       }
     }
-    if (nap_ok && !nap) nap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostNapAfterUs;
+    if (nap_ok && !nap) nap = loop_launched || std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostNapAfterUs;
     if (nap && tail_ev_) {
       // the persistent launch runs for milliseconds: wait for it on an event that blocks in the driver (interrupt) instead
       // of spinning in hipStreamSynchronize
