@@ -21,9 +21,35 @@ def _syntax(path, *flags):
     assert r.returncode == 0, r.stderr[-4000:]
 
 
-def test_reference_call_style_compiles():
-    _syntax(os.path.join(ROOT, "tests", "cpp", "reference_call_style.cpp"))
+def test_pointer_api_driver_compiles():
+    _syntax(os.path.join(ROOT, "tests", "cpp", "pointer_api_driver.cpp"))  # the repository's own driver of the pointer-taking API
     _syntax(os.path.join(ROOT, "tests", "cpp", "al_cost_views.cpp"))  # Init(), GetALCost(k)->...->GetDuals(): auglag_test.cpp:250-275
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "perf")), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("driver", ["benchmark_unicycle.cpp", "benchmark_triple_integrator.cpp"])
+def test_reference_perf_drivers_compile_in_place(tmp_path, driver):
+    """Row B1, on the reference's OWN call sites: /root/reference/perf/benchmark_unicycle.cpp and benchmark_triple_integrator.cpp
+    are compiled where they lie, unedited, against this repository's include/ (the forwarding headers at the reference's include
+    paths).  The only things added are what the image lacks and the path does not need: a stand-in for the three fmt headers the
+    drivers include (fmt is not installed; the drivers only print with it) and a copy of the drivers' own perf/benchmarks.hpp
+    made at test time (it sits beside them in the reference and includes nothing but the solver headers).  Nothing of the
+    reference is committed here or travels to the GPU box, where this test is skipped."""
+    stub = tmp_path / "stub"
+    (stub / "fmt").mkdir(parents=True)
+    fmt_stub = ("#pragma once\n#include <string>\nnamespace fmt {\n"
+                "template <class... A> void print(const A&...) {}\n"
+                "template <class... A> std::string format(const A&...) { return {}; }\n}\n")
+    for name in ("format.h", "ostream.h", "chrono.h"):
+        (stub / "fmt" / name).write_text(fmt_stub)
+    (stub / "perf").mkdir()
+    (stub / "perf" / "benchmarks.hpp").write_text(open(os.path.join(REFERENCE, "perf", "benchmarks.hpp")).read())
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + INC, "-I" + str(stub), os.path.join(REFERENCE, "perf", driver)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]
 
 
 def test_perf_drivers_and_reference_gtests_compile():

@@ -72,24 +72,24 @@ def test_benchmark_expansions_driver():
 
 
 @pytest.mark.gpu
-def test_reference_call_style_program_runs(tmp_path):
-    """tests/cpp/reference_call_style.cpp -- the statements of the reference's perf drivers and problem factory, compiled
-    unedited (tests/test_facade_compile.py) -- solves what the reference's own tests say those calls solve:
-    example_unicycle_test.cpp:65-80 (50 iterations, 5 outer, kSolved), example_triple_integrator_test.cpp:16-70."""
-    exe = _build(os.path.join("tests", "cpp"), "reference_call_style")
+def test_pointer_api_driver_runs(tmp_path):
+    """tests/cpp/pointer_api_driver.cpp -- the repository's own driver of the facade's pointer-taking API (shared_ptr setters and
+    their vector overloads, the options the reference's drivers set, by-value trajectories, the profiler file) -- solves what the
+    reference's tests say these problems solve: example_unicycle_test.cpp:65-80 (50 iterations, 5 outer, kSolved),
+    example_triple_integrator_test.cpp:16-70 (2 iterations)."""
+    exe = _build(os.path.join("tests", "cpp"), "pointer_api_driver")
     r = subprocess.run([exe, "2", "4"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "SolveUnicycle: iters = 50, outer = 5, status = 0" in r.stdout, r.stdout
-    assert len(re.findall(r"Iteration \d+: Cost = [0-9.e+-]+, iters = 50,", r.stdout)) == 2, r.stdout
-    assert "SolveTripleIntegrator(0): iters = 2, status = 0" in r.stdout, r.stdout
-    assert re.search(r"SolveTripleIntegrator\(1\): iters = \d+, status = 0", r.stdout), r.stdout
-    assert re.search(r"DefineByPointers: iters = \d+, status = 0, constraints = 502, threads = 1", r.stdout), r.stdout
+    assert len(re.findall(r"three_obstacles\[\d\]: iterations 50 outer 5 status 0 ", r.stdout)) == 2, r.stdout
+    assert "triple_integrator[0]: iterations 2 outer" in r.stdout, r.stdout
+    assert re.search(r"triple_integrator_bounded\[0\]: iterations \d+ outer \d+ status 0 ", r.stdout), r.stdout
+    assert re.search(r"assembled_through_pointers\[0\]: iterations \d+ outer \d+ status 0 cost \S+ constraints 502 threads 1", r.stdout), r.stdout
+    assert "ALL SCENARIOS OK" in r.stdout
     # verbose = kDebug: the log of the solve (every column of solver_stats.cpp:80-116), printed after it
     assert re.search(r"iters\s+cost\s+viol\s+dJ\s+grad\s+alpha\s+reg\s+z\s+pen", r.stdout), r.stdout[:2000]
     # profiler_output_to_file: the tree of the solver's solves, written at its destruction (timer.cpp:10-14)
-    for name in ("profiler_unicycle.out", "profiler_unicycle-loop.out", "profiler_triple_integrator.out"):
-        text = (tmp_path / name).read_text()
-        assert "Description                  Time (us)   %Total  %Parent" in text and "backward_pass" in text, text
+    text = (tmp_path / "profiler_three_obstacles.out").read_text()
+    assert "Description                  Time (us)   %Total  %Parent" in text and "backward_pass" in text, text
 
 
 @pytest.mark.gpu
