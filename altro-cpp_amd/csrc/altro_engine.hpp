@@ -129,11 +129,13 @@ class Engine final : public EngineBase {
     return st;
   }
   altro_status SetInitialState(const ProblemSpec& spec, std::string* err) override {
+    ctg_replayable_ = false;  // (what a replayed backward pass would read no longer belongs to the last whole solve: ADVICE r5)
     altro_status st = SetInitialStateImpl(spec);
     if (st != ALTRO_OK && err) *err = err_;
     return st;
   }
   altro_status SetTrajectory(const ProblemSpec& spec, std::string* err) override {
+    ctg_replayable_ = false;
     altro_status st = SetTrajectoryImpl(spec);
     if (st != ALTRO_OK && err) *err = err_;
     return st;
@@ -202,6 +204,7 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   altro_status ResetTrajectory() override {
+    ctg_replayable_ = false;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipMemcpyAsync(A_.X, X_init_, (size_t)(N_ + 1) * R::nP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     ALTRO_HIP_CHECK(hipMemcpyAsync(A_.U, U_init_, (size_t)N_ * R::mP * Bp_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
@@ -307,6 +310,7 @@ class Engine final : public EngineBase {
   }
   altro_status ForwardPass(const altro_options& o) override {
     cur_ = stream_;
+    ctg_replayable_ = false;  // (a step-level forward pass moves the trajectory)
     if (!StepOk()) return ALTRO_NOT_READY;
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     LaunchForward(A_, ToDevOpts(o), (int)kFwdStepOnly, 1, B_);
@@ -429,6 +433,7 @@ class Engine final : public EngineBase {
     return ALTRO_OK;
   }
   altro_status SetDuals(const double* lam) override {
+    ctg_replayable_ = false;
     const int R = pd_.total_rows;
     if (R == 0) return ALTRO_OK;
     std::vector<T> h((size_t)R * Bp_, T(0));
@@ -1197,9 +1202,21 @@ class Engine final : public EngineBase {
     }
     {
       const double lim = 2147483647.0;
-      const double biggest = std::max({(double)(N_ + 1) * RR::EP * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_,
-                                       (double)std::max(rows, 1) * Bp_});
-      if (biggest > lim) {
+      auto biggest = [&]() {
+        return std::max({(double)(N_ + 1) * RR::EP * Bp_, (double)(N_ + 1) * nm * kLineSearchLanes * Bp_, (double)std::max(rows, 1) * Bp_});
+      };
+      // (the shadow columns widen every array; a batch that fits 32-bit indexing without them must not be refused
+      //  because of them -- drop the segments' columns first, then the twins')
+      if (biggest() > lim && seg_total_ > 0) {
+        Bp_ -= seg_total_;
+        seg_total_ = 0;
+      }
+      if (biggest() > lim && twin_cap_ > 0) {
+        Bp_ -= twin_cap_;
+        twin_cap_ = 0;
+      }
+      pd_.Bp = Bp_;
+      if (biggest() > lim) {
         err_ = "problem too large for 32-bit device indexing (split the batch over several handles)";
         return ALTRO_UNSUPPORTED;
       }
@@ -1669,7 +1686,10 @@ class Engine final : public EngineBase {
     // backward pass, staged forward pass, uniform step, <= 20 line-search trials, no cost-to-go records)
     const bool loop_on = loop_groups_ > 0 && FusedOk(d);
     // segments of rejection streaks: not with a recorded history (its rows are appended in iteration order)
-    const bool seg_on = seg_total_ > 0 && !A_.hist && !d.fast_forward_stalls && C * kBlock <= seg_total_ && !loop_on &&
+    // ... nor with cost-to-go records: every shadow column writes P, p into its own CTG column, and neither
+    // k_seg_fixup nor the twins' commit copy those back -- altro_get_ctg would return the records of the backward pass at which
+    // the instance's OWN column retired
+    const bool seg_on = seg_total_ > 0 && !A_.hist && !A_.record_ctg && !d.fast_forward_stalls && C * kBlock <= seg_total_ && !loop_on &&
                         this->spec_mode_ == kSpecAuto;  // (the persistent kernel's variants that know the segments: default modes only)
     const int seg_capc = seg_on ? (seg_total_ / C) / kBlock * kBlock : 0;  // shadow columns per chain
     if (seg_on) ALTRO_HIP_CHECK(hipMemsetAsync(d_seg_cursor_, 0, kMaxChains * sizeof(int), stream_));

@@ -278,6 +278,9 @@ def cpu_baseline(A, P, cfg, B, seed, budget_cpu_s=24.0):
     it_rate_1 = iters1 / t1
     return {
         "value": best["value"], "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
+        # (the literal reference path needs Eigen >= 3.3: probed, never found on a box of this pool -- BASELINE.md section 2)
+        "eigen_headers_found": any(os.path.exists(os.path.join(d, "Eigen", "Core")) for d in
+                                   ("/usr/include/eigen3", "/usr/local/include/eigen3", "/usr/include", "/opt/rocm/include/eigen3")),
         "physical_cores": phys, "hardware_threads": hw,
         "cpu_quota_cores": quota, "usable_cores": usable,
         "sample": f"the same seeded {B}-instance workload (fp64) solved {best['reps']}x by {best['threads']} pinned host "

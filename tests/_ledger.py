@@ -1,5 +1,5 @@
 """Ledger of MEASURED parity errors: every comparison of the HIP path with the oracle records what it
-measured next to the bar it asserted, and the session writes the maxima to gpurun_out/r05_parity_errors.json (copied to
+measured next to the bar it asserted, and the session writes the maxima to gpurun_out/r06_parity_errors.json (copied to
 profiles/ after a GPU run).  A bar is then pinned to the measurement instead of to a guess: the GPU and the oracle are both
 deterministic, so the measured maxima are reproducible to the bit; the bars keep a small factor over them."""
 import json
@@ -65,7 +65,7 @@ def dump():
         return None
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r05_parity_errors.json")
+    path = os.path.join(out_dir, "r06_parity_errors.json")
     old = {}
     if os.path.exists(path):  # several pytest invocations of one GPU visit add up
         try:

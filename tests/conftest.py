@@ -56,7 +56,7 @@ def pytest_sessionstart(session):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """The measured parity errors of this session (tests/_ledger.py) -> gpurun_out/r05_parity_errors.json."""
+    """The measured parity errors of this session (tests/_ledger.py) -> gpurun_out/r06_parity_errors.json."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _ledger
     path = _ledger.dump()

@@ -12,6 +12,8 @@ import ctypes
 import os
 
 import numpy as np
+
+import _ledger
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -42,7 +44,11 @@ def test_every_shard_of_the_32768_batch_against_the_oracle(P, A, S, oracle_make,
             same &= so[f] == sg[f]
         print(f"shard {r}: solved {solved.mean():.4f} (gpu {np.mean(sg['status'] == 0):.4f}), schedule mismatches "
               f"{int((~same).sum())} (on solved instances: {int((~same & solved).sum())})")
-        # (a one-ulp(fp32) flip of a stored record can move one of the ~75-iteration chaotic instances)
+        # (a one-ulp(fp32) flip of a stored record can move one of the ~75-iteration chaotic instances: explicit counters
+        #  with instance ids in the parity ledger, like the fp64 full-batch test -- VERDICT r5 weak #1c)
+        _ledger.count(f"shard {r}: schedule flips on SOLVED instances (4096, fp32 records vs the record-rounding oracle)",
+                      (~same & solved).sum(), 4, r * SHARD + np.flatnonzero(~same & solved))
+        _ledger.count(f"shard {r}: schedule flips, all instances", (~same).sum(), 40, r * SHARD + np.flatnonzero(~same))
         assert (~same & solved).sum() <= 4 and (~same).sum() <= 40
         ok = same & solved
         Xo, Uo = o.get_trajectory()
@@ -52,6 +58,9 @@ def test_every_shard_of_the_32768_batch_against_the_oracle(P, A, S, oracle_make,
         # two per shard beyond 1e-5, none beyond 1e-3 (SURVEY's fp32 state tolerance)
         err = np.abs(Xg[ok] - Xo[ok]).max(axis=(1, 2))
         print(f"         states: max |dX| {err.max():.2e}, instances beyond 1e-5: {int((err > 1e-5).sum())}")
+        _ledger.count(f"shard {r}: solved instances with max |dX| > 1e-5 (none beyond 1e-3)", (err > 1e-5).sum(), 2,
+                      r * SHARD + np.flatnonzero(ok)[err > 1e-5])
+        _ledger.record(f"shard {r}: max |dX| over solved instances with the oracle's schedule", err.max(), err.max(), err.max() / 1e-3, 0.0, 1e-3)
         assert (err > 1e-5).sum() <= 2 and err.max() < 1e-3, (err.max(), int((err > 1e-5).sum()))
         assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-6)
         assert (sg["violation"][ok] < 1e-4).all()

@@ -40,6 +40,11 @@ def test_pendulum_on_the_oracle(A, P, pend_oracle):
     assert (np.abs(X[ok][:, -1, 0] - np.linspace(0.3, 1.0, 8)[ok]) < 1e-3).all()
 
 
+# norm-wise bars of the gain comparison (set from profiles/r06_parity_errors.json, a small factor over the measured maxima)
+BAR_K_SHORT = {"F64": 1e-8, "F32": 1e-8}
+BAR_K_LONG = 1e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,batch", [("F64", 48), ("F32", 48), ("F64", 1536)])
 def test_pendulum_matches_the_oracle(A, P, hip_make, pend_oracle, dtype_name, batch):
@@ -70,7 +75,18 @@ def test_pendulum_matches_the_oracle(A, P, hip_make, pend_oracle, dtype_name, ba
     assert np.allclose(Ug[ok], Uo[ok], rtol=10 * tol, atol=10 * tol), np.abs(Ug[ok] - Uo[ok]).max()
     Ko, do_ = o.get_gains()
     Kg, dg = g.get_gains()
-    assert np.allclose(Kg[ok], Ko[ok], rtol=1e-5, atol=1e-7)
+    # gains, norm-wise per instance (VERDICT r5 weak #1b: the bar follows the measurement, tests/_ledger.py).  Two populations: the
+    # instances that converge in a few dozen iterations, and -- only in the 1536 batch -- the ones that iterate 100+ times,
+    # whose last backward pass runs on a trajectory that ~100 accepted / rejected steps have moved apart by 1e-10 ... 1e-8
+    # (X above) under penalties up to 1e8: their gains are DEFINED to ~1e-5 (the oracle against itself with a goal moved by
+    # one ulp moves them as much, test_parity_gpu.py::_config5_sensitivity is the same argument for the 12-state model).
+    import _ledger
+    short = ok & (so["iterations_total"] <= 40)
+    long_ = ok & ~short
+    if short.any():
+        _ledger.close_normwise(Kg[short], Ko[short], BAR_K_SHORT[dtype_name], f"pendulum {dtype_name} {batch}: K, instances of <= 40 iterations")
+    if long_.any():
+        _ledger.close_normwise(Kg[long_], Ko[long_], BAR_K_LONG, f"pendulum {dtype_name} {batch}: K, instances of > 40 iterations")
     assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-7)
 
 
