@@ -1251,7 +1251,7 @@ class Engine final : public EngineBase {
       ALTRO_ALLOC(kd, (size_t)N_ * RR::KP * bp);
       A_.KD = kd;
     }
-    ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp);
+    ALTRO_ALLOC(A_.CTG, (size_t)(N_ + 1) * R::CP * bp + kBlock);  // (+ the junk sink of the recording backward pass)
     ALTRO_HIP_CHECK(hipMalloc((void**)&A_.trial, (size_t)(N_ + 1) * nm * kLineSearchLanes * bp * sizeof(T)));
     allocs_.push_back((void*)A_.trial);
     if (poison_on_) {
@@ -1408,8 +1408,10 @@ class Engine final : public EngineBase {
       // LDS plan of the forward pass: up to 3 instances per wavefront, at most 80 KiB per workgroup
       // (two workgroups per CU); if even one instance does not fit in 160 KiB, read from HBM instead.
       auto padv = [](size_t e) { return (e + R::V - 1) / R::V * R::V; };
-      const size_t per_inst = ((size_t)(N_ + 1) * R::nP + (size_t)N_ * R::mP + (size_t)N_ * R::KP +
-                               2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T);
+      // (+ the optional padding between the instances' blocks of a workgroup: FwdLds::total)
+      auto padded = [](size_t bytes) { return bytes + (size_t)fwd_block_pad_bytes((long long)bytes); };
+      const size_t per_inst = padded(((size_t)(N_ + 1) * R::nP + (size_t)N_ * R::mP + (size_t)N_ * R::KP +
+                                      2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T));
       const int lanes_max = kBlock / kLineSearchLanes;
       fwd_per_wave_ = lanes_max;
       while (fwd_per_wave_ > 1 && fwd_per_wave_ * per_inst > 80 * 1024) fwd_per_wave_--;
@@ -1432,7 +1434,7 @@ class Engine final : public EngineBase {
         // Small models: the rollout wave reads (xbar, ubar, K, d) from global memory two knots ahead; LDS keeps only the
         // multipliers and the parameters, so that four workgroups (the register limit) instead of two share a CU.
         // Needs the winner-only gradient measure of phase 2, whose terms live in the hand-off slots.
-        const size_t per_inst_g = (2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T);
+        const size_t per_inst_g = padded((2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T));
         // Taken when it lets more instances be resident on a CU than the fully staged variant: workgroups per CU =
         // min(LDS limit, register limit: waves per SIMD of the kernel * 4 SIMDs / 3 waves).  Config 3 (fp32 records: 152
         // VGPRs, three waves per SIMD): 6 -> 9 instances, -7 % per forward sweep; config 2 (fp64 records in flight: 171
@@ -1467,7 +1469,8 @@ class Engine final : public EngineBase {
         // Models whose gain records fill the LDS (12-state model: 83 of 134 KB per instance -> one instance per CU):
         // keep only d in LDS, let the rollout wave read K from global memory one knot ahead, and put up to three
         // instances into one workgroup (one workgroup per CU, 160 KiB)
-        const size_t per_inst_b = per_inst - (size_t)N_ * R::KP * sizeof(T) + (size_t)N_ * R::mP * sizeof(T);
+        const size_t per_inst_b = padded(((size_t)(N_ + 1) * R::nP + (size_t)N_ * R::mP + (size_t)N_ * R::mP +
+                                          2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T));
         int pw_b = lanes_max;
         while (pw_b > 1 && shared_bytes + pw_b * per_inst_b > 160 * 1024) pw_b--;
         if (shared_bytes + per_inst > 80 * 1024 && pw_b > 1 && !std::getenv("ALTRO_HIP_NO_KDG")) {

@@ -800,7 +800,11 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
   // The gains are collected in LDS and written out in bulk: a store in the loop would share the memory
   // counter with the prefetched tiles (loads and stores retire out of order with respect to each
   // other), and every wait on a tile would have to drain the whole queue.
-  T* const sink = A.trial + lane;  // CTG build only: junk sink of the lanes that own no element
+  // CTG build only: junk sink of the lanes that own no element -- 64 elements behind the last cost-to-go record (round 6: it
+  // used to be the first 64 elements of the line-search candidates, i.e. instance 0's; with several chains of sweeps another
+  // chain's backward pass then overwrote candidates that chain 0's forward pass was about to read -- instance 0 of a batch
+  // of >= 2048 solved with altro_set_record_ctg(1) took 119 iterations instead of 11)
+  T* const sink = A.CTG + (size_t)(unsigned)(N + 1) * Bp * R::CP + lane;
   while (__ballot(need) != 0ull) {
     if (!primed) prime();  // restart after a failed factorisation
     primed = false;
@@ -2126,12 +2130,29 @@ ALTRO_DEV void rollout_run(const Ctx& C, const ProblemDesc* pd, const DevArrays<
   }
 }
 
+// DISTANCE BETWEEN THE STAGED BLOCKS OF A WORKGROUP'S INSTANCES (round 6).  The lanes of a wave read the
+// staged block 20 per address, three addresses per wave (one per instance), the blocks `total()` elements apart.  The LDS has
+// 64 banks of 4 bytes (256 B), and what SQ_LDS_BANK_CONFLICT counts for that pattern depends on the distance modulo 256 B
+// (scripts/probes/lds_conflict_probe.hip, profiles/r06_lds_conflict_probe.txt): 32 B -- the unicycle's 17 696 B block with
+// fp64 records, config 2 -- 1.86 / 2.78 conflict cycles per b64 / b128 read, 0 B 2.78 / 4.64, 128 B 0.93, but 64, 96 and
+// 160 B none; config 3 stages nothing but the multipliers (kSrcGlb) and counts none.  The block is padded to
+// ALTRO_FWD_BLOCK_MOD = 160 B modulo 256 (the engine sizes the allocation with the same function; -1: no padding, rounds 1 - 5).
+// What it buys is LDS issue slots, not time -- a lone wave reads at the same pace with and without the counted conflicts, and
+// the A/B on the real kernel is neutral (6.09 - 6.19 against 6.15 - 6.20 ms per step; 96 B, equally conflict-free in the
+// probe, is 5 % SLOWER: profiles/r06_experiments.txt #5).
+#ifndef ALTRO_FWD_BLOCK_MOD
+#define ALTRO_FWD_BLOCK_MOD 160
+#endif
+__host__ __device__ constexpr int fwd_block_pad_bytes(long long raw_bytes) {
+  return ALTRO_FWD_BLOCK_MOD < 0 ? 0 : (int)(((ALTRO_FWD_BLOCK_MOD - raw_bytes % 256) + 256) % 256);
+}
 template <class T>
 struct FwdLds {  // element counts of one instance's staged block (16-byte aligned sub-blocks)
   int nX, nU, nKD, nR, nS, V;
   ALTRO_DEV int padv(int e) const { return (e + V - 1) / V * V; }
   ALTRO_DEV int rowsP() const { return padv(nR); }
-  ALTRO_DEV int total() const { return nX + nU + nKD + 2 * padv(nR) + padv(nS); }
+  ALTRO_DEV int raw() const { return nX + nU + nKD + 2 * padv(nR) + padv(nS); }
+  ALTRO_DEV int total() const { return raw() + fwd_block_pad_bytes((long long)raw() * (long long)sizeof(T)) / (int)sizeof(T); }
 };
 
 // Single-wave forward pass that reads everything from global memory: the fallback when the staged block of

@@ -64,6 +64,21 @@ int main() {
   run<16, 16, 1>("b128, consecutive lanes (staging writes' pattern)", d_out);
   run<16, 17696, 20>("b128, 20 lanes per address, instances 17696 B apart (nominal knot)", d_out);
   run<4, 4, 1>("b32, consecutive lanes", d_out);
+  // round 6: can a different distance between the instances' staged blocks remove the counted conflicts of
+  // "20 lanes per address, three addresses per wave"?  Distances that put the three addresses on other banks / bank groups:
+  run<8, 17696 + 8, 20>("b64, 20 lanes per address, instances 17704 B apart", d_out);
+  run<8, 17696 + 32, 20>("b64, 20 lanes per address, instances 17728 B apart", d_out);
+  run<8, 17696 + 64, 20>("b64, 20 lanes per address, instances 17760 B apart", d_out);
+  run<8, 17696 + 96, 20>("b64, 20 lanes per address, instances 17792 B apart", d_out);
+  run<8, 17696 + 128, 20>("b64, 20 lanes per address, instances 17824 B apart", d_out);
+  run<8, 17696 + 224, 20>("b64, 20 lanes per address, instances 17920 B apart (multiple of 256)", d_out);
+  run<8, 17696, 32>("b64, 32 lanes per address (two addresses per wave, one per half)", d_out);
+  run<8, 17696, 64>("b64, all 64 lanes on one address", d_out);
+  run<8, 17696, 16>("b64, 16 lanes per address (four addresses per wave)", d_out);
+  run<16, 17696 + 64, 20>("b128, 20 lanes per address, instances 17760 B apart", d_out);
+  run<16, 17696 + 224, 20>("b128, 20 lanes per address, instances 17920 B apart", d_out);
+  run<16, 17696, 32>("b128, 32 lanes per address", d_out);
+  run<16, 17696, 64>("b128, all 64 lanes on one address", d_out);
   hipDeviceSynchronize();
   hipFree(d_out);
   return 0;

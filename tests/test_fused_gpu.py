@@ -420,3 +420,40 @@ def test_device_side_sweep_loop_is_bit_identical(tmp_path):
             if k.endswith("_tm"):
                 continue
             assert np.array_equal(ref[k], got[k], equal_nan=True), (tag, k)
+
+
+_SCRIPT_CTG_CHAINS = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+s = P.batch_turn90(make, batch=2304, seed=P.SEED_BASE + 3)
+if sys.argv[2] == "record":
+    s.set_record_ctg(True)
+s.solve()
+st = s.get_stats()
+X, U = s.get_trajectory()
+Pc, pc = s.get_ctg()
+tm = s.get_timing()
+np.savez(sys.argv[1], X=X, U=U, P=Pc, p=pc, it=st["iterations_total"], status=st["status"], launches=np.array([tm["sweep_launches"], tm["fused_sweeps"]]))
+'''
+
+
+def test_recording_the_cost_to_go_with_four_chains_of_sweeps(tmp_path):
+    """altro_set_record_ctg(1) on a batch that runs as FOUR chains of sweeps (the first large handle of a process): the
+    recording backward pass (k_backward_mfma<.., CTG>) of one chain runs beside the forward passes of the others, and must
+    write nothing outside its own cost-to-go records.  Round 6 found its junk sink aliased on instance 0's line-search
+    candidates (instance 0: 119 iterations instead of 11).  Statistics, trajectories and P, p must be those of the default
+    solve (persistent kernel + replayed backward pass)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag in ("default", "record"):
+        out = str(tmp_path / f"ctg_{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_CTG_CHAINS % root, out, tag], check=True, env=dict(os.environ, ALTRO_HIP_CHAINS="4"), timeout=600)
+        res[tag] = np.load(out)
+    a, b = res["default"], res["record"]
+    assert b["launches"][1] == 0 and b["launches"][0] > 4 * 100    # four chains swept to the end, no persistent kernel
+    for k in ("it", "status", "X", "U", "P", "p"):
+        assert np.array_equal(a[k], b[k]), (k, np.flatnonzero((a[k] != b[k]).reshape(len(a[k]), -1).any(axis=1))[:8])
