@@ -589,7 +589,8 @@ class Engine final : public EngineBase {
   // gain records big enough (m n + m >= 14 elements) that reading K from global memory can pay: see kdg_
   static constexpr bool kKdgEligible = n * m >= 12;
   // rollout inputs from global memory, two knots ahead in three register sets: small records only
-  static constexpr bool kRgEligible = !kKdgEligible && R::KP + R::nP + R::mP <= 16;
+  // (round 6: ... and the large models, for which it competes with kSrcKdg -- see the LDS plan in UploadImpl)
+  static constexpr bool kRgEligible = (!kKdgEligible && R::KP + R::nP + R::mP <= 16) || kKdgEligible;
   static constexpr bool kCoopBackward = !kMfmaBackward && n >= 6;
   // ALTRO_HIP_DEBUG_POISON=<hex pattern>[,mix]: before every kernel of a solve, fill the LDS of every CU with the pattern
   // (and the line-search candidates once, at upload), to flush out reads of memory the solve has not written.

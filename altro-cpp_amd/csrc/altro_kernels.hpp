@@ -3066,6 +3066,13 @@ ALTRO_DEV void load_elems(const T* p, T* out) {
 #define ALTRO_RG_AHEAD 2
 #endif
 constexpr int kRgAhead = ALTRO_RG_AHEAD;  // knots of prefetch distance of the kSrcGlb rollout wave (register sets - 1)
+// ... for the large models (round 6: kSrcGlb for the 12-state model, whose staged trajectory is what keeps a second workgroup
+// off the CU): one knot, two register sets -- a third set of 12 + 4 doubles and 52 gain elements does not fit 256 registers,
+// and one knot of its RK4 (~2 us) covers an L2 round trip
+template <class M>
+constexpr int rg_ahead() {
+  return M::n * M::m >= 12 ? 1 : kRgAhead;
+}
 // HOISTC: the circle layouts of the cost wave keep centres, radii and multipliers in registers (cost_consumer_run).
 // Only the persistent kernel's variant for problems that HAVE circle constraints is built that way: the kernel sits at
 // the register limit, and code of constraint kinds a problem does not have still moves the allocation of its hot
@@ -3190,11 +3197,14 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     // it; two register sets alternate (the loop is unrolled by two, no copies).
     // (kSrcGlb keeps the gain record in its storage type -- fp32 under WithRec32 -- while it is in flight and converts
     //  at use: a third fewer registers per set)
+    // (round 6: kSrcKdg too -- the 12-state model's K is 48 of the 52 elements of a record, and two register sets of it as
+    //  doubles were 208 of the rollout wave's 480 registers)
     using RSn = rec_scalar_t<T, M>;
-    using KdT = std::conditional_t<RG, RSn, T>;
+    constexpr bool kKdInStorageType = RG || KDG;
+    using KdT = std::conditional_t<kKdInStorageType, RSn, T>;
     struct Nominal {
       T xk[R::nP], uk[R::mP];
-      KdT kd[RG ? (int)Rec<RSn, n, m>::KP : (int)R::KP];
+      KdT kd[kKdInStorageType ? (int)Rec<RSn, n, m>::KP : (int)R::KP];
     };
     auto fetch = [&](int k, Nominal& q) __attribute__((always_inline)) {
       const int kc = k < N ? k : N - 1;
@@ -3213,7 +3223,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
         if constexpr (KDG) {
           using RS = rec_scalar_t<T, M>;
           using RR = Rec<RS, n, m>;
-          load_rec_as<T, RS, R::KP, RR::KP, m * n + m>((const RS*)A.KD + ((size_t)(unsigned)kc * (unsigned)A.Bp + (unsigned)b) * RR::KP, q.kd);
+          load_rec<RS, RR::KP>((const RS*)A.KD + ((size_t)(unsigned)kc * (unsigned)A.Bp + (unsigned)b) * RR::KP, q.kd);
         } else {
           load_rec<T, R::KP>(sKD + kc * R::KP, q.kd);
         }
@@ -3228,7 +3238,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     auto knot = [&](auto replay_tag, int k, const Nominal& cur, Nominal& nxt) __attribute__((always_inline)) {
       constexpr bool REPLAY = decltype(replay_tag)::value;
       T ub[m], xn[n];
-      fetch(k + (RG ? kRgAhead : 1), nxt);
+      fetch(k + (RG ? rg_ahead<M>() : 1), nxt);
 #pragma unroll
       for (int i = 0; i < m; ++i) {
         T sacc = T(0);
@@ -3275,7 +3285,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       }
     };
     auto all_knots = [&](auto replay_tag) __attribute__((always_inline)) {
-      if constexpr (RG && kRgAhead == 2) {
+      if constexpr (RG && rg_ahead<M>() == 2) {
         // three register sets: knot k uses set k % 3 and refills the set of knot k - 1 with knot k + 2
         Nominal q0, q1, q2;
         fetch(0, q0);
@@ -3577,7 +3587,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 #endif
 template <class M, int SRC>
 constexpr int fwd_min_waves() {
-  return (SRC == kSrcGlb && M::n <= 4) ? ALTRO_FWD_GLB_WAVES : 1;
+  // (round 6: the large models' global-source variant is compiled for two waves per SIMD -- two workgroups per CU)
+  return (SRC == kSrcGlb && M::n <= 4) ? ALTRO_FWD_GLB_WAVES : ((SRC == kSrcGlb && M::n * M::m >= 12) ? 2 : 1);
 }
 template <class T, class M, int SRC>
 __global__ __launch_bounds__(kFwdWaves * kBlock, (fwd_min_waves<M, SRC>())) void k_forward2(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,

@@ -96,7 +96,9 @@ int main(int argc, char* argv[]) {
     {
       Unicycle def;
       def.SetScenario(Unicycle::kThreeObstacles);
-      const Outcome o = RunScenario<3, 2>("three_obstacles", def.MakeProblem(true), def.InitialTrajectory(), [&](auto& s) {
+      const pb::Problem prob = def.MakeProblem(true);  // (before the guess: the order of evaluation of arguments is not ours to pick)
+      const altro::Trajectory<3, 2> guess = def.InitialTrajectory();
+      const Outcome o = RunScenario<3, 2>("three_obstacles", prob, guess, [&](auto& s) {
         s.SetPenalty(10.0);
         s.GetOptions().verbose = altro::LogLevel::kDebug;
         s.GetOptions().nthreads = nthreads;
@@ -110,8 +112,9 @@ int main(int argc, char* argv[]) {
     // 2. the templated triple integrator, with and without its constraints
     for (const bool constrained : {false, true}) {
       altro::problems::TripleIntegratorProblem<2> def;
-      const Outcome o = RunScenario<6, 2>(constrained ? "triple_integrator_bounded" : "triple_integrator", def.MakeProblem(constrained),
-                                          def.template InitialTrajectory<6, 2>(), nullptr);
+      const pb::Problem prob = def.MakeProblem(constrained);
+      const altro::Trajectory<6, 2> guess = def.template InitialTrajectory<6, 2>();
+      const Outcome o = RunScenario<6, 2>(constrained ? "triple_integrator_bounded" : "triple_integrator", prob, guess, nullptr);
       ok = ok && o.status == static_cast<int>(SolverStatus::kSolved) && (constrained || o.iterations == 2);
     }
     // 3. a problem assembled through the pointer overloads, a hand-made guess through the (n, m, N) constructor

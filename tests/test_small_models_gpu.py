@@ -40,9 +40,7 @@ def test_pendulum_on_the_oracle(A, P, pend_oracle):
     assert (np.abs(X[ok][:, -1, 0] - np.linspace(0.3, 1.0, 8)[ok]) < 1e-3).all()
 
 
-# norm-wise bars of the gain comparison (set from profiles/r06_parity_errors.json, a small factor over the measured maxima)
-BAR_K_SHORT = {"F64": 1e-8, "F32": 1e-8}
-BAR_K_LONG = 1e-4
+BAR_K = 1e-7  # norm-wise bar of the gain comparison: ~6 x the measured maximum (profiles/r06_parity_errors.json)
 
 
 @pytest.mark.gpu
@@ -75,18 +73,11 @@ def test_pendulum_matches_the_oracle(A, P, hip_make, pend_oracle, dtype_name, ba
     assert np.allclose(Ug[ok], Uo[ok], rtol=10 * tol, atol=10 * tol), np.abs(Ug[ok] - Uo[ok]).max()
     Ko, do_ = o.get_gains()
     Kg, dg = g.get_gains()
-    # gains, norm-wise per instance (VERDICT r5 weak #1b: the bar follows the measurement, tests/_ledger.py).  Two populations: the
-    # instances that converge in a few dozen iterations, and -- only in the 1536 batch -- the ones that iterate 100+ times,
-    # whose last backward pass runs on a trajectory that ~100 accepted / rejected steps have moved apart by 1e-10 ... 1e-8
-    # (X above) under penalties up to 1e8: their gains are DEFINED to ~1e-5 (the oracle against itself with a goal moved by
-    # one ulp moves them as much, test_parity_gpu.py::_config5_sensitivity is the same argument for the 12-state model).
+    # gains, norm-wise per instance (VERDICT r5 weak #1b: the bar follows the measurement, tests/_ledger.py -> profiles/r06_parity_errors.json).
+    # Measured: 8.2e-13 (batch 48), 1.7e-8 (batch 1536: |dK| 1.05e-5 on gains of ~600 -- the old bar, rtol 1e-5 elementwise, was three
+    # orders of magnitude wider than that), 0 against the record-rounding oracle with fp32 records.
     import _ledger
-    short = ok & (so["iterations_total"] <= 40)
-    long_ = ok & ~short
-    if short.any():
-        _ledger.close_normwise(Kg[short], Ko[short], BAR_K_SHORT[dtype_name], f"pendulum {dtype_name} {batch}: K, instances of <= 40 iterations")
-    if long_.any():
-        _ledger.close_normwise(Kg[long_], Ko[long_], BAR_K_LONG, f"pendulum {dtype_name} {batch}: K, instances of > 40 iterations")
+    _ledger.close_normwise(Kg[ok], Ko[ok], BAR_K, f"pendulum {dtype_name} {batch}: K of the solved instances")
     assert np.allclose(sg["cost"][ok], so["cost"][ok], rtol=1e-7)
 
 
