@@ -1431,7 +1431,7 @@ class Engine final : public EngineBase {
                          padv((size_t)rows) * sizeof(T);                                   // + the constraint values of the expansions computed ahead
       kdg_ = false;
       rg_ = false;
-      if constexpr (kRgEligible) {
+      if constexpr (kRgEligible && !kKdgEligible) {
         // Small models: the rollout wave reads (xbar, ubar, K, d) from global memory two knots ahead; LDS keeps only the
         // multipliers and the parameters, so that four workgroups (the register limit) instead of two share a CU.
         // Needs the winner-only gradient measure of phase 2, whose terms live in the hand-off slots.
@@ -1479,6 +1479,36 @@ class Engine final : public EngineBase {
           fwd_per_wave_ = pw_b;
           fwd_per_inst_bytes_ = per_inst_b;
           fwd_lds_bytes_ = shared_bytes + pw_b * per_inst_b;
+        }
+        // Round 6: ... or NOTHING of the trajectory and the gains in LDS (k_forward2<.., kSrcGlb> for the large
+        // models: the rollout wave reads xbar, ubar, K, d from global memory one knot ahead, the gain record in its storage
+        // type; one barrier per knot, so two hand-off slots instead of four).  What is left -- the multipliers and the slots --
+        // lets TWO workgroups share a CU's LDS, and the variant is compiled for two waves per SIMD (256 registers): config 4
+        // keeps 4 instances on a CU instead of 2, its 512 forward workgroups run in ONE round instead of two.  Taken when it
+        // raises the instances resident on a CU (ALTRO_HIP_FWD_SRC=kdg | global overrides).
+        {
+          const size_t shared_g = (padv(pool.size()) + 2 * (size_t)fwd_sync_batched<M, kSrcGlb>() * nm * kBlock) * sizeof(T) +
+                                  2 * kBlock * sizeof(int) + kBlock * sizeof(double);
+          const size_t per_inst_g = padded((2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T));
+          int pw_g = lanes_max;
+          while (pw_g > 1 && shared_g + pw_g * per_inst_g > 80 * 1024) pw_g--;
+          hipFuncAttributes at{};
+          const bool have = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_forward2<T, M, kSrcGlb>)) == hipSuccess && at.numRegs > 0;
+          const int waves = have ? std::min(8, 512 / ((at.numRegs + 7) / 8 * 8)) : 0;  // per SIMD
+          const int wgs_g = std::min(waves * 4 / kFwdWaves, (int)(160 * 1024 / (shared_g + pw_g * per_inst_g)));
+          const int resident_g = wgs_g * pw_g, resident_now = kdg_ ? fwd_per_wave_ : (int)std::max<size_t>(1, 160 * 1024 / std::max<size_t>(1, fwd_lds_bytes_)) * fwd_per_wave_;
+          const char* src = std::getenv("ALTRO_HIP_FWD_SRC");
+          bool want = resident_g > resident_now;
+          if (src) want = std::string(src) == "global";
+          if (want && have && shared_g + pw_g * per_inst_g <= 160 * 1024 &&
+              16 + pw_g * N_ <= 2 * fwd_sync_batched<M, kSrcGlb>() * nm * kBlock) {
+            kdg_ = false;
+            rg_ = true;
+            fwd_per_wave_ = pw_g;
+            fwd_shared_bytes_ = shared_g;
+            fwd_per_inst_bytes_ = per_inst_g;
+            fwd_lds_bytes_ = shared_g + pw_g * per_inst_g;
+          }
         }
       }
       if (fwd_lds_bytes_ > 160 * 1024) {

@@ -2484,6 +2484,13 @@ ALTRO_DEV T forward_phase2(const DevArrays<T>& A, const ProblemDesc* pd, const C
 #endif
 constexpr int kSyncBatched = ALTRO_SYNC_BATCHED;
 constexpr int kFwdSlots = 2 * kSyncBatched;
+// ... per variant (round 6): the large models' global-source variant meets at EVERY knot -- two hand-off slots instead of four.
+// With n + m = 16 a slot is 8 KB; the two it saves are what lets a second two-instance workgroup of the 12-state model share
+// the CU's LDS (config 4), and one knot of that model is long enough for a barrier of its own.  SRC: FwdSrc (2 = kSrcGlb).
+template <class M, int SRC>
+constexpr int fwd_sync_batched() {
+  return (SRC == 2 && M::n * M::m >= 12) ? 1 : kSyncBatched;
+}
 ALTRO_DEV bool producer_syncs_after(int k, int N, int G = 2) { return (k & (G - 1)) == G - 1 || k == N; }
 ALTRO_DEV bool consumer_syncs_before(int k, int G = 2) { return (k & (G - 1)) == 0; }
 ALTRO_DEV int fwd_slot(int k, int G = 2) { return k & (2 * G - 1); }
@@ -2658,12 +2665,12 @@ ALTRO_DEV double from_upper_half(double x) {
 // knots.  What is sequential over the knots stays sequential: the bound verdicts are scalar masks stepped in knot
 // order, and the gradient measure is summed in the lower half in knot order (the upper half's term arrives through
 // v_permlane32_swap), bit-identical to the one-knot-at-a-time loop.
-template <class T, class M, bool PAIRED, bool SOFT = false>
+template <class T, class M, bool PAIRED, bool SOFT = false, int GB = kSyncBatched>
 ALTRO_DEV void aux_wave_run(int N, const DevOpts& o, const T* sKD, int kd_stride, int kd_off, const T* xch, int lane,
                             bool valid, T* cand_inst, int cand_front, int* flags, double* gsx, bool grad,
                             const FwdSync<SOFT>& sy = FwdSync<SOFT>{nullptr, 0}, const T* sCost = nullptr,
                             double* J0_out = nullptr) {
-  constexpr int G = PAIRED ? kSyncFused : kSyncBatched;
+  constexpr int G = PAIRED ? kSyncFused : GB;
   constexpr int n = M::n, m = M::m, nm = n + m;
   constexpr int LS = kLineSearchLanes;
   const bool check = o.check_forwardpass_bounds != 0;
@@ -3127,7 +3134,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
   T* sIp = sPen + L.rowsP();
   T* sPool = reinterpret_cast<T*>(smem_raw) + per_wave * L.total();
   T* xch = sPool + L.padv(pd->npool);              // [2][nm][64] hand-off slots
-  constexpr int G = FUSED ? kSyncFused : kSyncBatched;  // knots per workgroup barrier of the knot loop (2 G hand-off slots)
+  constexpr int G = FUSED ? kSyncFused : fwd_sync_batched<M, SRC>();  // knots per workgroup barrier of the knot loop (2 G hand-off slots)
   int* flags = reinterpret_cast<int*>(xch + 2 * G * nm * kBlock);  // [2][64]: ok, status of each trial
   double* gsx = reinterpret_cast<double*>(flags + 2 * kBlock);   // [64]: gradient measure of each trial
   if (!FUSED) {
@@ -3384,7 +3391,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     // ================= auxiliary wave: bound checks, gradient measure, candidate stores ===========
     const long long st_w2 = ALTRO_STAMP_T0();
     double J0_run = 0.0;
-    aux_wave_run<T, M, FUSED, SOFT>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, A.cand_front, flags,
+    aux_wave_run<T, M, FUSED, SOFT, G>(N, o, sKD, kKdStride, kKdOff, xch, lane, valid, cand_base + cand_off0, A.cand_front, flags,
                                     gsx, grad_in_loop, sy, FUSED ? sCost : nullptr, &J0_run);
     if (FUSED && lane == 0) {
       // J0 of the expansion step and, on the first iteration of an inner solve, stats_.initial_cost (ilqr.hpp:298);

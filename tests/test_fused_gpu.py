@@ -457,3 +457,49 @@ def test_recording_the_cost_to_go_with_four_chains_of_sweeps(tmp_path):
     assert b["launches"][1] == 0 and b["launches"][0] > 4 * 100    # four chains swept to the end, no persistent kernel
     for k in ("it", "status", "X", "U", "P", "p"):
         assert np.array_equal(a[k], b[k]), (k, np.flatnonzero((a[k] != b[k]).reshape(len(a[k]), -1).any(axis=1))[:8])
+
+
+_SCRIPT_BIG_SRC = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+A = g.load_package()
+P = importlib.import_module("altro_cpp_amd.problems")
+make = lambda n, m, N, b, d: A.BatchSolver(n, m, N, b, d)
+out = {}
+for name, fac in (("quad12_r32", lambda: P.batch_quadrotor12(make, batch=300, dtype=A.F32)),
+                  ("quad12_f64", lambda: P.batch_quadrotor12(make, batch=40, dtype=A.F64)),
+                  ("tripleint", lambda: P.batch_triple_integrator(make, batch=200))):
+    s = fac()
+    if name == "tripleint":
+        s.solve_ilqr()
+    else:
+        s.solve()
+    X, U = s.get_trajectory(); st = s.get_stats(); K, d = s.get_gains()
+    out[name + "_X"] = X; out[name + "_U"] = U; out[name + "_K"] = K; out[name + "_d"] = d
+    out[name + "_lam"] = s.get_duals(); out[name + "_c"] = s.get_constraint_values()
+    for f in st.dtype.names:
+        out[name + "_st_" + f] = st[f]
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_forward_pass_sources_of_the_large_models_are_bit_identical(tmp_path):
+    """Round 6: the 12-state model's forward pass reads its rollout inputs from global memory (k_forward2<.., kSrcGlb>: one knot
+    ahead, the gain record in its storage type, one barrier per knot, two workgroups per CU) instead of keeping K in global
+    memory and the rest staged (kSrcKdg, rounds 2 - 5: one workgroup per CU).  Same arithmetic on the same values: the two
+    variants must agree bit for bit, with fp32 and fp64 records; the triple integrator (n m = 12 as well) keeps its staged
+    variant by default and must not change either way."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, env_extra):
+        out = str(tmp_path / f"bigsrc_{tag}.npz")
+        subprocess.run([sys.executable, "-c", _SCRIPT_BIG_SRC % root, out], check=True, env=dict(os.environ, **env_extra), timeout=900)
+        return np.load(out)
+    ref = run("default", {})
+    assert (ref["quad12_r32_st_status"] == 0).all()
+    for tag, env in (("kdg", {"ALTRO_HIP_FWD_SRC": "kdg"}), ("global", {"ALTRO_HIP_FWD_SRC": "global"}),
+                     ("global_poisoned", {"ALTRO_HIP_FWD_SRC": "global", "ALTRO_HIP_DEBUG_POISON": "7ff80000,mix"})):
+        got = run(tag, env)
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (tag, k)
