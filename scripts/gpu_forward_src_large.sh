@@ -37,4 +37,4 @@ with tempfile.TemporaryDirectory() as tmp:
 bad = [k for k in res["global"] if not np.array_equal(res["global"][k], res["kdg"][k], equal_nan=True)]
 print("quadrotor12, 300 instances, fp32 records + fp64: global-source variant vs kSrcKdg:", "BIT-IDENTICAL" if not bad else "DIFFERENT " + str(bad))
 PY
-} 2>&1 | tee gpurun_out/r6_c4.log
+} 2>&1 | tee gpurun_out/forward_src_large.log

@@ -2,8 +2,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ldsprobe
 cd scripts/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o lds_conflict_probe lds_conflict_probe.hip && cd ../..
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT -d gpurun_out/ldsprobe -o probe --output-format csv -- scripts/probes/lds_conflict_probe 2>&1 | grep "us per launch" | tee gpurun_out/r6_ldsprobe.txt
-python - <<'PY' | tee -a gpurun_out/r6_ldsprobe.txt
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT -d gpurun_out/ldsprobe -o probe --output-format csv -- scripts/probes/lds_conflict_probe 2>&1 | grep "us per launch" | tee gpurun_out/lds_probe.txt
+python - <<'PY' | tee -a gpurun_out/lds_probe.txt
 import csv, glob, collections
 f = glob.glob("gpurun_out/ldsprobe/**/*counter_collection.csv", recursive=True)
 rows = collections.OrderedDict()

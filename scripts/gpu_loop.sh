@@ -9,4 +9,4 @@ for c in ${BENCH_CONFIGS:-2}; do
   timeout 900 python bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1
   ALTRO_HIP_SWEEP_LOOP=0 timeout 900 python bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1
 done
-} 2>&1 | tee gpurun_out/r6_loop.log | cut -c1-1500
+} 2>&1 | tee gpurun_out/loop.log | cut -c1-1500

@@ -9,4 +9,4 @@ for lib in "$@"; do
   ALTRO_HIP_LIB=$lib ALTRO_HIP_LOOP_LOG=1 ALTRO_HIP_SWEEP_LOOP=1 timeout 600 python scripts/probe_loop.py --child ${AB_KIND:-turn90} ${AB_BATCH:-4096} 3 /tmp/x.npz 2>&1 | grep -v "^$" | tail -4
 done
 done
-} 2>&1 | tee gpurun_out/r6_ab.log | cut -c1-1200
+} 2>&1 | tee gpurun_out/loop_ab.log | cut -c1-1200

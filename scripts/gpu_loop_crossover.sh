@@ -7,4 +7,4 @@ for kind in turn90 obstacles32 obstacles; do
     timeout 600 python scripts/probe_loop.py $kind $b 3 2>&1 | grep -v "^$" | grep "ms per solve\|IDENTICAL\|DIFFERENT\|FAILED"
   done
 done
-} 2>&1 | tee gpurun_out/r6_cross.log | cut -c1-300
+} 2>&1 | tee gpurun_out/loop_crossover.log | cut -c1-300
