@@ -87,7 +87,6 @@ class Engine final : public EngineBase {
     //  the CUs queue up behind the first round; from 6x on the persistent kernel loses to the batched sweeps)
     persist_at_ = 2 * num_cus_;
     fwd_single_at_ = 2 * num_cus_;  // (measured 1x .. 8x the CUs: config 3 -1.2 % at 2x, config 2 indifferent)
-    if (const char* e = std::getenv("ALTRO_HIP_FWD_SINGLE_AT")) fwd_single_at_ = atoi(e);
     if (const char* e = std::getenv("ALTRO_HIP_DEBUG_POISON")) {
       poison_on_ = true;
       poison_pattern_ = (unsigned)strtoul(e, nullptr, 16);
@@ -891,13 +890,11 @@ class Engine final : public EngineBase {
         //  with 2048 / 3520 / 4096 unused columns behind its 4672; config 3 is as fast with 2560 as with 4096;
         //  profiles/r05_experiments.txt #3)
         int want = (Bp_ * 5 / 8) / kBlock * kBlock;
-        if (const char* e2 = std::getenv("ALTRO_HIP_SEG_COLUMNS")) want = std::max(kBlock, atoi(e2) / kBlock * kBlock);
         const size_t bytes = ((size_t)kBwdFrontPad + (size_t)N_ + 2) * RR::EP * (size_t)(Bp_ + want + twin_cap_) * sizeof(RS);
         if (bytes < (size_t)0xffffffffu) seg_total_ = want;
       }
     }
     seg_parts_ = 4;
-    if (const char* e = std::getenv("ALTRO_HIP_SEG_PARTS")) seg_parts_ = std::max(1, std::min(8, atoi(e)));
     Bp_ += seg_total_ + twin_cap_;
     std::memset(&pd_, 0, sizeof(pd_));
     pd_.n = n;
@@ -1474,7 +1471,7 @@ class Engine final : public EngineBase {
                                           2 * padv((size_t)rows) + padv(ip.size())) * sizeof(T));
         int pw_b = lanes_max;
         while (pw_b > 1 && shared_bytes + pw_b * per_inst_b > 160 * 1024) pw_b--;
-        if (shared_bytes + per_inst > 80 * 1024 && pw_b > 1 && !std::getenv("ALTRO_HIP_NO_KDG")) {
+        if (shared_bytes + per_inst > 80 * 1024 && pw_b > 1) {
           kdg_ = true;
           fwd_per_wave_ = pw_b;
           fwd_per_inst_bytes_ = per_inst_b;
@@ -1565,7 +1562,6 @@ class Engine final : public EngineBase {
           if (const char* e2 = std::getenv("ALTRO_HIP_LOOP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e2)));
           const int slots = lanes_per_wave();
           loop_groups_ = std::max(0, std::min(per_cu * num_cus_, (B_ + slots - 1) / slots));
-          if (const char* e2 = std::getenv("ALTRO_HIP_LOOP_GROUPS")) loop_groups_ = std::max(1, std::min(loop_groups_, atoi(e2)));
           loop_per_cu_ = per_cu;
           // WHEN it takes the bulk phase (measured, profiles/r06_experiments.txt #1): a batch that fits the slots of the
           // resident workgroups (two per CU, three slots each: 1536 instances on an MI355X) runs as fast (kTurn90) or up to
@@ -1588,8 +1584,7 @@ class Engine final : public EngineBase {
     // 6: 7.91 / 38.7 / 5.65; 4: 7.96 / 38.8 / 5.62 (profiles/r04_experiments.txt)
     A_.cand_front = 6;
     if (const char* e = std::getenv("ALTRO_HIP_CAND_FRONT")) A_.cand_front = std::max(0, std::min(kLineSearchLanes - 1, atoi(e)));
-    A_.xcd_remap = 1;  // (ALTRO_HIP_XCD_REMAP=0: workgroup i takes slot block i, round 3)
-    if (const char* e = std::getenv("ALTRO_HIP_XCD_REMAP")) A_.xcd_remap = atoi(e) != 0;
+    A_.xcd_remap = 1;  // (0: workgroup i takes slot block i, round 3)
     if (!s.knot_model.empty()) {
       bool any = false;
       for (int k = 0; k < N_; ++k) any = any || s.knot_model[k] != 0;
@@ -1770,7 +1765,7 @@ class Engine final : public EngineBase {
     auto list_of = [&](int which, const Chain& ch) { return d_list_[which] + ch.lo + (int)(&ch - chain) * seg_capc; };
     // (the kernels only see the arrays -- and pay for the bookkeeping of streaks, a few dependent words per instance and
     //  sweep -- from sweep seg_from of a chain on: a batch whose sweeps are over by then, config 2, never does)
-    const int seg_from = std::getenv("ALTRO_HIP_SEG_FROM") ? atoi(std::getenv("ALTRO_HIP_SEG_FROM")) : 24;
+    const int seg_from = 24;
     auto seg_fields = [&](DevArrays<T>& A, const Chain& ch, int i) {
       if (!seg_on || i < seg_from) {
         A.seg_end = nullptr;
@@ -1793,9 +1788,9 @@ class Engine final : public EngineBase {
     // instead of one (config 3: 32.2 - 32.6 ms with this bound, 33 - 35 ms with 1.5 x).  Once a chain has split, the
     // hand-over itself moves to 1.5 x persist_at_: what is left when the segments retire are the long runners, whose
     // iterations the persistent kernel runs at a fifth of a batched sweep's latency.
-    const int seg_above = std::getenv("ALTRO_HIP_SEG_ABOVE") ? atoi(std::getenv("ALTRO_HIP_SEG_ABOVE")) : std::min(3 * persist_at_, B_ * 3 / 8);  // (a batch of 2048 keeps a window below its 65 %)
-    const int seg_persist_at = std::getenv("ALTRO_HIP_SEG_PERSIST_AT") ? atoi(std::getenv("ALTRO_HIP_SEG_PERSIST_AT")) : persist_at_ * 3 / 2;
-    const int seg_every = std::getenv("ALTRO_HIP_SEG_EVERY") ? std::max(1, atoi(std::getenv("ALTRO_HIP_SEG_EVERY"))) : kSegSplitEvery;
+    const int seg_above = std::min(3 * persist_at_, B_ * 3 / 8);  // (a batch of 2048 keeps a window below its 65 %)
+    const int seg_persist_at = persist_at_ * 3 / 2;
+    const int seg_every = kSegSplitEvery;
     auto splits_in = [&](int i) {
       return seg_on && i >= seg_from + 2 && (i % seg_every) == 0 && total_known() <= seg_below && total_known() > seg_above;
     };
@@ -1910,8 +1905,7 @@ class Engine final : public EngineBase {
     // enqueue only has to be in the queue before the one in flight ends, a hundred microseconds or more away -- so it
     // need not burn a core on the poll: a short spin (the word usually lands within microseconds of a neighbouring
     // chain's), then naps of ~50 us (eight ranks of a node, or the worker threads of libaltro_group.so, share the
-    // container's CPU quota with RCCL's proxy threads).  A small batch -- the latency path -- keeps spinning, and so
-    // does ALTRO_HIP_HOST_WAIT=spin.
+    // container's CPU quota with RCCL's proxy threads).  A small batch -- the latency path -- keeps spinning.
     const bool nap_ok = host_wait_backoff_ && B_ >= kHostNapMinBatch;
     bool nap = false;  // (only once the solve has run for kHostNapAfterUs: a 0.3 ms solve of 1024 small problems keeps the spin)
     unsigned spins = 0, naps = 0;
@@ -2045,7 +2039,7 @@ class Engine final : public EngineBase {
         TwinCtl tw{};
         if (twin_cap_ > 0 && !A.hist && spec_mode_ != kSpecHelper && !d.fast_forward_stalls) {
           hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * (kTwWords + 1) * sizeof(unsigned long long), stream_);
-          tw = TwinCtl{d_twin_box_, d_twin_box_ + (size_t)twin_cap_ * kTwWords, ninst, twin_cap_, Bp_ - twin_cap_, twin_lag_, std::getenv("ALTRO_HIP_TWIN_DEBUG") ? 1 : 0};
+          tw = TwinCtl{d_twin_box_, d_twin_box_ + (size_t)twin_cap_ * kTwWords, ninst, twin_cap_, Bp_ - twin_cap_, kTwinLag, twin_debug_ ? 1 : 0};
         }
         const dim3 g(ninst + (tw.base > 0 ? std::min(ninst, twin_cap_) : 0)), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
         timing_.twin_workgroups = tw.base > 0 ? (int)g.x - ninst : 0;  // twin workgroups of this launch
@@ -2126,7 +2120,7 @@ class Engine final : public EngineBase {
         timing_.loop_iterations = words[kLwMaxLoops];
         sweeps = words[kLwMaxLoops];
         extra[2] += words[kLwMaxLoops];
-        if (std::getenv("ALTRO_HIP_LOOP_LOG")) {
+        if (loop_log_) {
           const double per = words[kLwGroups] > 0 ? 0.01 / words[kLwGroups] : 0.0;  // 100 MHz ticks -> us per workgroup
           fprintf(stderr, "LOOPLOG %d workgroups (%d per CU), %d units, longest %d iterations, handed over %d | us per workgroup: slots %.1f E %.1f B %.1f F %.1f\n",
                   words[kLwGroups], loop_per_cu_, words[kLwUnits], words[kLwMaxLoops], words[kLwTail], per * words[kLwTicks],
@@ -2138,13 +2132,13 @@ class Engine final : public EngineBase {
       timing_.twin_handovers = extra[4];
       timing_.twin_claims = extra[5];
       timing_.fused_workgroup_iterations = extra[6];
-      if (seg_on && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {
+      if (seg_on && twin_debug_) {
         int cur[kMaxChains] = {0};
         ALTRO_HIP_CHECK(CopySync(cur, d_seg_cursor_, sizeof(cur), hipMemcpyDeviceToHost));
         fprintf(stderr, "segments: shadow columns used per chain %d %d %d %d (of %d each), persistent launch over <= %d slots, longest own chain %d, longest workgroup %d\n",
                 cur[0], cur[1], cur[2], cur[3], seg_capc, (int)timing_.twin_workgroups, extra[0], extra[6]);
       }
-      if (twin_cap_ > 0 && std::getenv("ALTRO_HIP_TWIN_DEBUG")) {  // the mailboxes after the launch, slot by slot
+      if (twin_cap_ > 0 && twin_debug_) {  // the mailboxes after the launch, slot by slot
         std::vector<unsigned long long> box((size_t)twin_cap_ * kTwWords);
         ALTRO_HIP_CHECK(CopySync(box.data(), d_twin_box_, box.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         int hist[4] = {0, 0, 0, 0}, why[8] = {0};
@@ -2220,7 +2214,7 @@ class Engine final : public EngineBase {
         hipEventElapsedTime(&lms, prof_ev_[loop_ev], prof_ev_[loop_ev + 1]);
         timing_.loop_ms = lms;
       }
-      if (std::getenv("ALTRO_HIP_SWEEP_LOG")) {
+      if (sweep_log_) {
         // timeline of the chains of sweeps (diagnostics): per sweep its start since the solve began, the length of the list it
         // worked on (what the sweep before it left) and the durations of its three kernels
         for (int c = 0; c < C; ++c) {
@@ -2232,7 +2226,7 @@ class Engine final : public EngineBase {
             hipEventElapsedTime(&e, prof_ev_[ev[e0]], prof_ev_[ev[e0 + 1]]);
             hipEventElapsedTime(&b, prof_ev_[ev[e0 + 1]], prof_ev_[ev[e0 + 2]]);
             hipEventElapsedTime(&f, prof_ev_[ev[e0 + 2]], prof_ev_[ev[e0 + 3]]);
-            if (idx % 4 == 0 || e0 + 6 >= ev.size() || std::string(std::getenv("ALTRO_HIP_SWEEP_LOG")) == "all")
+            if (idx % 4 == 0 || e0 + 6 >= ev.size() || std::string(sweep_log_) == "all")
               fprintf(stderr, "SWEEPLOG chain %d sweep %3d t %7.3f ms list %5d E %6.1f B %6.1f F %6.1f us\n", c, idx, t,
                       idx == 0 ? chain[c].hi - chain[c].lo : (int)chain[c].h_cnt[idx - 1], 1e3 * e, 1e3 * b, 1e3 * f);
           }
@@ -2275,29 +2269,31 @@ class Engine final : public EngineBase {
   }
   int seg_total_ = 0, seg_col0_ = 0, seg_parts_ = 4;  // shadow columns of the batched sweeps' segments (DevArrays::seg_*)
   int* d_seg_cursor_ = nullptr;                       // next free column of each chain's slice
-  int seg_below_pct_ = std::getenv("ALTRO_HIP_SEG_BELOW") ? atoi(std::getenv("ALTRO_HIP_SEG_BELOW")) : 65;  // split only below this share of the batch
+  // diagnostics, read once (no getenv on the solve path): mailbox dump of the twins, timeline of the chains of sweeps, phase log of the loop
+  const bool twin_debug_ = std::getenv("ALTRO_HIP_TWIN_DEBUG") != nullptr;
+  const char* const sweep_log_ = std::getenv("ALTRO_HIP_SWEEP_LOG");
+  const bool loop_log_ = std::getenv("ALTRO_HIP_LOOP_LOG") != nullptr;
+  int seg_below_pct_ = 65;  // split only below this share of the batch
   int twin_cap_ = 0;                          // shadow columns behind the batch (twin workgroups of the persistent kernel)
-  int twin_lag_ = std::getenv("ALTRO_HIP_TWIN_LAG") ? atoi(std::getenv("ALTRO_HIP_TWIN_LAG")) : kTwinLag;
   unsigned long long* d_twin_box_ = nullptr;  // their mailboxes, [twin_cap_][kTwWords]
   int* d_list_[2] = {nullptr, nullptr};
   bool mfma_offsets_ok_ = false;
-  // ALTRO_HIP_BACKWARD = valu | coop selects a fallback backward kernel (tests); ALTRO_HIP_VALU_BACKWARD: legacy
+  // ALTRO_HIP_BACKWARD = valu | coop selects a fallback backward kernel (tests)
   static bool BackwardEnvIs(const char* what) {
     const char* e = std::getenv("ALTRO_HIP_BACKWARD");
     return e && std::string(e) == what;
   }
-  bool force_valu_backward_ = std::getenv("ALTRO_HIP_VALU_BACKWARD") != nullptr || BackwardEnvIs("valu");
+  bool force_valu_backward_ = BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
   bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
   // speculative backward pass of the persistent kernel: on its fourth wave (default), in helper workgroups
-  // (ALTRO_HIP_SPECULATION=helper), or not at all (ALTRO_HIP_NO_SPECULATION / =off)
+  // (ALTRO_HIP_SPECULATION=helper), or not at all (=off)
   // (default, kSpecAuto: the fourth wave -- free-running beside software-synchronised forward waves where the rollout
   //  wave paces the knot loop, in lock step on problems with circle constraints, whose knot loop is paced by the cost
   //  wave: there the sequence words only add their polls.  Measured per tail iteration: config 2 46.0 -> 42.0 us free,
   //  config 3 54.7 lock step against 57.0 us free.)
   static constexpr int kSpecAuto = -1;
   int spec_mode_ = [] {
-    if (std::getenv("ALTRO_HIP_NO_SPECULATION")) return (int)kSpecOff;
     const char* e = std::getenv("ALTRO_HIP_SPECULATION");
     if (e && std::string(e) == "helper") return (int)kSpecHelper;
     if (e && std::string(e) == "off") return (int)kSpecOff;
@@ -2330,14 +2326,11 @@ class Engine final : public EngineBase {
   hipEvent_t chain_ev_[kMaxChains] = {};
   hipEvent_t start_ev_ = nullptr;
   hipEvent_t tail_ev_ = nullptr;  // blocking-sync event behind the last launch of a large batch's solve
-  // host side of the sweep loop: spin briefly, then nap (see Solve); ALTRO_HIP_HOST_WAIT=spin restores the pure spin
+  // host side of the sweep loop: spin briefly, then nap (see Solve)
   static constexpr int kHostNapMinBatch = 256;
   static constexpr unsigned kHostSpinsBeforeNap = 400;  // ~10 us of pause instructions
   static constexpr double kHostNapAfterUs = 500.0;      // a solve shorter than this never naps
-  bool host_wait_backoff_ = [] {
-    const char* e = std::getenv("ALTRO_HIP_HOST_WAIT");
-    return !(e && std::string(e) == "spin");
-  }();
+  bool host_wait_backoff_ = true;
   // the device-side sweep loop (k_sweep_loop): persistent workgroups, their windows, the control words, the tail list
   int loop_groups_ = 0, loop_per_cu_ = 0;
   size_t loop_lds_bytes_ = 0;
@@ -2360,7 +2353,7 @@ class Engine final : public EngineBase {
   int persist_at_ = 256;  // active instances at which the persistent tail kernel takes over
   size_t fused_lds_bytes_ = 0;
   bool no_fused_ = std::getenv("ALTRO_HIP_NO_FUSED_SWEEP") != nullptr;
-  bool no_fused_first_ = std::getenv("ALTRO_HIP_NO_FUSED_FIRST") != nullptr;  // (A/B: first sweep as three launches)
+  bool no_fused_first_ = false;  // (A/B builds: first sweep of a small batch as three launches)
   T *X_init_ = nullptr, *U_init_ = nullptr;
   double* d_scalarT_ = nullptr;
   int* d_scalarI_ = nullptr;

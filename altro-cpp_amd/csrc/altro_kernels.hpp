@@ -3673,7 +3673,7 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // recursion again, and goes straight to its forward pass; otherwise the speculation is dropped.  Every straggler of
 // the tail sits in exactly that regime (a line search that rejects all 20 trials, iteration after iteration), so the
 // two serial chains of an iteration overlap: 64 -> ~40 us.  Same arithmetic on the same inputs: same bits
-// (ALTRO_HIP_NO_SPECULATION runs the three-wave kernel).
+// (ALTRO_HIP_SPECULATION=off runs the three-wave kernel).
 // SPEC = kSpecHelper: the speculative pass runs in a workgroup of its own (k_spec_helper, one wave, any CU with a free
 // SIMD) at its own pace instead of in lock step with the forward waves' barriers; regularisation in, gains and
 // hand-over values out travel through global memory with release / acquire flags at agent scope.  Neither side ever

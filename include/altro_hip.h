@@ -164,7 +164,7 @@ typedef struct altro_timing {
   long long instance_iterations; /* sum over instances of iterations_total                  */
   long long fused_instance_iterations; /* (instance, iteration) units run by the fused launch */
   int host_naps;           /* times the host thread slept (~50 us) instead of spinning while it    */
-                           /* waited for a sweep counter (large batches; ALTRO_HIP_HOST_WAIT=spin: 0) */
+                           /* waited for a sweep counter (large batches)                             */
   int twin_workgroups;     /* twin workgroups of the persistent launch: each may take over the second half  */
                            /* of one straggler's rejection streak (0: none launched, ALTRO_HIP_TWIN=0)        */
   int twin_claims;         /* ... twins that found a streak and claimed its second half                      */

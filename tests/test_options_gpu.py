@@ -117,7 +117,7 @@ def test_valu_backward_matches_mfma(P, hip_make, monkeypatch):
     """The one-lane-per-instance VALU backward pass and the MFMA one agree (same schedule, ~1e-12)."""
     g1 = P.batch_turn90(hip_make, batch=16)
     g1.solve()
-    monkeypatch.setenv("ALTRO_HIP_VALU_BACKWARD", "1")
+    monkeypatch.setenv("ALTRO_HIP_BACKWARD", "valu")
     g2 = P.batch_turn90(hip_make, batch=16)
     g2.solve()
     s1, s2 = g1.get_stats(), g2.get_stats()
