@@ -106,22 +106,29 @@ def dominant_kernel_roofline(cfg, tm, config_index):
     # (expansions + backward + forward of one instance per workgroup).
     kern_ms = {"expansions": tm["expansions_ms"], "backward_pass": tm["backward_pass_ms"],
                "forward_pass": tm["forward_pass_ms"], "sweep_fused": tm["fused_ms"]}
+    # (round 6: a batch that fits the slots of the device-side sweep loop runs its bulk phase as ONE launch of k_sweep_loop)
+    loop_ms = tm.get("loop_ms", 0.0) or 0.0
+    if loop_ms > 0:
+        kern_ms["sweep_loop"] = loop_ms
     # kern_ms are sums of launch durations.  A large batch runs its batched sweeps as several chains on streams of
     # their own: their launches overlap, so the three sweep kernels can add up to more than the
     # wall time.  The dominant kernel is the one with the largest share of the solve's WALL time: the sweep kernels
     # share what the solve took outside the initialisation and the persistent launch.
     sweep_sum = kern_ms["expansions"] + kern_ms["backward_pass"] + kern_ms["forward_pass"]
-    sweep_wall = min(sweep_sum, max(0.0, tm["total_ms"] - tm["init_ms"] - tm["fused_ms"]))
+    sweep_wall = min(sweep_sum, max(0.0, tm["total_ms"] - tm["init_ms"] - tm["fused_ms"] - loop_ms))
     scale = sweep_wall / sweep_sum if sweep_sum > 0 else 1.0
-    wall_ms = {k: (v if k == "sweep_fused" else v * scale) for k, v in kern_ms.items()}
+    wall_ms = {k: (v if k in ("sweep_fused", "sweep_loop") else v * scale) for k, v in kern_ms.items()}
     dom = max(wall_ms, key=wall_ms.get)
     units_total = tm["instance_iterations"]  # (trajectory, iteration) units of the whole solve
     units_fused = tm["fused_instance_iterations"]
+    units_loop = tm.get("loop_instance_iterations", 0) or 0
     if dom == "sweep_fused":
         launches, units, bytes_per_unit = max(1, tm.get("fused_launches", 1) or 1), units_fused, ab["total"]
+    elif dom == "sweep_loop":
+        launches, units, bytes_per_unit = 1, units_loop, ab["total"]  # (whole iterations: E + B + F of every unit)
     else:
         launches = tm.get("sweep_launches") or (tm["sweeps"] - tm["fused_sweeps"])  # all chains of sweeps together
-        units, bytes_per_unit = units_total - units_fused, ab[dom]
+        units, bytes_per_unit = units_total - units_fused - units_loop, ab[dom]
     launches = max(launches, 1)
     avg_launch_ms = kern_ms[dom] / launches
     achieved = bytes_per_unit * units / launches / (avg_launch_ms * 1e-3) / 1e9  # GB/s
@@ -132,7 +139,7 @@ def dominant_kernel_roofline(cfg, tm, config_index):
     # see profiles/rNN_traffic.json); bench.py itself cannot run the profiler.
     traffic, traffic_src = None, None
     key = {"expansions": "k_expansions", "backward_pass": "k_backward", "forward_pass": "k_forward",
-           "sweep_fused": "k_sweep_fused"}[dom]
+           "sweep_fused": "k_sweep_fused", "sweep_loop": "k_sweep_loop"}[dom]
     tag = "" if config_index == 2 else f"_config{config_index}"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag}_traffic.json")), reverse=True):
         if config_index == 2 and "_config" in os.path.basename(f):
@@ -474,6 +481,55 @@ def measure_other_config(A, P, S, torch, ci, steps, warmup, device_id):
     }
 
 
+def measure_device_loop(A, P, S, torch, device_id, batch=1536, steps=5, warmup=1):
+    """SECONDARY, never `value` (round 6): the device-side sweep loop against the host-paced chains of sweeps on the largest
+    batch the loop takes by default -- config 2's problem with `batch` instances (the slots of the resident workgroups: 256
+    CUs x 2 x 3) -- same step definition as the headline; per mode: ms per step, kernel launches per solve, CPU time of the
+    rank per wall second, and the two modes' result records compared bit for bit."""
+    import numpy as np
+    cfg = CONFIGS[2]
+    rows, recs = {}, {}
+    for mode, env in (("loop", None), ("sweeps", "0")):
+        if env is None:
+            os.environ.pop("ALTRO_HIP_SWEEP_LOOP", None)
+        else:
+            os.environ["ALTRO_HIP_SWEEP_LOOP"] = env  # (read when the engine uploads the problem)
+        try:
+            make = lambda n_, m_, N_, b_, d_: A.BatchSolver(n_, m_, N_, b_, d_, device_id=device_id)  # noqa: E731
+            s_ = getattr(P, cfg["factory"])(make, batch=batch, dtype=getattr(A, cfg["dtype"]), seed=P.SEED_BASE + cfg["seed"],
+                                             shard=S.shard_range(batch, 1, 0))
+            s_.set_options(profiler_enable=0)
+            packed = torch.empty((batch, 4), dtype=torch.float64, device=f"cuda:{device_id}")
+            for _ in range(warmup):
+                solve_once(s_, cfg["mode"])
+                S.pack_and_gather(s_, packed, packed, None)
+            torch.cuda.synchronize()
+            c0, t0 = time.process_time(), time.perf_counter()
+            for _ in range(steps):
+                solve_once(s_, cfg["mode"])
+                S.pack_and_gather(s_, packed, packed, None)
+            torch.cuda.synchronize()
+            el, cpu = time.perf_counter() - t0, time.process_time() - c0
+            recs[mode] = packed.cpu().numpy().copy()
+            s_.set_options(profiler_enable=1)
+            solve_once(s_, cfg["mode"])
+            tm = s_.get_timing()
+            solved = int((recs[mode][:, 3].astype(int) == 0).sum())
+            rows[mode] = {"ms_per_step": round(1e3 * el / steps, 3), "value": round(solved * steps / el, 1),
+                          "host_cpu_cores": round(cpu / max(el, 1e-9), 3), "kernel_launches_per_solve": tm["launches"],
+                          "sweep_launches": tm["sweep_launches"], "loop_ms": round(tm.get("loop_ms", 0.0), 3),
+                          "loop_instance_iterations": tm.get("loop_instance_iterations", 0), "persistent_ms": round(tm["fused_ms"], 3),
+                          "handed_to_persistent_kernel": tm.get("loop_handover", 0)}
+            s_.close()
+        finally:
+            os.environ.pop("ALTRO_HIP_SWEEP_LOOP", None)
+    return {"workload": f"BASELINE configs[2]'s problem, batch {batch} (fits the loop's slots)", "unit": "trajectories/s", "steps": steps,
+            "loop": rows.get("loop"), "sweeps": rows.get("sweeps"),
+            "records_identical": bool(np.array_equal(recs.get("loop"), recs.get("sweeps"))),
+            "note": "NOT the headline: the batch the headline is quoted on (4096) exceeds the loop's slots and runs the host-paced "
+                    "sweeps (profiles/r06_experiments.txt #1)"}
+
+
 def measure_latency(A, P, device_id, with_cpu=True):
     """The MPC use case (reference docs/Overview.dox:48-54, test/augmented_lagrangian/auglag_test.cpp:353-380): wall time
     of ONE altro_solve_al call for a batch of 1 / 8 / 64 -- cold (the reference problem's initial guess) and warm-started
@@ -562,6 +618,7 @@ def main():
                     help="device = local_rank %% visible devices (several ranks on one GPU; tests only, needs --dist-backend gloo)")
     ap.add_argument("--no-fast-forward", action="store_true", help="skip the secondary `fast_forward` key")
     ap.add_argument("--no-pipeline2", action="store_true", help="skip the secondary `pipeline_2` key (two handles in flight)")
+    ap.add_argument("--no-device-loop", action="store_true", help="skip the secondary `device_loop` key (k_sweep_loop against the sweeps, batch 1536)")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="multi-rank runs bind each rank's host threads to the NUMA node of its GPU; this switches it off")
     args = ap.parse_args()
@@ -882,6 +939,14 @@ def main():
                                   "solve of the headline's batch; the tail of one solve overlaps the sweeps of the next"}
             for s_ in pool:
                 s_.close()
+        device_loop = None
+        if world == 1 and args.pipeline == 1 and args.config == 2 and not args.no_device_loop and not os.environ.get("ALTRO_HIP_SWEEP_LOOP"):
+            if others is None and latency is None and fast_forward is None and pipeline_2 is None:
+                solver.close()
+            try:
+                device_loop = measure_device_loop(A, P, S, torch, local_rank)
+            except Exception as e:  # (never fail the line for a secondary key)
+                device_loop = {"error": str(e)[:300]}
         # ---- the achievable HBM ceiling of this device beside the data-sheet peak ----
         try:
             copy_gbs = measure_hbm_copy_gbs(torch, dev)
@@ -922,6 +987,7 @@ def main():
             "latency": latency,
             "fast_forward": fast_forward,
             "pipeline_2": pipeline_2,
+            "device_loop": device_loop,
             **({"dist_check": dist_check} if dist_check is not None else {}),
         }
         print(json.dumps(out), flush=True)

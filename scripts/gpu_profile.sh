@@ -10,7 +10,7 @@ rm -rf $P; mkdir -p $P
 # the size of the trace pass's.  ALTRO_HIP_CHAINS forces the count (and skips the check): what a fresh process picks
 # (4 for a batch >= 2048, else 1).
 case $C in 2|3) export ALTRO_HIP_CHAINS=4;; *) export ALTRO_HIP_CHAINS=1;; esac
-CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --no-fast-forward --no-pipeline2"
+CMD="python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --no-fast-forward --no-pipeline2 --no-device-loop ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o bench -- $CMD > $P/trace_run.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -o bench -- $CMD > $P/fetch_run.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -o bench -- $CMD > $P/write_run.log 2>&1
@@ -25,7 +25,7 @@ python - $P <<'PY'
 import csv, glob, collections, json, sys
 P = sys.argv[1]
 def short(name):
-    for k in ('k_sweep_fused', 'k_forward2', 'k_forward', 'k_backward_mfma16', 'k_backward_mfma', 'k_backward_coop', 'k_backward', 'k_expansions',
+    for k in ('k_sweep_loop', 'k_sweep_fused', 'k_forward2', 'k_forward', 'k_backward_mfma16', 'k_backward_mfma', 'k_backward_coop', 'k_backward', 'k_expansions',
               'k_rollout', 'k_al_init', 'k_solve_setup', 'k_pack_results', 'k_set_rows', 'k_reset_stats'):
         if k in name: return k
     return name[:40]
