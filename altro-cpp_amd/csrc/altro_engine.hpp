@@ -2081,10 +2081,19 @@ class Engine final : public EngineBase {
     }
     if (nap_ok && !nap) nap = loop_launched || std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostNapAfterUs;
     if (nap && tail_ev_) {
-      // the persistent launch runs for milliseconds: wait for it on an event that blocks in the driver (interrupt) instead
-      // of spinning in hipStreamSynchronize
+      // the persistent launch (or the device-side loop) runs for milliseconds: wait for it WITHOUT a core.  Round 4 waited in
+      // hipEventSynchronize on a blocking-sync event; measured in round 6 (bench.py's device_loop key: one launch per solve, the
+      // host does nothing else) that wait still costs a whole core -- the runtime spins on the signal.  So: query the event
+      // and nap (~70 us with the timer slack: < 2 % of the solves that get here -- large batches only; the latency path
+      // below kHostNapMinBatch instances keeps hipStreamSynchronize).
       ALTRO_HIP_CHECK(hipEventRecord(tail_ev_, stream_));
-      ALTRO_HIP_CHECK(hipEventSynchronize(tail_ev_));
+      for (;;) {
+        const hipError_t q = hipEventQuery(tail_ev_);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) ALTRO_HIP_CHECK(q);
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        timing_.host_naps += 1;
+      }
     }
     for (int c = 1; c < C; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(chain[c].st));
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
