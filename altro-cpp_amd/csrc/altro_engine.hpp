@@ -1676,22 +1676,6 @@ class Engine final : public EngineBase {
     size_t nev = 0;
     cur_ = stream_;
     PoisonShadowColumns();
-    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-    if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
-    // (no shadow column starts a solve as an active instance, whatever the last solve left in it: the dense expansion
-    //  launches rebuild their lists from these flags)
-    if (seg_total_ + twin_cap_ > 0)
-      ALTRO_HIP_CHECK(hipMemsetAsync(A_.phase + (Bp_ - seg_total_ - twin_cap_), 0, (size_t)(seg_total_ + twin_cap_) * sizeof(int), stream_));
-    {
-      DevArrays<T> As = A_;
-      if (seg_total_ > 0) SegArrays(As);  // (resets the bookkeeping of the segments, DevArrays::seg_*)
-      hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, As, d, 1);
-    }
-    hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
-    timing_.launches += (mode == kFwdAL) ? 3 : 2;
-    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
-    ALTRO_HIP_CHECK(hipGetLastError());
-
     // upper bound on sweeps: every sweep advances every active instance by one inner iteration
     // (64-bit product, clamped: the counters of the sweeps live in a pinned array of this length)
     const long long inner_outer = (long long)std::max(1, o.max_iterations_inner) *
@@ -1710,7 +1694,49 @@ class Engine final : public EngineBase {
       altro_status rs = ReserveCounters(C * cstride + 16);
       if (rs != ALTRO_OK) return rs;
     }
-    ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+    twin_box_clean_ = false;
+    if (begin_merged_) {
+      // ONE launch (k_begin_solve): AL Init, SolveSetup, activation, the open-loop rollout, and the clearing of the shadow
+      // columns' flags (no shadow column starts a solve as an active instance, whatever the last solve left in it: the
+      // dense expansion launches rebuild their lists from these flags), of the sweep counters and of the twins' mailboxes
+      DevArrays<T> As = A_;
+      if (seg_total_ > 0) SegArrays(As);  // (resets the bookkeeping of the segments, DevArrays::seg_*)
+      ZeroJobs z{};
+      int nz = 0;
+      auto zero = [&](void* ptr, size_t words) {
+        z.p[nz] = reinterpret_cast<unsigned*>(ptr);
+        z.n[nz++] = (unsigned)words;
+      };
+      if (seg_total_ + twin_cap_ > 0) zero(A_.phase + (Bp_ - seg_total_ - twin_cap_), (size_t)(seg_total_ + twin_cap_));
+      zero(d_counter_, (size_t)(C * cstride + 16));
+      if (twin_cap_ > 0) {
+        zero(d_twin_box_, (size_t)twin_cap_ * (kTwWords + 1) * 2);
+        twin_box_clean_ = true;
+      }
+      size_t words = 0;
+      for (int j = 0; j < nz; ++j) words += z.n[j];
+      const int gx = (B_ + kBlock - 1) / kBlock;
+      const int rows_y = (mode == kFwdAL) ? std::max(1, (pd_.total_rows + kAlInitRows - 1) / kAlInitRows) : 0;
+      const int zero_y = (int)std::min<size_t>(32, std::max<size_t>(1, words / ((size_t)gx * kBlock * 16)));
+      hipLaunchKernelGGL((k_begin_solve<T, M>), dim3(gx, 1 + rows_y + zero_y), dim3(kBlock), 0, stream_, As, d_pd_, d,
+                         mode == kFwdAL ? 1 : 0, rows_y, z);
+      timing_.launches += 1;
+    } else {
+      if (mode == kFwdAL) hipLaunchKernelGGL(k_al_init<T>, GridAlInit(), dim3(kBlock), 0, stream_, A_, d_pd_, d);
+      if (seg_total_ + twin_cap_ > 0)
+        ALTRO_HIP_CHECK(hipMemsetAsync(A_.phase + (Bp_ - seg_total_ - twin_cap_), 0, (size_t)(seg_total_ + twin_cap_) * sizeof(int), stream_));
+      {
+        DevArrays<T> As = A_;
+        if (seg_total_ > 0) SegArrays(As);
+        hipLaunchKernelGGL(k_solve_setup<T>, GridB(), dim3(kBlock), 0, stream_, As, d, 1);
+      }
+      hipLaunchKernelGGL((k_rollout<T, M>), GridB(), dim3(kBlock), 0, stream_, A_, d_pd_, 1);
+      timing_.launches += (mode == kFwdAL) ? 3 : 2;
+      ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+    }
+    if (prof) hipEventRecord(ProfEvent(nev++), stream_);
+    ALTRO_HIP_CHECK(hipGetLastError());
     // the device-side sweep loop takes the bulk phase whenever the persistent tail kernel can follow it (FusedOk: MFMA
     // backward pass, staged forward pass, uniform step, <= 20 line-search trials, no cost-to-go records)
     const bool loop_on = loop_groups_ > 0 && FusedOk(d);
@@ -2000,7 +2026,11 @@ class Engine final : public EngineBase {
           A.chain_size = 0;
         }
         const int ninst = (int)std::min<long long>(std::max<long long>(ninst_l, 1), (long long)B_ + (seg_on ? seg_total_ : 0));
-        if (any_split()) SegArrays(A);
+        if (any_split()) {
+          SegArrays(A);
+          A.seg_lo = seg_col0_;  // (this launch: first shadow column / columns per chain, for the report of a handed-over column)
+          A.seg_hi = seg_capc;
+        }
         if (loop_launched) {
           A.act_list = d_loop_tail_;
           A.act_count = d_loop_ctl_ + kLwTail;
@@ -2038,7 +2068,8 @@ class Engine final : public EngineBase {
         // indices); not with a recorded history (its rows are appended in iteration order) nor in helper mode
         TwinCtl tw{};
         if (twin_cap_ > 0 && !A.hist && spec_mode_ != kSpecHelper && !d.fast_forward_stalls) {
-          hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * (kTwWords + 1) * sizeof(unsigned long long), stream_);
+          if (!twin_box_clean_)  // (cleared by k_begin_solve otherwise: nothing touches the mailboxes before this launch)
+            hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * (kTwWords + 1) * sizeof(unsigned long long), stream_);
           tw = TwinCtl{d_twin_box_, d_twin_box_ + (size_t)twin_cap_ * kTwWords, ninst, twin_cap_, Bp_ - twin_cap_, kTwinLag, twin_debug_ ? 1 : 0};
         }
         const dim3 g(ninst + (tw.base > 0 ? std::min(ninst, twin_cap_) : 0)), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
@@ -2323,6 +2354,13 @@ class Engine final : public EngineBase {
   size_t fwd_lds_bytes_ = 0, fwd_shared_bytes_ = 0, fwd_per_inst_bytes_ = 0;
   int num_cus_ = 256;
   bool fast_forward_ = std::getenv("ALTRO_HIP_FAST_FORWARD_STALLS") != nullptr;
+  // the start of a solve as one launch (k_begin_solve); ALTRO_HIP_BEGIN_SOLVE=split restores the seven stream operations
+  // (the bit-identity test of the two, tests/test_fused_gpu.py)
+  const bool begin_merged_ = [] {
+    const char* e = std::getenv("ALTRO_HIP_BEGIN_SOLVE");
+    return !(e && std::strcmp(e, "split") == 0);
+  }();
+  bool twin_box_clean_ = false;  // this solve's k_begin_solve has cleared the twins' mailboxes
   double* d_stage_ = nullptr;
   size_t stage_cap_ = 0;
   static constexpr int kMaxChains = kMaxSweepChains;

@@ -1489,6 +1489,96 @@ __global__ __launch_bounds__(kBlock) void k_solve_setup(DevArrays<T> A, DevOpts 
     A.seg_streak[b] = 0;
   }
 }
+// -------------------------------------------------------------------------------------------------
+// The start of a whole solve in ONE launch (round 6): what Solve() used to enqueue as k_al_init, a memset of the shadow
+// columns' flags, k_solve_setup, k_rollout and the memsets of the sweep counters and of the twins' mailboxes -- seven
+// stream operations, 73 us in front of the first iteration of a batch of one (scripts/gpu_latency_trace.sh: 41 us of them
+// the open-loop rollout, a single lane that met the latency of its control loads at every knot).  None of the parts reads
+// what another writes, so they run side by side over blockIdx.y:
+//   y = 0                 per instance: AL Init's statistics (al_solver.hpp:287-302), SolveSetup (ilqr.hpp:629-645),
+//                         activation, then iLQR::Rollout (ilqr.hpp:453-459) with the NEXT knot's controls, step, time and
+//                         model requested before this knot's RK4 chain starts -- same discrete_step on the same inputs as
+//                         k_rollout, same bits
+//   y = 1 .. rows_y       AL Init's multiplier / penalty rows, kAlInitRows each (as k_al_init)
+//   y > rows_y            zero jobs: word ranges cleared by all threads of those blocks (grid stride)
+// The step-level API keeps the separate kernels.
+// -------------------------------------------------------------------------------------------------
+constexpr int kZeroJobs = 3;
+struct ZeroJobs {
+  unsigned* p[kZeroJobs];
+  unsigned n[kZeroJobs];  // 32-bit words
+};
+template <class T, class M>
+__global__ __launch_bounds__(kBlock) void k_begin_solve(DevArrays<T> A, const ProblemDesc* __restrict__ pd, DevOpts o, int al,
+                                                        int rows_y, ZeroJobs z) {
+  constexpr int n = M::n;
+  using R = Rec<T, M::n, M::m>;
+  const int by = (int)blockIdx.y;
+  if (by > rows_y) {
+    const unsigned nthreads = (gridDim.y - 1u - (unsigned)rows_y) * gridDim.x * kBlock;
+    const unsigned t = ((unsigned)(by - rows_y - 1) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kZeroJobs; ++j)
+      for (unsigned i = t; i < z.n[j]; i += nthreads) z.p[j][i] = 0u;
+    return;
+  }
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= A.B) return;
+  if (by > 0) {
+    const bool zero_lam = o.reset_duals != 0, set_pen = o.initial_penalty > 0;  // quirk Q8
+    const int r0 = (by - 1) * kAlInitRows, r1 = min(r0 + kAlInitRows, pd->total_rows);
+    for (int r = r0; r < r1; ++r) {
+      if (zero_lam) A.lam[(size_t)r * A.Bp + b] = T(0);
+      if (set_pen) A.pen[(size_t)r * A.Bp + b] = T(o.initial_penalty);
+    }
+    return;
+  }
+  if (al) {
+    reset_stats(A, b);  // stats.Reset()
+    if (o.initial_penalty > 0) {  // stats.Log("pen", GetMaxPenalty()) of Init (al_solver.hpp:301)
+      A.penmax[b] = o.initial_penalty;
+    } else {
+      T v, pm;
+      rows_viol_pen(A, pd, b, &v, &pm);
+      A.penmax[b] = (double)pm;
+    }
+    A.status_al[b] = ALTRO_UNSOLVED;
+  }
+  begin_inner_solve(A, o, b);
+  A.phase[b] = 1;
+  if (A.seg_end) {  // no segment bookkeeping survives a solve
+    A.seg_end[b] = kSegNoEnd;
+    A.seg_next[b] = -1;
+    A.seg_flag[b] = 0;
+    A.seg_streak[b] = 0;
+  }
+  const unsigned Bp = A.Bp;
+  const int N = A.N;
+  T x[R::nP], u[R::mP], un[R::mP], xn[n];
+  load_rec<T, R::nP>(A.x0 + (size_t)b * R::nP, x);
+  if (N > 0) load_rec<T, R::mP>(RECP(A.U, 0, R::mP), u);
+  T h = step_of(A, pd, 0);
+  float t = time_of(A, 0);
+  int md = model_of(A, 0);
+  for (int k = 0; k < N; ++k) {
+    store_rec<T, R::nP>(RECP(A.X, k, R::nP), x);
+    const int kn = k + 1 < N ? k + 1 : k;
+    load_rec<T, R::mP>(RECP(A.U, kn, R::mP), un);
+    const T hn = step_of(A, pd, kn);
+    const float tn = time_of(A, kn);
+    const int mdn = model_of(A, kn);
+    discrete_step<T, M>(x, u, h, xn, t, md);
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = xn[i];
+#pragma unroll
+    for (int i = 0; i < R::mP; ++i) u[i] = un[i];
+    h = hn;
+    t = tn;
+    md = mdn;
+  }
+  store_rec<T, R::nP>(RECP(A.X, N, R::nP), x);
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_set_rows(DevArrays<T> A, const ProblemDesc* __restrict__ pd,
                                                      int zero_lam, int set_pen, T rho) {
@@ -3868,7 +3958,13 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
       atomicMax(sweeps_out, chain_loops);      // longest chain of iterations of one instance inside this launch
       atomicAdd(sweeps_out + 1, units);        // (instance, iteration) units processed by this launch
       atomicMax(sweeps_out + 6, units + skipped);  // most iterations any ONE workgroup ran (a twin or its primary: their share)
-      const int chain = A.chain_size ? (b_real / A.chain_size < kMaxSweepChains - 1 ? b_real / A.chain_size : kMaxSweepChains - 1) : 0;
+      // (a column of a split streak that the sweeps handed over sits behind the batch; the tail launch carries
+      //  the first shadow column in seg_lo and the columns per chain in seg_hi, which give the chain that owns it)
+      int chain = 0;
+      if (A.chain_size) {
+        chain = (SEG && A.seg_end && b_real >= A.B && A.seg_hi > 0 && b_real >= A.seg_lo) ? (b_real - A.seg_lo) / A.seg_hi : b_real / A.chain_size;
+        chain = chain < kMaxSweepChains - 1 ? chain : kMaxSweepChains - 1;
+      }
       atomicMax(sweeps_out + 2, A.chain_base[chain] + chain_loops);  // ... counted from the first sweep of the solve
       if (kSoft && sync_words[kSyErr] != 0) atomicMax(sweeps_out + 3, 1);  // a wave gave up waiting for a sequence word
     }
@@ -4578,6 +4674,10 @@ constexpr int kLoopXcds = 8;
 // prefetch depth of the backward pass inside the loop kernel: the stand-alone kernel's six knots in two ping-pong blocks are
 // 120 of its 256 registers; here the workgroup shares its SIMDs with a second one (two waves per SIMD, 256 registers each)
 constexpr int kLoopBwdAhead = ALTRO_LOOP_BWD_AHEAD;
+#ifndef ALTRO_LOOP_MIN_BLOCKS
+#define ALTRO_LOOP_MIN_BLOCKS 2
+#endif
+constexpr int kLoopMinBlocks = ALTRO_LOOP_MIN_BLOCKS;  // workgroups per CU the loop kernel is compiled for (registers: 512 / ceil(3 * blocks / 4) per lane)
 // up to `want` not yet started instances for a workgroup of XCD `xcd`: own range first, then the others' (thread 0 only)
 ALTRO_DEV int loop_pull(const LoopCtl& lc, int B, int xcd, int want, int* out) {
   int got = 0;
@@ -4616,7 +4716,7 @@ ALTRO_LOOP_F_ATTR void loop_forward(const DevArrays<T>& Aw, const ProblemDesc* _
                                   FwdSync<false>{nullptr, 0}, nullptr, nullptr, nullptr, 0, 0, -1, 0);
 }
 template <class T, class M, int SRC>
-__global__ __launch_bounds__(kFwdWaves * kBlock, 2) void k_sweep_loop(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+__global__ __launch_bounds__(kFwdWaves * kBlock, kLoopMinBlocks) void k_sweep_loop(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
                                                                         const ProblemDesc pd_arg, DevOpts o, int mode, LoopCtl lc) {
   constexpr int PW = kBlock / kLineSearchLanes;  // slots of a workgroup (instances per wave of the forward pass)
   static_assert(PW <= 3, "a window holds four entries, the fourth stays empty for the backward pass's fourth block");

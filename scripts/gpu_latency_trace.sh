@@ -19,7 +19,7 @@ python - $P <<'PY'
 import csv, glob, sys
 P = sys.argv[1]
 rows = sorted(csv.DictReader(open(glob.glob(f'{P}/trace/**/*kernel_trace.csv', recursive=True)[0])), key=lambda r: int(r['Start_Timestamp']))
-last = [i for i, r in enumerate(rows) if 'k_al_init' in r['Kernel_Name']][-1]
+last = [i for i, r in enumerate(rows) if 'k_al_init' in r['Kernel_Name'] or 'k_begin_solve' in r['Kernel_Name']][-1]
 t0 = int(rows[last - 2]['Start_Timestamp']) if last >= 2 else int(rows[last]['Start_Timestamp'])
 prev = None
 with open('gpurun_out/latency_trace.txt', 'w') as out:

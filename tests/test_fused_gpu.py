@@ -114,7 +114,7 @@ np.savez(sys.argv[1], **out)
                                     {"ALTRO_HIP_SPECULATION": "free", "ALTRO_HIP_DEBUG_POISON": "12345678,mix"},
                                     {"ALTRO_HIP_SWEEP_LOOP": "0"}, {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_LOOP_PER_CU": "1"},
                                     {"ALTRO_HIP_PERSIST_AT": "600"}, {"ALTRO_HIP_CHAINS": "4"}, {"ALTRO_HIP_CHAINS": "3", "ALTRO_HIP_PERSIST_AT": "100"}, {"ALTRO_HIP_DEBUG_POISON": "ffffffff"},
-                                    {"ALTRO_HIP_DEBUG_POISON": "12345678,mix"}],
+                                    {"ALTRO_HIP_DEBUG_POISON": "12345678,mix"}, {"ALTRO_HIP_BEGIN_SOLVE": "split"}],
                          ids=lambda d: "-".join(f"{k}={v}" for k, v in d.items()))
 def test_launch_variants_are_bit_identical(tmp_path, switch):
     """The batched sweeps have several launch variants chosen by measurements (dense / list-addressed expansions with
