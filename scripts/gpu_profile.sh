@@ -26,7 +26,7 @@ import csv, glob, collections, json, sys
 P = sys.argv[1]
 def short(name):
     for k in ('k_sweep_loop', 'k_sweep_fused', 'k_forward2', 'k_forward', 'k_backward_mfma16', 'k_backward_mfma', 'k_backward_coop', 'k_backward', 'k_expansions',
-              'k_rollout', 'k_al_init', 'k_solve_setup', 'k_pack_results', 'k_set_rows', 'k_reset_stats'):
+              'k_begin_solve', 'k_rollout', 'k_al_init', 'k_solve_setup', 'k_pack_results', 'k_set_rows', 'k_reset_stats'):
         if k in name: return k
     return name[:40]
 out = {}
