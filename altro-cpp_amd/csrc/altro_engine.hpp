@@ -1551,22 +1551,17 @@ class Engine final : public EngineBase {
     if constexpr (kMfmaBackward) {
       const char* e = std::getenv("ALTRO_HIP_SWEEP_LOOP");
       if (!(e && atoi(e) == 0) && fwd_lds_bytes_ > 0 && !kdg_ && fwd_per_wave_ == lanes_per_wave() && B_ > persist_at_) {
-        // LDS of a loop workgroup: the forward block of one window, and behind it the gain buffer of the recursion wave, which
-        // runs beside the forward pass of the other window
-        const size_t bwd_bytes = ((size_t)kLoopBwdChunk * 4 * R::KP + kBlock) * sizeof(double);
-        loop_bwd_off_ = (fwd_lds_bytes_ + 15) / 16 * 16;
-        loop_lds_bytes_ = loop_bwd_off_ + bwd_bytes;
+        const size_t bwd_bytes = ((size_t)kBwdChunk * 4 * R::KP + kBlock) * sizeof(double);
+        loop_lds_bytes_ = std::max(fwd_lds_bytes_, bwd_bytes);
         const void* fn = rg_ ? LoopKernel<kSrcGlb>() : LoopKernel<kSrcLds>();
         if (fn && loop_lds_bytes_ <= 160 * 1024) {
           if (loop_lds_bytes_ > 64 * 1024)
             ALTRO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_lds_bytes_));
           int per_cu = 0;
-          ALTRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (kFwdWaves + 1) * kBlock, loop_lds_bytes_));
+          ALTRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFwdWaves * kBlock, loop_lds_bytes_));
           if (const char* e2 = std::getenv("ALTRO_HIP_LOOP_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e2)));
-          // (a batch that does not fill the GPU is spread one window per workgroup: the second windows then stay empty and
-          //  a workgroup runs E -> B -> F one after the other, on more CUs)
-          const int slots = 2 * lanes_per_wave();  // two windows per workgroup
-          loop_groups_ = std::max(0, std::min(per_cu * num_cus_, (B_ + lanes_per_wave() - 1) / lanes_per_wave()));
+          const int slots = lanes_per_wave();
+          loop_groups_ = std::max(0, std::min(per_cu * num_cus_, (B_ + slots - 1) / slots));
           loop_per_cu_ = per_cu;
           // WHEN it takes the bulk phase (measured, profiles/r06_experiments.txt #1): a batch that fits the slots of the
           // resident workgroups (two per CU, three slots each: 1536 instances on an MI355X) runs as fast (kTurn90) or up to
@@ -1577,7 +1572,7 @@ class Engine final : public EngineBase {
           if (!(e && atoi(e) != 0) && B_ > per_cu * num_cus_ * slots) loop_groups_ = 0;
         }
         if (loop_groups_ > 0) {
-          ALTRO_ALLOC(d_loop_win_, (size_t)loop_groups_ * 8);
+          ALTRO_ALLOC(d_loop_win_, (size_t)loop_groups_ * 4);
           ALTRO_ALLOC(d_loop_ctl_, (size_t)kLwWords + 8);  // (+ the words the persistent tail kernel reports)
           ALTRO_ALLOC(d_loop_tail_, (size_t)B_ + 16);
         }
@@ -1904,13 +1899,13 @@ class Engine final : public EngineBase {
       if constexpr (kMfmaBackward) {
         ALTRO_HIP_CHECK(hipMemsetAsync(d_loop_ctl_, 0, (size_t)(kLwWords + 8) * sizeof(int), stream_));
         const int per_xcd = ((B_ + kLoopXcds - 1) / kLoopXcds + 15) / 16 * 16;
-        const LoopCtl lc{d_loop_win_, d_loop_ctl_, d_loop_tail_, loop_handover, per_xcd, (int)loop_bwd_off_};
+        const LoopCtl lc{d_loop_win_, d_loop_ctl_, d_loop_tail_, loop_handover, per_xcd};
         PoisonLds();
         if (prof) {
           loop_ev = nev;
           hipEventRecord(ProfEvent(nev++), stream_);
         }
-        const dim3 gl(loop_groups_), bl((kFwdWaves + 1) * kBlock);
+        const dim3 gl(loop_groups_), bl(kFwdWaves * kBlock);
         if (rg_) {
           if constexpr (kRgEligible)
             hipLaunchKernelGGL((k_sweep_loop<T, M, kSrcGlb>), gl, bl, loop_lds_bytes_, stream_, A_, d_pd_, pd_, d, mode, lc);
@@ -2167,7 +2162,7 @@ class Engine final : public EngineBase {
         extra[2] += words[kLwMaxLoops];
         if (loop_log_) {
           const double per = words[kLwGroups] > 0 ? 0.01 / words[kLwGroups] : 0.0;  // 100 MHz ticks -> us per workgroup
-          fprintf(stderr, "LOOPLOG %d workgroups (%d per CU), %d units, longest %d phases, handed over %d | us per workgroup: slots %.1f E %.1f B beside F %.1f (%.1f)\n",
+          fprintf(stderr, "LOOPLOG %d workgroups (%d per CU), %d units, longest %d iterations, handed over %d | us per workgroup: slots %.1f E %.1f B %.1f F %.1f\n",
                   words[kLwGroups], loop_per_cu_, words[kLwUnits], words[kLwMaxLoops], words[kLwTail], per * words[kLwTicks],
                   per * words[kLwTicks + 1], per * words[kLwTicks + 2], per * words[kLwTicks + 3]);
         }
@@ -2385,7 +2380,7 @@ class Engine final : public EngineBase {
   bool host_wait_backoff_ = true;
   // the device-side sweep loop (k_sweep_loop): persistent workgroups, their windows, the control words, the tail list
   int loop_groups_ = 0, loop_per_cu_ = 0;
-  size_t loop_lds_bytes_ = 0, loop_bwd_off_ = 0;
+  size_t loop_lds_bytes_ = 0;
   int *d_loop_win_ = nullptr, *d_loop_ctl_ = nullptr, *d_loop_tail_ = nullptr;
   static constexpr int lanes_per_wave() { return kBlock / kLineSearchLanes; }
   template <int SRC>

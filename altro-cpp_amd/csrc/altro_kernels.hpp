@@ -678,16 +678,10 @@ constexpr int kBwdChunk = 126;  // knots of gains buffered in LDS between two bu
 // this wave writes is read before the kernel's own __syncthreads.  (Schedules that decouple the two paces -- 70 % or
 // 88 % of the recursion's knots spread over the loop's barriers, the rest behind barriers A / S / V -- measured
 // 4 - 9 % slower than this lock step: profiles/r02_experiments_not_kept.txt.)
-// CHUNK / BARG (the device-side sweep loop, k_sweep_loop): knots of gains buffered in LDS between two bulk stores (the loop
-// kernel's recursion wave shares the workgroup's LDS with a forward pass that runs beside it), and BARG > 0: this wave is one
-// of FOUR of a workgroup whose other three run a forward pass meanwhile -- it takes one workgroup barrier per BARG knots (the
-// forward waves' pace), counted in *nbar and never more than bar_cap of them (a restarted sweep takes none), and the caller
-// tops the count up to the forward pass's.
-template <class T, class M, bool CTG, bool FUSED, bool SPEC = false, int AHEAD = kBwdAhead, int CHUNK = kBwdChunk, int BARG = 0>
+template <class T, class M, bool CTG, bool FUSED, bool SPEC = false, int AHEAD = kBwdAhead>
 ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int all, int lane, int slot_base,
                                   double* sKD, T* sKDf, int fused_junk, double* fh, double spec_rho = 0.0,
-                                  double spec_drho = 0.0, int* nbar = nullptr, int b_fixed = -1, int bar_cap = 0) {
-  static_assert(BARG == 0 || (!SPEC && !FUSED), "barrier participation of the batched recursion: the loop kernel's fourth wave");
+                                  double spec_drho = 0.0, int* nbar = nullptr, int b_fixed = -1) {
   static_assert(!SPEC || FUSED, "the speculative pass is a variant of the fused one");
   // 4 x 4 tiles with the vectors riding as column n: n <= 3 states, m <= 2 controls (round 4: was n = 3, m = 2 only -- the
   // tile offsets below are generic; what m = 1 changes is the 2 x 2 inverse, see qc)
@@ -820,8 +814,8 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
     // write the buffered knots (k_top, k_top - 1, ... in slots 0 .. slot-1) of the four instances out
     // (only of the instances that take part in THIS sweep: in a restarted sweep the slots of a block whose instance finished in
     //  an earlier one hold whatever that sweep's last chunk left there -- the same knots' values only as long as a pass is ONE
-    //  chunk; with N > CHUNK they are other knots' gains, and writing them out corrupted the finished instance's record.
-    //  Found in round 6 with the loop kernel's 32-knot chunks on the obstacle batch, whose Cholesky restarts are real.)
+    //  chunk; with N > kBwdChunk they are other knots' gains, and writing them out corrupted the finished instance's record.
+    //  Found in round 6 by an experimental build with 32-knot chunks on the obstacle batch, whose Cholesky restarts are real.)
     int slot = 0, k_top = N - 1;
     auto flush = [&]() __attribute__((always_inline)) {
       for (int i = lane; i < slot * 4 * R::KP; i += kBlock) {
@@ -902,7 +896,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
         pin(idx);
         sKDf[idx] = (T)(RS)KD;  // as stored
       } else {
-        int idx = (commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : CHUNK * 4 * R::KP + lane;
+        int idx = (commit && offKD >= 0) ? (slot * 4 + blk) * R::KP + offKD : kBwdChunk * 4 * R::KP + lane;
         pin(idx);
         sKD[idx] = KD;
       }
@@ -910,10 +904,6 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
       need = need && !gave_up;
       slot++;
       if (SPEC && nbar && (k & (kSyncFused - 1)) == 0) {  // the forward waves' barrier of this stretch of knots
-        __builtin_amdgcn_s_barrier();
-        ++*nbar;
-      }
-      if (BARG > 0 && nbar && (k & (BARG - 1)) == 0 && *nbar < bar_cap) {  // (k_sweep_loop: wave-uniform)
         __builtin_amdgcn_s_barrier();
         ++*nbar;
       }
@@ -931,7 +921,7 @@ ALTRO_DEV void backward_mfma_body(const DevArrays<T>& A, const DevOpts& o, int a
         if (k - j == 0) return false;
       }
       k -= H;
-      if (!FUSED && slot + H > CHUNK) flush();
+      if (!FUSED && slot + H > kBwdChunk) flush();
       return true;
     };
     for (;;) {
@@ -3199,10 +3189,7 @@ struct FwdSpec {
   double* inbox;  // {rho, drho} the pass assumed
   bool armed;     // speculate in this forward pass (the previous line search was rejected: a streak is likely)
 };
-// RBAR (k_sweep_loop): barrier R is taken by every wave whether or not a winner is replayed, so that the number of
-// workgroup barriers of a forward pass is a constant the loop kernel's fourth wave can match (staging, N / G + 1 in the knot
-// loop, A, S, R, V).
-template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false, bool SOFT = false, bool SEG = true, bool RBAR = false>
+template <class T, class M, bool FUSED, int SRC = kSrcLds, bool HOISTC = false, bool SOFT = false, bool SEG = true>
 ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd,
                              const DevOpts& o, int mode, int all, int per_wave, unsigned char* smem_raw,
                              const double* fh, int* active_out = nullptr, T* sCand = nullptr, double* ff = nullptr,
@@ -3444,8 +3431,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
       const int* selr = reinterpret_cast<const int*>(xch);
       const int trep = valid ? selr[2 * grp] : -1;
       const bool need = trep >= 0 && CL.needs_replay(trep);
-      const bool replay_any = __ballot(need) != 0ull;
-      if (replay_any) {
+      if (__ballot(need) != 0ull) {
         if (need) {
           alpha = T(1);
           for (int i = 0; i < trep; ++i) alpha /= T(o.line_search_decrease_factor);
@@ -3463,8 +3449,8 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
 #pragma unroll
           for (int i = 0; i < n; ++i) cand[i] = xb[i];
         }
+        __syncthreads();  // (drains the stores: s_waitcnt vmcnt(0) in front of the barrier) -- "R"
       }
-      if (replay_any || RBAR) __syncthreads();  // (drains the stores: s_waitcnt vmcnt(0) in front of the barrier) -- "R"
     }
     ALTRO_STAMP_ADD(1, st_w0b);
     const long long st_w0c = ALTRO_STAMP_T0();
@@ -3520,7 +3506,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     ALTRO_STAMP_ADD(7, st_w2);
     sy.signal_a();  // barrier A
     sy.await_s();   // barrier S
-    if (RBAR || wg_replays()) __syncthreads();  // barrier R: the rollout wave has rewritten the shared candidate slot
+    if (wg_replays()) __syncthreads();  // barrier R: the rollout wave has rewritten the shared candidate slot
     {
       const int* sel = reinterpret_cast<const int*>(xch);
       T* vpart2 = xch + 12;
@@ -3661,7 +3647,7 @@ ALTRO_DEV void forward2_body(const DevArrays<T>& A, const ProblemDesc* __restric
     }
   }
   sy.signal_s();  // barrier S: selection visible, candidate stores of this wave drained
-  if (RBAR || wg_replays()) __syncthreads();  // barrier R (see the rollout wave)
+  if (wg_replays()) __syncthreads();  // barrier R (see the rollout wave)
   ALTRO_STAMP_ADD(4, st_w1b);
   const long long st_w1c = ALTRO_STAMP_T0();
   T viol = T(0);
@@ -4675,17 +4661,16 @@ enum LoopWord {
   kLwUnits = 2,     // (instance, iteration) units this launch ran
   kLwMaxLoops = 3,  // most iterations one workgroup ran
   kLwGroups = 4,    // workgroups that ran at least one iteration
-  kLwTicks = 8,     // [4] 100 MHz ticks all workgroups spent in: slot bookkeeping, E, B beside F, - (diagnostics: ALTRO_HIP_LOOP_LOG)
+  kLwTicks = 8,     // [4] 100 MHz ticks all workgroups spent in: slot bookkeeping, E, B, F (diagnostics: ALTRO_HIP_LOOP_LOG)
   kLwCursor = 16,   // [8] instances handed out of each XCD's range
   kLwWords = 24
 };
 struct LoopCtl {
-  int* win;        // [gridDim.x][2][4]: the instances in the slots of the workgroup's two windows (-1: empty; [3] is always empty)
+  int* win;        // [gridDim.x][4]: the instances in the workgroup's slots this iteration (-1: empty; [3] is always empty)
   int* ctl;        // [kLwWords], zeroed by the host before the launch
   int* tail_list;  // [handover + slots of the launch]: what is handed to the persistent tail kernel
   int handover;    // unfinished instances of the batch at or below which the workgroups hand over and leave
   int per_xcd;     // instances per XCD range (a multiple of 16: the instances of one 128-byte line of the row arrays)
-  int bwd_off;     // byte offset of the recursion wave's gain buffer in the workgroup's LDS (behind the forward block)
 };
 constexpr int kLoopXcds = 8;
 #ifndef ALTRO_LOOP_BWD_AHEAD
@@ -4725,51 +4710,37 @@ ALTRO_DEV int loop_pull(const LoopCtl& lc, int B, int xcd, int want, int* out) {
 #else
 #define ALTRO_LOOP_F_ATTR ALTRO_DEV
 #endif
-constexpr int kLoopBwdChunk = 32;  // knots of gains the loop's recursion wave buffers in LDS between two bulk stores (8.4 KB)
-template <class T, class M, int G>
-ALTRO_LOOP_B_ATTR void loop_backward(const DevArrays<T>& Aw, const DevOpts& o, int lane, double* sKD, int* nbar, int bar_cap) {
-  backward_mfma_body<T, M, false, false, false, kLoopBwdAhead, kLoopBwdChunk, G>(Aw, o, 0, lane, 0, sKD, nullptr, 0, nullptr, 0.0, 0.0, nbar,
-                                                                                 -1, bar_cap);
+template <class T, class M>
+ALTRO_LOOP_B_ATTR void loop_backward(const DevArrays<T>& Aw, const DevOpts& o, int lane, double* sKD) {
+  backward_mfma_body<T, M, false, false, false, kLoopBwdAhead>(Aw, o, 0, lane, 0, sKD, nullptr, 0, nullptr);
 }
 template <class T, class M, int SRC>
 ALTRO_LOOP_F_ATTR void loop_forward(const DevArrays<T>& Aw, const ProblemDesc* __restrict__ pdg, const ProblemDesc* pd, const DevOpts& o,
                                     int mode, int per_wave, unsigned char* smem_raw) {
-  forward2_body<T, M, false, SRC, false, false, true, true>(Aw, pdg, pd, o, mode, 0, per_wave, smem_raw, nullptr, nullptr, nullptr, nullptr,
-                                                            nullptr, nullptr, FwdSync<false>{nullptr, 0}, nullptr, nullptr, nullptr, 0, 0, -1, 0);
+  forward2_body<T, M, false, SRC>(Aw, pdg, pd, o, mode, 0, per_wave, smem_raw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  FwdSync<false>{nullptr, 0}, nullptr, nullptr, nullptr, 0, 0, -1, 0);
 }
-// PIPELINE OF TWO WINDOWS (round 6, second version).  The first version ran E -> B -> F for ONE window of three instances:
-// two of its three waves idled during the recursion (a third of every iteration), and 1 536 instances in flight lost against
-// the 4 096 of the chains of sweeps.  Now a workgroup has FOUR waves and TWO windows.  In every phase the window that has its
-// gains (X) runs its forward pass on waves 0 - 2 while wave 3 runs the recursion of the other window (Y), whose expansions all
-// four waves computed just before; then the windows swap.  Wave 3 is part of the workgroup, so it takes as many workgroup
-// barriers as the forward pass does (a constant, see RBAR): one per G knots inside its recursion -- the forward waves' pace --
-// and the rest behind it.  An instance is only ever handed over (or refilled) at an iteration boundary: a window that has had
-// its recursion always runs its forward pass before the bookkeeping looks at it again.
 template <class T, class M, int SRC>
-__global__ __launch_bounds__((kFwdWaves + 1) * kBlock, kLoopMinBlocks) void k_sweep_loop(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
-                                                                                              const ProblemDesc pd_arg, DevOpts o, int mode, LoopCtl lc) {
-  constexpr int PW = kBlock / kLineSearchLanes;  // slots of a window (instances per wave of the forward pass)
+__global__ __launch_bounds__(kFwdWaves * kBlock, kLoopMinBlocks) void k_sweep_loop(DevArrays<T> A, const ProblemDesc* __restrict__ pdg,
+                                                                        const ProblemDesc pd_arg, DevOpts o, int mode, LoopCtl lc) {
+  constexpr int PW = kBlock / kLineSearchLanes;  // slots of a workgroup (instances per wave of the forward pass)
   static_assert(PW <= 3, "a window holds four entries, the fourth stays empty for the backward pass's fourth block");
-  constexpr int kThreads = (kFwdWaves + 1) * kBlock;
-  constexpr int G = fwd_sync_batched<M, SRC>();
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __shared__ int s_slot[2][4];
+  __shared__ int s_slot[4];
   __shared__ int s_go;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int N = A.N;
-  // workgroup barriers of one forward pass of this kernel: staging, N / G + 1 in the knot loop, A, S, R, V
-  const int fwd_bars = 1 + (N / G + 1) + 4;
-  double* const sKDb = reinterpret_cast<double*>(smem_raw + lc.bwd_off);  // the recursion's gain buffer, behind the forward block
-  int* const win = lc.win + (size_t)blockIdx.x * 8;                       // [2][4]
-  // what the bodies of the batched kernels see: a list of four entries -- a window -- and nobody to append to
+  int* const win = lc.win + (size_t)blockIdx.x * 4;
+  // what the bodies of the batched kernels see: a list of four entries -- this workgroup's window -- and nobody to append to
   DevArrays<T> Aw = A;
+  Aw.act_list = win;
   Aw.act_count = nullptr;
   Aw.act_count_const = 4;
   Aw.next_list = nullptr;
   Aw.next_count = nullptr;
   Aw.host_count = nullptr;
   Aw.seg_end = nullptr;
-  if (tid < 8) (&s_slot[0][0])[tid] = -1;
+  if (tid < 4) s_slot[tid] = -1;
   int loops = 0, units = 0;
   int ticks[4] = {0, 0, 0, 0};
   long long t_mark = wall_clock64();
@@ -4780,85 +4751,67 @@ __global__ __launch_bounds__((kFwdWaves + 1) * kBlock, kLoopMinBlocks) void k_sw
       t_mark = now;
     }
   };
-  // slots of window w (thread 0): drop what has finished, hand over or refill; returns whether the window runs an iteration
-  auto bookkeep = [&](int w) __attribute__((always_inline)) -> int {
-    int* const sl = s_slot[w];
-    int fin = 0, held = 0;
-    for (int g = 0; g < PW; ++g) {
-      const int b = sl[g];
-      if (b < 0) continue;
-      if (A.phase[b] != 1) {
-        sl[g] = -1;
-        ++fin;
-      } else {
-        ++held;
-      }
-    }
-    const int done = fin ? atomicAdd(lc.ctl + kLwFinished, fin) + fin
-                         : __hip_atomic_load(lc.ctl + kLwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int xcd = (int)(blockIdx.x % kLoopXcds);
-    int go = 0;
-    if (A.B - done <= lc.handover) {
-      // the tail: whatever this window holds, and whatever nobody has started yet, goes to the persistent kernel
-      for (int g = 0; g < PW; ++g) {
-        if (sl[g] >= 0) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = sl[g];
-        sl[g] = -1;
-      }
-      int b1;
-      while (loop_pull(lc, A.B, xcd, 1, &b1) == 1) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = b1;
-    } else {
-      if (held < PW) {
-        int fresh[PW];
-        const int got = loop_pull(lc, A.B, xcd, PW - held, fresh);
-        for (int g = 0, j = 0; g < PW && j < got; ++g)
-          if (sl[g] < 0) sl[g] = fresh[j++];
-        held += got;
-      }
-      go = held > 0 ? 1 : 0;
-      units += held;
-    }
-    for (int g = 0; g < 4; ++g) win[4 * w + g] = sl[g];
-    return go;
-  };
   __syncthreads();
-  int X = 0;          // the window that has had its recursion (workgroup-uniform)
-  bool has_x = false;  // ... and holds instances
   for (;;) {
-    const int Y = X ^ 1;
-    if (tid == 0) s_go = bookkeep(Y);
+    if (tid == 0) {
+      // ---- slots: drop what has finished, hand over or refill ----
+      int fin = 0, held = 0;
+      for (int g = 0; g < PW; ++g) {
+        const int b = s_slot[g];
+        if (b < 0) continue;
+        if (A.phase[b] != 1) {
+          s_slot[g] = -1;
+          ++fin;
+        } else {
+          ++held;
+        }
+      }
+      const int done = fin ? atomicAdd(lc.ctl + kLwFinished, fin) + fin
+                           : __hip_atomic_load(lc.ctl + kLwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int xcd = (int)(blockIdx.x % kLoopXcds);
+      int go = 0;
+      if (A.B - done <= lc.handover) {
+        // the tail: whatever this workgroup holds, and whatever nobody has started yet, goes to the persistent kernel
+        for (int g = 0; g < PW; ++g) {
+          if (s_slot[g] >= 0) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = s_slot[g];
+          s_slot[g] = -1;
+        }
+        int b1;
+        while (loop_pull(lc, A.B, xcd, 1, &b1) == 1) lc.tail_list[atomicAdd(lc.ctl + kLwTail, 1)] = b1;
+      } else {
+        if (held < PW) {
+          int fresh[PW];
+          const int got = loop_pull(lc, A.B, xcd, PW - held, fresh);
+          for (int g = 0, j = 0; g < PW && j < got; ++g)
+            if (s_slot[g] < 0) s_slot[g] = fresh[j++];
+          held += got;
+        }
+        go = held > 0 ? 1 : 0;
+        units += held;
+      }
+      for (int g = 0; g < 4; ++g) win[g] = s_slot[g];
+      s_go = go;
+    }
     __syncthreads();  // (s_waitcnt vmcnt(0) in front of the barrier: the window is in memory)
-    const bool go_y = s_go != 0;
-    if (!go_y && !has_x) break;
+    if (!s_go) break;
     ++loops;
     mark(0);
-    if (go_y) {
-      // ---- E: iLQR::UpdateExpansions (ilqr.hpp:670-677) of window Y, one (instance, knot) per thread and round ----
-      for (int u = tid; u < PW * (N + 1); u += kThreads) {
-        const int g = u / (N + 1), k = u - g * (N + 1);
-        const int b = s_slot[Y][g];
-        if (b >= 0) expansion_body<T, M>(A, pdg, b, k);
-      }
-      __syncthreads();
-    }
-    mark(1);
-    if (wave == kFwdWaves) {
-      // ---- B: iLQR::BackwardPass (ilqr.hpp:385-445) of window Y, one 4 x 4 x 4 block per slot, beside the forward pass of X ----
-      const int bars = has_x ? fwd_bars : 0;
-      int nbar = 0;
-      if (go_y) {
-        Aw.act_list = win + 4 * Y;
-        loop_backward<T, M, G>(Aw, o, lane, sKDb, has_x ? &nbar : nullptr, bars);
-      }
-      for (; nbar < bars; ++nbar) __builtin_amdgcn_s_barrier();
-    } else if (has_x) {
-      // ---- F: iLQR::ForwardPass + the state machine (ilqr.hpp:512-619, al_solver.hpp:313-401) of window X ----
-      Aw.act_list = win + 4 * X;
-      loop_forward<T, M, SRC>(Aw, pdg, &pd_arg, o, mode, PW, smem_raw);
+    // ---- E: iLQR::UpdateExpansions (ilqr.hpp:670-677) of the slots' instances, one (instance, knot) per thread and round ----
+    for (int u = tid; u < PW * (N + 1); u += kFwdWaves * kBlock) {
+      const int g = u / (N + 1), k = u - g * (N + 1);
+      const int b = s_slot[g];
+      if (b >= 0) expansion_body<T, M>(A, pdg, b, k);
     }
     __syncthreads();
+    mark(1);
+    // ---- B: iLQR::BackwardPass (ilqr.hpp:385-445) on wave 0, one 4 x 4 x 4 block per slot ----
+    if (wave == 0) loop_backward<T, M>(Aw, o, lane, reinterpret_cast<double*>(smem_raw));
+    __syncthreads();
     mark(2);
-    X = Y;
-    has_x = go_y;
+    // ---- F: iLQR::ForwardPass + the state machine (ilqr.hpp:512-619, al_solver.hpp:313-401) on the three waves ----
+    loop_forward<T, M, SRC>(Aw, pdg, &pd_arg, o, mode, PW, smem_raw);
+    __syncthreads();
+    mark(3);
   }
   if (tid == 0 && loops > 0) {
     for (int i = 0; i < 4; ++i) atomicAdd(lc.ctl + kLwTicks + i, ticks[i]);

@@ -94,6 +94,44 @@ def test_cholesky_restart_path(P, A, oracle_make, hip_make):
     assert np.allclose(Xg, Xo, rtol=1e-9, atol=1e-11)  # (measured 1e-15)
 
 
+def test_cholesky_restart_beside_finished_instances(A, oracle_make, hip_make):
+    """A restarted sweep beside instances that do not need one, on a horizon of more than one gain chunk (N = 160 > 126).
+    Even instances start inside their control bounds: R is indefinite, Quu + rho I fails its factorisation and the sweep
+    restarts until the regularisation has grown.  Odd instances start beyond both bounds: the active AL terms add the penalty
+    to Quu's diagonal and their first sweep goes through.  The four instances of a wavefront of k_backward_mfma are two of
+    each kind, so the restarted sweeps run with finished neighbours -- whose LDS slots the bulk store used to write out as
+    well (after the first chunk they hold other knots' gains; round 6).  Gains of the one backward pass against the oracle."""
+    def build(make):
+        N, B = 160, 640
+        s = make(3, 2, N, B, A.F64)
+        s.set_model(A.MODEL_UNICYCLE)
+        s.set_uniform_step(np.float32(0.05))
+        xf = np.tile(np.array([1.0, 0.5, 0.3]), (B, 1)) + np.linspace(0, 0.3, B)[:, None]
+        R = np.diag([-2e-3, 1e-3])
+        s.set_lqr_cost(0, N, np.eye(3) * 1e-3, R, xf, np.zeros(2))
+        s.set_lqr_cost(N, N + 1, np.eye(3) * 10.0, R * 0, xf, np.zeros(2))
+        s.add_control_bound(0, N, [-0.1, -0.1], [0.1, 0.1])
+        s.set_initial_state(np.zeros(3))
+        U = np.zeros((B, N, 2))
+        U[0::2] = 0.05
+        U[1::2] = 0.5
+        s.set_trajectory(None, U)
+        s.set_options(max_iterations_inner=1, max_iterations_outer=1)
+        return s
+    o, g = build(oracle_make), build(hip_make)
+    o.solve(); g.solve()
+    so, sg = o.get_stats(), g.get_stats()
+    assert (so["regularization"][0::2] > 0.1).all() and (so["regularization"][1::2] == 0).all()  # restarts on the even ones only
+    assert g.get_timing()["fused_sweeps"] == 0  # (the batched kernels ran: the backward pass with the chunked store)
+    assert (so["status"] == sg["status"]).all() and (so["iterations_total"] == sg["iterations_total"]).all()
+    assert np.allclose(sg["regularization"], so["regularization"], rtol=1e-12)
+    Ko, do = o.get_gains()
+    Kg, dg = g.get_gains()
+    for b in range(len(Ko)):
+        assert np.linalg.norm(Kg[b] - Ko[b]) <= 1e-9 * np.linalg.norm(Ko[b]), b
+    assert np.allclose(dg, do, rtol=1e-8, atol=1e-10)
+
+
 def test_state_limit_and_rejected_line_search(P, oracle_make, hip_make):
     """Huge feedforward steps: rollouts blow through state_max (kStateLimit) for large alpha and the line
     search has to back off; with a tiny state_max every trial fails and the status must say so."""

@@ -516,6 +516,18 @@ def test_horizon_lengths_and_ragged_batches(P, A, oracle_make, hip_make, no_fuse
         _compare_full(o, g)
 
 
+def test_long_horizon_with_cholesky_restarts(P, A, oracle_make, hip_make):
+    """N > 126: the MFMA recursion (k_backward_mfma) buffers 126 knots of gains in LDS between two bulk stores, so a pass of
+    160 knots is two chunks.  The obstacle batch has real Cholesky restarts (ilqr.hpp:409-427): a wavefront then runs another
+    sweep for the instance that failed while the three others of the wavefront sit it out -- and round 6 found the bulk store
+    writing THEIR slots too, which after the first chunk hold other knots' gains (one-chunk passes rewrote the same values).
+    Exact schedules against the oracle for every instance."""
+    o, g = both(P, P.batch_three_obstacles, oracle_make, hip_make, batch=768, N=160, dtype=A.F64)
+    o.solve(); g.solve()
+    assert g.get_timing()["sweeps"] > g.get_timing()["fused_sweeps"]  # (batched sweeps ran: the kernel with the chunks)
+    _compare_full(o, g)
+
+
 def test_setters_are_ordered_against_the_solver_stream(P, A, hip_make):
     """The engine's stream does not synchronise with the null stream: a trajectory handed over with SetTrajectory must be
     the one ResetTrajectory restores and the one the next solve starts from, however soon those calls follow (a
