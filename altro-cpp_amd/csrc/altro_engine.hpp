@@ -78,7 +78,6 @@ class Engine final : public EngineBase {
   altro_status Init() {
     ALTRO_HIP_CHECK(hipSetDevice(desc_.device_id));
     ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    ALTRO_HIP_CHECK(hipEventCreateWithFlags(&spec_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
     ALTRO_HIP_CHECK(hipEventCreateWithFlags(&tail_ev_, hipEventDisableTiming | hipEventBlockingSync));
     cur_ = stream_;
@@ -741,9 +740,6 @@ class Engine final : public EngineBase {
     d_iota_ = d_merged_ = nullptr;
     d_loop_win_ = d_loop_ctl_ = d_loop_tail_ = nullptr;
     loop_groups_ = 0;
-    d_spec_go_ = nullptr;
-    d_spec_io_ = nullptr;
-    d_spec_kd_ = nullptr;
     X_init_ = U_init_ = nullptr;
     d_phi_ = nullptr;
     d_pd_ = nullptr;
@@ -772,8 +768,6 @@ class Engine final : public EngineBase {
     }
     if (start_ev_) hipEventDestroy(start_ev_);
     if (tail_ev_) hipEventDestroy(tail_ev_);
-    if (stream2_) hipStreamDestroy(stream2_);
-    if (spec_ev_) hipEventDestroy(spec_ev_);
     if (stream_) hipStreamDestroy(stream_);
   }
   altro_status DownloadVec(const double* dev, double* out) {
@@ -1343,18 +1337,6 @@ class Engine final : public EngineBase {
           counted_chained_ = false;
         }
       }
-      // (a stream for the helper workgroups of ALTRO_HIP_SPECULATION=helper only where no chain stream is there to carry
-      //  them -- the chains are idle during the tail: the streams of a process share four hardware queues, and a
-      //  persistent kernel blocks whatever queues up behind it)
-      if (spec_mode_ == kSpecHelper && chains_ == 1 && !stream2_)
-        ALTRO_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-    }
-    if constexpr (kMfmaBackward) {
-      if (spec_mode_ == kSpecHelper) {  // hand-over buffers of the helper workgroups (SpecRemote)
-        ALTRO_ALLOC(d_spec_go_, 2 * (size_t)bp);
-        ALTRO_ALLOC(d_spec_io_, 10 * (size_t)bp);
-        ALTRO_ALLOC(d_spec_kd_, (size_t)bp * N_ * R::KP);
-      }
     }
     ALTRO_ALLOC(X_init_, (size_t)(N_ + 1) * R::nP * bp);
     ALTRO_ALLOC(U_init_, (size_t)N_ * R::mP * bp);
@@ -1535,8 +1517,6 @@ class Engine final : public EngineBase {
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecWave>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecHelper>),
-                                     reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecHelper>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecFree>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecFree>)};
           for (const void* fn : variants)
@@ -2062,45 +2042,32 @@ class Engine final : public EngineBase {
           circles = circles || pd_.runs[r].fast == kFastC || pd_.runs[r].fast == kFastCB || pd_.runs[r].fast == kFastBC;
         // (with a fourth wave that runs the next iteration's backward pass beside the forward pass: see the kernel)
         int* const out = loop_launched ? d_loop_ctl_ + kLwWords : d_counter_ + max_sweeps + 2;
-        SpecRemote<T> rs{};
         const int spec_mode_ = this->spec_mode_ == kSpecAuto ? (circles ? (int)kSpecWave : (int)kSpecFree) : this->spec_mode_;
         // twin workgroups (TwinCtl): one behind every primary, dispatched after all of them (same launch, higher block
-        // indices); not with a recorded history (its rows are appended in iteration order) nor in helper mode
+        // indices); not with a recorded history (its rows are appended in iteration order)
         TwinCtl tw{};
-        if (twin_cap_ > 0 && !A.hist && spec_mode_ != kSpecHelper && !d.fast_forward_stalls) {
+        if (twin_cap_ > 0 && !A.hist && !d.fast_forward_stalls) {
           if (!twin_box_clean_)  // (cleared by k_begin_solve otherwise: nothing touches the mailboxes before this launch)
             hipMemsetAsync(d_twin_box_, 0, (size_t)twin_cap_ * (kTwWords + 1) * sizeof(unsigned long long), stream_);
           tw = TwinCtl{d_twin_box_, d_twin_box_ + (size_t)twin_cap_ * kTwWords, ninst, twin_cap_, Bp_ - twin_cap_, kTwinLag, twin_debug_ ? 1 : 0};
         }
         const dim3 g(ninst + (tw.base > 0 ? std::min(ninst, twin_cap_) : 0)), b3(kFwdWaves * kBlock), b4((kFwdWaves + 1) * kBlock);
         timing_.twin_workgroups = tw.base > 0 ? (int)g.x - ninst : 0;  // twin workgroups of this launch
-        if (spec_mode_ == kSpecHelper) {
-          // the helper workgroups (one wave per straggler) run on a second stream beside the persistent kernel
-          rs = SpecRemote<T>{d_spec_go_, d_spec_go_ + Bp_, d_spec_io_, d_spec_io_ + 2 * (size_t)Bp_, d_spec_kd_};
-          hipMemsetAsync(d_spec_go_, 0, 2 * (size_t)Bp_ * sizeof(int), stream_);
-          hipEventRecord(spec_ev_, stream_);
-          hipStreamWaitEvent(HelperStream(), spec_ev_, 0);
-          const size_t hl = ((size_t)N_ * R::KP + kBlock) * sizeof(T) + 16 * sizeof(double);
-          hipLaunchKernelGGL((k_spec_helper<T, M>), dim3(ninst), dim3(kBlock), hl, HelperStream(), A, d, rs);
-          spec_helper_running_ = true;
-        }
 #define ALTRO_FUSED(CC, S, BLK) \
-  hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw)
+  hipLaunchKernelGGL((k_sweep_fused<T, M, CC, S>), g, BLK, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, tw)
         if (any_split()) {
           // columns of split streaks may be in the lists: the variants that verify / retire / cancel them in the loop's
           // bookkeeping step (every other launch runs the kernels as they were before the segments existed)
           if (circles)
-            hipLaunchKernelGGL((k_sweep_fused<T, M, true, kSpecWave, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw);
+            hipLaunchKernelGGL((k_sweep_fused<T, M, true, kSpecWave, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, tw);
           else
-            hipLaunchKernelGGL((k_sweep_fused<T, M, false, kSpecFree, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, rs, tw);
+            hipLaunchKernelGGL((k_sweep_fused<T, M, false, kSpecFree, true>), g, b4, fused_lds_bytes_, stream_, A, d_pd_, pd_, d, mode, 1, out, tw);
         } else if (circles) {
-          if (spec_mode_ == kSpecHelper) ALTRO_FUSED(true, kSpecHelper, b3);
-          else if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
+          if (spec_mode_ == kSpecWave) ALTRO_FUSED(true, kSpecWave, b4);
           else if (spec_mode_ == kSpecFree) ALTRO_FUSED(true, kSpecFree, b4);
           else ALTRO_FUSED(true, kSpecOff, b3);
         } else {
-          if (spec_mode_ == kSpecHelper) ALTRO_FUSED(false, kSpecHelper, b3);
-          else if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
+          if (spec_mode_ == kSpecWave) ALTRO_FUSED(false, kSpecWave, b4);
           else if (spec_mode_ == kSpecFree) ALTRO_FUSED(false, kSpecFree, b4);
           else ALTRO_FUSED(false, kSpecOff, b3);
         }
@@ -2128,10 +2095,6 @@ class Engine final : public EngineBase {
     }
     for (int c = 1; c < C; ++c) ALTRO_HIP_CHECK(hipStreamSynchronize(chain[c].st));
     ALTRO_HIP_CHECK(hipStreamSynchronize(stream_));
-    if (spec_helper_running_) {
-      ALTRO_HIP_CHECK(hipStreamSynchronize(HelperStream()));
-      spec_helper_running_ = false;
-    }
     ALTRO_HIP_CHECK(hipGetLastError());
     if (any_split()) {
       // chains of segments: the last valid column of each over the instance's own (k_seg_fixup; a workgroup per instance,
@@ -2326,8 +2289,7 @@ class Engine final : public EngineBase {
   bool force_valu_backward_ = BackwardEnvIs("valu");
   bool force_coop_backward_ = BackwardEnvIs("coop");
   bool dense_expansions_ = std::getenv("ALTRO_HIP_NO_DENSE_EXPANSIONS") == nullptr;
-  // speculative backward pass of the persistent kernel: on its fourth wave (default), in helper workgroups
-  // (ALTRO_HIP_SPECULATION=helper), or not at all (=off)
+  // speculative backward pass of the persistent kernel: on its fourth wave (default) or not at all (ALTRO_HIP_SPECULATION=off)
   // (default, kSpecAuto: the fourth wave -- free-running beside software-synchronised forward waves where the rollout
   //  wave paces the knot loop, in lock step on problems with circle constraints, whose knot loop is paced by the cost
   //  wave: there the sequence words only add their polls.  Measured per tail iteration: config 2 46.0 -> 42.0 us free,
@@ -2335,19 +2297,11 @@ class Engine final : public EngineBase {
   static constexpr int kSpecAuto = -1;
   int spec_mode_ = [] {
     const char* e = std::getenv("ALTRO_HIP_SPECULATION");
-    if (e && std::string(e) == "helper") return (int)kSpecHelper;
     if (e && std::string(e) == "off") return (int)kSpecOff;
     if (e && std::string(e) == "free") return (int)kSpecFree;
     if (e && std::string(e) == "wave") return (int)kSpecWave;
     return kSpecAuto;
   }();
-  hipStream_t stream2_ = nullptr;
-  hipStream_t HelperStream() const { return chains_ > 1 ? chain_stream_[1] : stream2_; }
-  hipEvent_t spec_ev_ = nullptr;
-  bool spec_helper_running_ = false;
-  int* d_spec_go_ = nullptr;      // [2][Bp]: request tags, delivered tags
-  double* d_spec_io_ = nullptr;   // [Bp][2] in, [Bp][8] out
-  T* d_spec_kd_ = nullptr;        // [Bp][N * KP]
   bool kdg_ = false;  // forward pass reads the feedback gains from global memory (k_forward2<.., kSrcKdg>)
   bool rg_ = false;   // ... all of the rollout wave's per-knot inputs (k_forward2<.., kSrcGlb>)
   int fwd_per_wave_ = kBlock / kLineSearchLanes;

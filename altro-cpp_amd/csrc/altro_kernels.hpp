@@ -3769,24 +3769,13 @@ ALTRO_DEV void expansion_from_lds(const DevArrays<T>& A, const ProblemDesc* pd, 
 // the tail sits in exactly that regime (a line search that rejects all 20 trials, iteration after iteration), so the
 // two serial chains of an iteration overlap: 64 -> ~40 us.  Same arithmetic on the same inputs: same bits
 // (ALTRO_HIP_SPECULATION=off runs the three-wave kernel).
-// SPEC = kSpecHelper: the speculative pass runs in a workgroup of its own (k_spec_helper, one wave, any CU with a free
-// SIMD) at its own pace instead of in lock step with the forward waves' barriers; regularisation in, gains and
-// hand-over values out travel through global memory with release / acquire flags at agent scope.  Neither side ever
-// blocks on the other: this kernel waits a bounded number of polls for a result and otherwise runs the recursion
-// itself, the helper gives up after a bounded number of idle polls.
+// (Rounds 2 - 5 also had a HELPER mode -- the speculative pass in a workgroup of its own, one wave on any CU with a free SIMD,
+//  results through global memory with release / acquire flags: it won with a few dozen stragglers and lost on a full tail
+//  (config 2 5.27 -> 5.52 ms), was never a default, and went in round 6 with its two kernel variants: git history.)
 // SPEC = kSpecFree: the fourth wave again, but the three forward waves synchronise through sequence words in LDS instead of
 // workgroup barriers (FwdSync<true>), so the recursion and the knot loop each run at their own pace instead of in lock step.
-enum SpecMode { kSpecOff = 0, kSpecWave = 1, kSpecHelper = 2, kSpecFree = 3 };
+enum SpecMode { kSpecOff = 0, kSpecWave = 1, kSpecFree = 3 };
 ALTRO_DEV constexpr bool spec_has_wave4(int spec) { return spec == kSpecWave || spec == kSpecFree; }
-template <class T>
-struct SpecRemote {
-  int* go;      // [Bp] tag of the pass requested by the instance's workgroup (-1: finished)
-  int* done;    // [Bp] tag of the pass the helper has delivered
-  double* in;   // [Bp][2] regularisation to assume
-  double* out;  // [Bp][8] dV0, dV1 / 2, rho, drho after DecreaseRegularization, rho used, ok
-  T* kd;        // [Bp][N * KP] gains
-};
-constexpr int kSpecPolls = 400;  // polls of the result flag before the recursion is run locally (~0.1 us each)
 
 // -------------------------------------------------------------------------------------------------
 // TWIN WORKGROUPS (round 5): the second half of a straggler's rejection streak, computed beside the first half.
@@ -3872,7 +3861,7 @@ ALTRO_DEV double tw_dbl(unsigned long long x) { return __longlong_as_double((lon
 template <class T, class M, bool CIRC, int SPEC, bool SEG = false>
 __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock) void k_sweep_fused(
     DevArrays<T> A, const ProblemDesc* __restrict__ pdg, const ProblemDesc pd_arg, DevOpts o, int mode, int persistent,
-    int* sweeps_out, SpecRemote<T> rs, TwinCtl tw) {
+    int* sweeps_out, TwinCtl tw) {
   constexpr int kThreads = (spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) * kBlock;
   constexpr bool kWave4 = spec_has_wave4(SPEC), kSoft = SPEC == kSpecFree;
   using R = Rec<T, M::n, M::m>;
@@ -3911,7 +3900,6 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
   T* sKD2 = sCand + (size_t)(N + 1) * kLineSearchLanes * nm;
   double* fh2 = reinterpret_cast<double*>(sKD2 + N * R::KP + kBlock);
   FwdSpec<T> spec{sKD2, N * R::KP, fh2, fh2 + 8, false};
-  int* const remote_ok = reinterpret_cast<int*>(fh2 + 10);  // helper mode: the poll's verdict for the workgroup
   T* const alpha_tab = reinterpret_cast<T*>(fh2 + 12);      // [20] step lengths of the line-search lanes (ilqr.hpp:544)
   int* const sync_words = reinterpret_cast<int*>(fh2 + 12 + kLineSearchLanes);  // [kSyWords] FwdSync<true> (kSpecFree), E ahead
   if (tid < kSyWords) sync_words[tid] = 0;  // (visible behind the staging barrier of the first iteration)
@@ -3922,17 +3910,6 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     for (int i = 0; i < tid; ++i) alpha /= T(o.line_search_decrease_factor);
     alpha_tab[tid] = alpha;
   }
-  int tag = 0;
-  // helper mode: ask for the backward pass of the next iteration under the regularisation a rejected step will set
-  auto request = [&]() __attribute__((always_inline)) {
-    double rho_in = fh[4], drho_in = fh[5];
-    increase_reg(o, &rho_in, &drho_in);
-    fh2[8] = rho_in;
-    fh2[9] = drho_in;
-    rs.in[2 * (size_t)b] = rho_in;
-    rs.in[2 * (size_t)b + 1] = drho_in;
-    __hip_atomic_store(rs.go + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  };
   bool adopt = false;
   bool prev_rej = false;
   double prev_rho = -1.0, prev_drho = -1.0;
@@ -4149,27 +4126,16 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     if (wave == 0 && adopt) ALTRO_STAMP_ADD(9, st_it);
     const long long st_b = ALTRO_STAMP_T0();
 
-    if (SPEC != kSpecOff) ++tag;  // (wave-uniform: every thread counts)
     // speculate only in a streak of rejections (ff: phase 3 of the previous iteration, rewritten by this one's): a
-    // converging instance accepts its steps, a recursion beside its forward pass would only slow that down, and the
-    // release fence of a request to the helper is not free
+    // converging instance accepts its steps, and a recursion beside its forward pass would only slow that down
     const bool armed = SPEC != kSpecOff && loops > 0 && ff[0] != 0.0;
     if (SPEC && adopt) {
       const long long st_cp = ALTRO_STAMP_T0();
-      // ---- B was run ahead (fourth wave / helper workgroup) during the previous forward pass: take its results ----
-      if (SPEC == kSpecHelper) {
-        const T* src = rs.kd + (size_t)b * (size_t)(N * R::KP);
-        for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = src[i];
-      } else {
-        for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = sKD2[i];
-      }
+      // ---- B was run ahead (fourth wave) during the previous forward pass: take its results ----
+      for (int i = tid; i < N * R::KP; i += kThreads) sKDf[i] = sKD2[i];
       if (tid == 0) {
         double h[6];
-        if (SPEC == kSpecHelper) {
-          for (int q = 0; q < 5; ++q) h[q] = rs.out[8 * (size_t)b + q];
-        } else {  // (the fourth wave's hand-over values)
-          h[0] = fh2[1]; h[1] = fh2[2]; h[2] = fh2[4]; h[3] = fh2[5]; h[4] = fh2[6];
-        }
+        h[0] = fh2[1]; h[1] = fh2[2]; h[2] = fh2[4]; h[3] = fh2[5]; h[4] = fh2[6];  // (the fourth wave's hand-over values)
         fh[1] = h[0];
         fh[2] = h[1];
         fh[4] = h[2];
@@ -4179,14 +4145,12 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
         A.reg_log[b] = h[4];  // stats_.Log("reg", rho_)
         A.rho_reg[b] = h[2];
         A.drho[b] = h[3];
-        if (SPEC == kSpecHelper) request();  // (adopted = in a streak of rejections)
       }
       if (wave == 0) ALTRO_STAMP_ADD(16, st_cp);
     } else if (wave == 0) {
       // ---- B ----
       backward_mfma_body<T, M, false, true>(A, o, 0, lane, blockIdx.x, nullptr, sKDf, fused_junk, fh, 0.0, 0.0, nullptr, b);
       // (its own LDS writes of fh[4], fh[5]: program order)
-      if (SPEC == kSpecHelper && lane == 0 && armed) request();
     }
     // (the running cost J0 of the expansion step is summed by the auxiliary wave during the forward pass: aux_wave_run)
     if (SPEC && adopt) lds_barrier(); else __syncthreads();
@@ -4241,24 +4205,6 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     // the speculation holds if the line search rejected every trial, the inner solve goes on (no dual / penalty
     // update: ff[3]) and phase 3 set exactly the regularisation the speculative pass assumed
     if (kWave4) adopt = armed && fh2[7] != 0.0 && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
-    if (SPEC == kSpecHelper) {
-      const bool mine = armed && ff[0] != 0.0 && ff[3] == 0.0 && ff[1] == fh2[8] && ff[2] == fh2[9];
-      if (tid == 0) {
-        int ok = 0;
-        if (mine) {
-          for (int tries = 0; tries < kSpecPolls; ++tries) {
-            if (__hip_atomic_load(rs.done + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag) {
-              ok = rs.out[8 * (size_t)b + 5] != 0.0 ? 1 : 0;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        *remote_ok = ok;
-      }
-      lds_barrier();
-      adopt = *remote_ok != 0;
-    }
     if (o.fast_forward_stalls) {
       // OPT-IN, off by default.  A rejected line search leaves the trajectory, the multipliers and -- once
       // the regularisation has settled into its increase/decrease cycle -- the whole state of the instance
@@ -4526,57 +4472,9 @@ __global__ __launch_bounds__((spec_has_wave4(SPEC) ? kFwdWaves + 1 : kFwdWaves) 
     using RS = rec_scalar_t<T, M>;
     if (e < (Rec<RS, M::n, M::m>::KP)) RECP((RS*)A.KD, k, (Rec<RS, M::n, M::m>::KP))[e] = (RS)sKDf[i];
   }
-  if (SPEC == kSpecHelper && tid == 0) __hip_atomic_store(rs.go + b, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   report(tw_loops0 + loops + skipped, loops);
 }
 
-// The speculative backward passes of k_sweep_fused<.., kSpecHelper>: one wavefront per straggler, on whatever CU has
-// a SIMD to spare.  Polls the instance's request tag, runs backward_mfma_body<.., SPEC> (no barriers: nbar = nullptr)
-// under the regularisation it is handed, publishes gains and hand-over values, repeats; leaves when the instance's
-// workgroup says so (tag -1) or after kSpecIdlePolls polls without a new request (never a hang).
-constexpr long long kSpecIdlePolls = 4000000;
-template <class T, class M>
-__global__ __launch_bounds__(kBlock) void k_spec_helper(DevArrays<T> A, DevOpts o, SpecRemote<T> rs) {
-  using R = Rec<T, M::n, M::m>;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  const int b = instance_of_slot(A, blockIdx.x, 0);
-  if (b < 0) return;
-  const int N = A.N;
-  T* sKD = reinterpret_cast<T*>(smem_raw);  // [N * KP] gains + one junk slot per lane
-  double* fh2 = reinterpret_cast<double*>(sKD + N * R::KP + kBlock);
-  int last = 0;
-  for (long long idle = 0; idle < kSpecIdlePolls;) {
-    int tag = 0;
-    if (lane == 0) tag = __hip_atomic_load(rs.go + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    tag = __shfl(tag, 0);
-    if (tag < 0) break;
-    if (tag == last) {
-      __builtin_amdgcn_s_sleep(8);
-      ++idle;
-      continue;
-    }
-    idle = 0;
-    last = tag;
-    const double rho_in = rs.in[2 * (size_t)b], drho_in = rs.in[2 * (size_t)b + 1];
-    if (lane == 0) fh2[7] = 0.0;
-    backward_mfma_body<T, M, false, true, true>(A, o, 0, lane, blockIdx.x, nullptr, sKD, N * R::KP, fh2, rho_in, drho_in, nullptr);
-    __syncthreads();
-    T* dst = rs.kd + (size_t)b * (size_t)(N * R::KP);
-    for (int i = lane; i < N * R::KP; i += kBlock) dst[i] = sKD[i];
-    if (lane == 0) {
-      double* out = rs.out + 8 * (size_t)b;
-      out[0] = fh2[1];
-      out[1] = fh2[2];
-      out[2] = fh2[4];
-      out[3] = fh2[5];
-      out[4] = fh2[6];
-      out[5] = fh2[7];
-    }
-    __threadfence();
-    if (lane == 0) __hip_atomic_store(rs.done + b, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 // The last valid column of every chain of segments (DevArrays::seg_*) over the instance's own: one workgroup per instance,
 // follows seg_next while the column it stands on has retired (= its successor started from exactly the state it arrived

@@ -109,7 +109,7 @@ np.savez(sys.argv[1], **out)
 
 @pytest.mark.parametrize("switch", [{"ALTRO_HIP_NO_DENSE_EXPANSIONS": "1"}, {"ALTRO_HIP_FWD_SRC": "global"},
                                     {"ALTRO_HIP_FWD_SRC": "lds"}, {"ALTRO_HIP_FWD_PER_WAVE": "1"},
-                                    {"ALTRO_HIP_SPECULATION": "off"}, {"ALTRO_HIP_SPECULATION": "helper"},
+                                    {"ALTRO_HIP_SPECULATION": "off"},
                                     {"ALTRO_HIP_SPECULATION": "free"}, {"ALTRO_HIP_SPECULATION": "wave"},
                                     {"ALTRO_HIP_SPECULATION": "free", "ALTRO_HIP_DEBUG_POISON": "12345678,mix"},
                                     {"ALTRO_HIP_SWEEP_LOOP": "0"}, {"ALTRO_HIP_SWEEP_LOOP": "1", "ALTRO_HIP_LOOP_PER_CU": "1"},
