@@ -1511,7 +1511,7 @@ class Engine final : public EngineBase {
         if (fused_lds_bytes_ > 64 * 1024 && fused_lds_bytes_ <= 160 * 1024)
         {
           // (+ the two variants that know the segments of rejection streaks: default speculation modes only, see Solve)
-          const void* variants[10] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecFree, true>),
+          const void* variants[] = {reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecFree, true>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecWave, true>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, false, kSpecOff>),
                                      reinterpret_cast<const void*>(&k_sweep_fused<T, M, true, kSpecOff>),
