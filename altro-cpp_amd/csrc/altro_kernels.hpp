@@ -3837,7 +3837,14 @@ constexpr unsigned long long kTwOk = 1, kTwRefused = 2, kTwRevoked = 3;
 //   kTwsLocked  a twin has taken the slot (compare-and-swap kTwsSnap -> kTwsSnap | kTwsLocked), or has found it not worth it
 constexpr unsigned long long kTwsSnap = 1, kTwsClosed = 2, kTwsLocked = 4;
 constexpr int kTwinMinRemaining = 12;   // iterations left in a streak below which a twin is not worth its start-up
-constexpr int kTwinLag = 3;             // iterations the primary advances while the twin clones and stages
+// iterations of the primary's share that pay for the twin's start-up (claim seen, clone, one unspeculated iteration): the twin
+// takes the iterations from snapshot + (R + lag) / 2 + 1 on.  Round 6 (mailbox stamps of config 2, ALTRO_HIP_TWIN_DEBUG): with 3
+// the twins finished 15 - 140 us before their primaries handed over; with 1 the two sides end together (persistent launch 2.42 -
+// 2.48 -> 2.33 - 2.42 ms, config 3's 7.4 -> 6.6 ms; A/B builds -DALTRO_TWIN_LAG=n)
+#ifndef ALTRO_TWIN_LAG
+#define ALTRO_TWIN_LAG 1
+#endif
+constexpr int kTwinLag = ALTRO_TWIN_LAG;
 // polls (~3 us each) a twin waits for its primary to publish a streak.  The primary closes the mailbox when it finishes, so the
 // wait ends with the primary at the latest; the bound only guards against a primary that never runs.  (Round 5, first version:
 // 200 polls = 0.6 ms.  88 of ~100 stragglers of config 2 got their twin -- and the launch was as long as before: it ends with
