@@ -1685,15 +1685,16 @@ class Engine final : public EngineBase {
       ZeroJobs z{};
       int nz = 0;
       auto zero = [&](void* ptr, size_t words) {
+        if (nz >= kZeroJobs || !ptr || words == 0 || words > 0xffffffffull) return false;  // (the caller falls back to a memset)
         z.p[nz] = reinterpret_cast<unsigned*>(ptr);
         z.n[nz++] = (unsigned)words;
+        return true;
       };
-      if (seg_total_ + twin_cap_ > 0) zero(A_.phase + (Bp_ - seg_total_ - twin_cap_), (size_t)(seg_total_ + twin_cap_));
-      zero(d_counter_, (size_t)(C * cstride + 16));
-      if (twin_cap_ > 0) {
-        zero(d_twin_box_, (size_t)twin_cap_ * (kTwWords + 1) * 2);
-        twin_box_clean_ = true;
-      }
+      if (seg_total_ + twin_cap_ > 0 && !zero(A_.phase + (Bp_ - seg_total_ - twin_cap_), (size_t)(seg_total_ + twin_cap_)))
+        ALTRO_HIP_CHECK(hipMemsetAsync(A_.phase + (Bp_ - seg_total_ - twin_cap_), 0, (size_t)(seg_total_ + twin_cap_) * sizeof(int), stream_));
+      if (!zero(d_counter_, (size_t)(C * cstride + 16)))
+        ALTRO_HIP_CHECK(hipMemsetAsync(d_counter_, 0, (size_t)(C * cstride + 16) * sizeof(int), stream_));
+      if (twin_cap_ > 0) twin_box_clean_ = zero(d_twin_box_, (size_t)twin_cap_ * (kTwWords + 1) * 2);  // (else: cleared at the launch)
       size_t words = 0;
       for (int j = 0; j < nz; ++j) words += z.n[j];
       const int gx = (B_ + kBlock - 1) / kBlock;
